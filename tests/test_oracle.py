@@ -1,0 +1,142 @@
+"""CPU tests: the oracle (oracle/sit_oracle.py) against the golden vectors captured from the
+reference's own Python (oracle/make_golden.py), and the encoder restatement against an independent
+implementation (torch.nn.TransformerEncoderLayer).  No GPU."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detgen, sit_oracle
+from oracle.make_golden import MPP_CASES, SIT_CASES, mpp_case_inputs, sit_case_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DATA = os.path.join(ROOT, "surface-vision-transformers_amd", "data")
+
+
+def _table(k):
+    return np.load(os.path.join(DATA, f"ico6_sub_ico_{k}.npy"))
+
+
+def _load(module, seed):
+    vals = detgen.fill_state_dict(module.state_dict(), seed=seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+
+
+def test_detgen_is_stable():
+    a = detgen.normal("x", (5,), seed=1)
+    np.testing.assert_array_equal(a, detgen.normal("x", (5,), seed=1))
+    assert abs(float(detgen.normal("stat", (200000,)).mean())) < 0.01
+    assert abs(float(detgen.normal("stat", (200000,)).std()) - 1) < 0.01
+    r = detgen.randint("r", (1000,), 0, 7)
+    assert r.min() == 0 and r.max() == 6
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_gather_matches_reference_bit_exact(golden_dir, k):
+    g = np.load(os.path.join(golden_dir, "gather.npz"))
+    t = _table(k)
+    assert hashlib.sha256(t.tobytes()).digest() == g[f"table_sha256/sub_ico_{k}"].tobytes()
+    x = detgen.normal("gather/x", (2, 4, sit_oracle.ICO6_VERTICES), seed=1)
+    out = sit_oracle.gather_patches(x, t)
+    assert hashlib.sha256(out.tobytes()).digest() == g[f"sha256/sub_ico_{k}"].tobytes()
+    np.testing.assert_array_equal(out[:, :, :3, :5], g[f"corner/sub_ico_{k}"])
+    np.testing.assert_array_equal(out[:, :, -1, -5:], g[f"last/sub_ico_{k}"])
+    # channels-last north-star entry == rearranged reference layout
+    tok = sit_oracle.gather_tokens(np.ascontiguousarray(x.transpose(0, 2, 1)), t)
+    np.testing.assert_array_equal(tok, sit_oracle.tokens_from_patches(out))
+
+
+def test_table_invariants():
+    t1, t2 = _table(1).astype(int), _table(2).astype(int)
+    assert t1.shape == (80, 561) and t2.shape == (320, 153)
+    for t in (t1, t2):
+        assert len(np.unique(t)) == 40962
+        assert all(len(set(r)) == t.shape[1] for r in t)
+    for j in range(320):                                   # 4:1 nesting
+        assert set(t2[j]) <= set(t1[j // 4])
+    t3 = np.load(os.path.join(DATA, "ico6_sub_ico_3_synth.npy")).astype(int)
+    assert t3.shape == (1280, 45) and len(np.unique(t3)) == 40962
+    for j in range(1280):
+        assert set(t3[j]) <= set(t2[j // 4])
+
+
+@pytest.mark.parametrize("name", list(SIT_CASES))
+def test_sit_oracle_matches_reference_wrapper(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "sit.npz"))
+    kw, x, y = sit_case_inputs(name)
+    model = sit_oracle.SiT(**kw)
+    _load(model, 3)
+    out = model(torch.from_numpy(x))
+    loss = torch.nn.functional.mse_loss(out.squeeze(), torch.from_numpy(y).squeeze())
+    loss.backward()
+    np.testing.assert_allclose(out.detach().numpy(), g[f"{name}/out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{name}/loss"]), rtol=1e-5)
+    n = 0
+    for k, p in model.named_parameters():
+        gn = float(g[f"{name}/gnorm/{k}"])
+        np.testing.assert_allclose(float(p.grad.double().norm()), gn, rtol=2e-4, atol=1e-9)
+        np.testing.assert_allclose(p.grad.reshape(-1)[:8].numpy(), g[f"{name}/ghead/{k}"],
+                                   rtol=2e-3, atol=1e-6 * max(gn, 1e-3))
+        n += 1
+    assert n == 4 + 11 * kw["depth"] + 4          # SURVEY App. B key count
+
+
+@pytest.mark.parametrize("name", list(MPP_CASES))
+def test_mpp_oracle_matches_reference(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "mpp.npz"))
+    kw, x, probs, seed = mpp_case_inputs(name)
+    V = kw["num_vertices"]
+    model = sit_oracle.SiT(**kw)
+    ssl = sit_oracle.MaskedPatchPretraining(model, kw["dim"], 4 * V, channels=4, num_vertices=V, **probs)
+    _load(ssl, 5)
+    # (1) replay the seed: the draw order must reproduce the captured random tensors
+    torch.manual_seed(seed)
+    rnd = sit_oracle.draw_mpp_randoms(x.shape[0], kw["num_patches"], **probs)
+    for k, v in rnd.items():
+        np.testing.assert_array_equal(v.numpy(), g[f"{name}/rnd/{k}"])
+    import math
+    assert (rnd["corrupted_sequence"].sum(1) == math.ceil(probs["mask_prob"] * kw["num_patches"])).all()
+    # (2) forward/backward with the captured tensors
+    rnd = {k: torch.from_numpy(g[f"{name}/rnd/{k}"]) for k in rnd}
+    loss, out = ssl(torch.from_numpy(x), randoms=rnd)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{name}/loss"]), rtol=1e-5)
+    np.testing.assert_allclose(out.detach()[:, :4, :16].numpy(), g[f"{name}/out_head"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(out.double().sum()), float(g[f"{name}/out_sum"]), rtol=1e-4, atol=1e-2)
+    for k, p in ssl.named_parameters():
+        gn = float(g[f"{name}/gnorm/{k}"])
+        if gn < 0:                                # mlp_head gets no grad in MPP
+            assert p.grad is None and k.startswith("transformer.mlp_head")
+            continue
+        np.testing.assert_allclose(float(p.grad.double().norm()), gn, rtol=2e-4, atol=1e-9)
+    # dense form of the masked loss (what the HIP path computes) equals the boolean-index form
+    tok = sit_oracle.tokens_from_patches(x)
+    m = rnd["corrupted_sequence"].numpy()[..., None]
+    dense = (((out.detach().numpy() - tok) ** 2) * m).sum() / (m.sum() * tok.shape[-1])
+    np.testing.assert_allclose(dense, float(loss), rtol=1e-5)
+
+
+@pytest.mark.parametrize("dim,heads,mlp", [(192, 3, 768), (384, 6, 1536)])
+def test_encoder_block_matches_independent_torch_layer(dim, heads, mlp):
+    """Independent cross-check of the third-party block (parity unpinned by the reference):
+    nn.TransformerEncoderLayer(norm_first, gelu) with a zero in_proj_bias is the same function."""
+    torch.manual_seed(0)
+    enc = sit_oracle.Encoder(dim, 1, heads, 64, mlp)
+    _load(enc, 9)
+    ref = torch.nn.TransformerEncoderLayer(dim, heads, mlp, dropout=0.0, activation="gelu",
+                                           batch_first=True, norm_first=True)
+    a, f = enc.layers[0]
+    with torch.no_grad():
+        ref.self_attn.in_proj_weight.copy_(a.fn.to_qkv.weight)
+        ref.self_attn.in_proj_bias.zero_()
+        ref.self_attn.out_proj.weight.copy_(a.fn.to_out[0].weight)
+        ref.self_attn.out_proj.bias.copy_(a.fn.to_out[0].bias)
+        ref.norm1.weight.copy_(a.norm.weight); ref.norm1.bias.copy_(a.norm.bias)
+        ref.norm2.weight.copy_(f.norm.weight); ref.norm2.bias.copy_(f.norm.bias)
+        ref.linear1.weight.copy_(f.fn.net[0].weight); ref.linear1.bias.copy_(f.fn.net[0].bias)
+        ref.linear2.weight.copy_(f.fn.net[3].weight); ref.linear2.bias.copy_(f.fn.net[3].bias)
+    ref.train()  # keep the slow (math) path
+    x = torch.from_numpy(detgen.normal("blk/x", (2, 321, dim), seed=1))
+    np.testing.assert_allclose(enc(x).detach().numpy(), ref(x).detach().numpy(), rtol=1e-4, atol=2e-5)
