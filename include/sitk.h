@@ -1,0 +1,246 @@
+/* sitk.h -- C ABI of libsitk.so: the MI355X (gfx950) native SiT training hot path.
+ *
+ * The reference (SD3004/surface-vision-transformers) has no FFI layer: its boundary for this path
+ * is the nn.Module API of models/sit.py:26-82 and models/mpp.py:46-134 plus the third-party
+ * vit_pytorch.vit.Transformer it constructs at models/sit.py:57.  Every entry point below cites
+ * the reference lines whose arithmetic it replaces.  The Python mirror of those modules
+ * (surface-vision-transformers_amd/models/{sit,mpp}.py) binds these symbols with ctypes.
+ *
+ * Conventions:
+ *   - plain C: raw DEVICE pointers, explicit sizes / leading dimensions (in ELEMENTS), a
+ *     hipStream_t passed as void*; no torch types, no allocation, no ownership transfer,
+ *     no host synchronisation, no global mutable state.  Every call only ENQUEUES work on
+ *     `stream` and is re-entrant (a communication stream may run concurrently).
+ *   - return 0 on success, <0 on error; sitk_last_error() returns a thread-local message.
+ *   - `dtype` selects the COMPUTE/STORAGE type of activations and weight copies:
+ *       SITK_BF16  bf16 operands, v_mfma_f32_16x16x32_bf16, fp32 accumulate   (benchmark mode)
+ *       SITK_F32   f32 operands,  v_mfma_f32_16x16x4_f32 (exact fp32)          (parity mode)
+ *     LayerNorm statistics, softmax, GELU, the residual stream, every gradient of a parameter
+ *     and the optimizer state are fp32 in both modes.
+ *   - all pointers 16-byte aligned; feature counts (dim, mlp_dim, heads*64, patch_dim) and leading
+ *     dimensions multiples of 8.
+ */
+#ifndef SITK_H
+#define SITK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SITK_F32 0
+#define SITK_BF16 1
+
+#define SITK_OK 0
+#define SITK_ERR_INVALID (-1)
+#define SITK_ERR_LAUNCH (-2)
+
+#define SITK_ABI_VERSION 1
+
+typedef void* sitk_stream_t; /* hipStream_t */
+
+int sitk_abi_version(void);
+const char* sitk_last_error(void);
+/* size in bytes of one element of `dtype` (4 or 2) */
+int sitk_dtype_size(int dtype);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1-a3  Patch gather.  tools/preprocessing.py:74-84 (out[s,c,j,v] = X[s,c,table[v,j]]) fused with
+ * Rearrange('b c n v -> b n (v c)') of models/sit.py:49 / models/mpp.py:82-83.
+ *   x_bvc     (B, n_vertices, C) fp32, channels last (C == 4)
+ *   table_pv  (P, V) uint16, PATCH-major vertex ids (ids < n_vertices)
+ *   tokens    (B*P, ld) `dtype`; columns [0, V*C) are written as f = v*C + c, columns
+ *             [V*C, ld) are zero-filled (ld >= V*C, multiple of 8) so GEMM K-tiles need no tail.
+ * Integer-indexed copy: bit exact in SITK_F32; one RNE rounding per element in SITK_BF16.      */
+int sitk_gather_tokens(const float* x_bvc, const uint16_t* table_pv, void* tokens, int B, int n_vertices,
+                       int C, int P, int V, int ld, int dtype, sitk_stream_t stream);
+
+/* Drop-in layout of the reference: x_bcpv (B, C, P, V) fp32 (models/sit.py:47-49) -> tokens as above. */
+int sitk_patchify(const float* x_bcpv, void* tokens, int B, int C, int P, int V, int ld, int dtype,
+                  sitk_stream_t stream);
+
+/* rows x cols fp32 (leading dim lds) -> `dtype` (leading dim ldd >= cols, pad columns zeroed). */
+int sitk_cast_rows(const float* src, int lds, void* dst, int ldd, int64_t rows, int cols, int dtype,
+                   sitk_stream_t stream);
+
+/* Weight staging for one Linear: w (rows, cols) fp32 ->
+ *   w_c (rows, ldc) `dtype`  [pad zeroed]   used as  Y = X W^T      (nn.Linear forward)
+ *   w_t (cols, ldt) `dtype`  = W^T          used as dX = dY W       (input gradient)
+ * either destination may be NULL.                                                               */
+int sitk_stage_weight(const float* w, int rows, int cols, void* w_c, int ldc, void* w_t, int ldt, int dtype,
+                      sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM  C[m][n] = sum_k A[m][k] W[n][k]  (nn.Linear: models/sit.py:50,63; the encoder's to_qkv,
+ * to_out.0, net.0, net.3; models/mpp.py:66) with fused epilogues.                               */
+typedef struct {
+  int group;  /* 0: identity.  else physical_row(m) = (m / group) * stride + offset + m % group */
+  int stride;
+  int offset;
+} sitk_rowmap;
+
+#define SITK_EPI_STORE 0     /* out = acc (+bias)                                  out_dtype any  */
+#define SITK_EPI_BIAS_RES 1  /* out(f32) = acc + bias + aux(f32)   residual / pos-embedding add   */
+#define SITK_EPI_BIAS_GELU 2 /* out = u = acc + bias ; out2 = gelu_erf(u)          both `dtype`   */
+#define SITK_EPI_DGELU 3     /* out = acc * gelu_erf'(aux)          aux = saved u, both `dtype`   */
+
+typedef struct {
+  int M, N, K;
+  const void* A; /* (M, K): `dtype`, or fp32 when a_is_f32 (converted while staging)        */
+  int lda;
+  int a_is_f32;
+  sitk_rowmap amap;
+  const void* W; /* (N, K) `dtype`                                                           */
+  int ldw;
+  int epilogue;
+  void* out;
+  int ldo;
+  int out_is_f32;
+  sitk_rowmap omap;
+  void* out2;
+  const float* bias; /* (N) or NULL */
+  const void* aux;
+  int ldaux;
+  sitk_rowmap auxmap;
+} sitk_gemm_desc;
+
+int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream);
+
+/* Weight gradient: dW[n][k] += sum_m dY[m][n] X[m][k]   (fp32 accumulate with float atomics
+ * across token chunks), optionally db[n] += sum_m dY[m][n].
+ *   dY (M, N): `dtype` or fp32 (dy_is_f32); X (M, K) `dtype`; row maps as above.               */
+typedef struct {
+  int M, N, K;
+  const void* dY;
+  int lddy;
+  int dy_is_f32;
+  sitk_rowmap dymap;
+  const void* X;
+  int ldx;
+  sitk_rowmap xmap;
+  float* dW; /* (N, lddw) fp32, accumulated */
+  int lddw;
+  float* db; /* (N) fp32 accumulated, or NULL */
+} sitk_wgrad_desc;
+
+int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (eps 1e-5, biased variance, affine): the PreNorm norms of the
+ * encoder (state-dict keys transformer.layers.i.{0,1}.norm, utils/utils.py:18-22).
+ *   x (rows, D) fp32 -> y (rows, D) `dtype`; mean/rstd (rows) fp32 saved for backward.          */
+int sitk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
+                       float* rstd, int64_t rows, int D, int dtype, sitk_stream_t stream);
+/* dx_out (fp32) = dres (fp32, may be NULL, may alias dx_out) + LN'(dy); dgamma/dbeta accumulated. */
+int sitk_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
+                       const float* gamma, const float* dres, float* dx_out, float* dgamma, float* dbeta,
+                       int64_t rows, int D, int dtype, sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-head self-attention core of vit_pytorch.vit.Attention (dim_head = 64):
+ * softmax((q k^T) * scale) v, flash-style (the (B,H,N,N) matrix is never materialised).
+ *   qkv (B*N, 3*H*64) `dtype`: columns [q | k | v], each (h d) h-major   (to_qkv + chunk(3))
+ *   o   (B*N, H*64) `dtype`, 'b h n d -> b n (h d)'
+ *   lse (B, H, N) fp32: log-sum-exp of the scaled scores (natural log), saved for backward.    */
+int sitk_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int dtype,
+                       sitk_stream_t stream);
+/* dqkv (B*N, 3*H*64) `dtype` <- gradients of q, k, v.  delta (B,H,N) fp32 is scratch.          */
+int sitk_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                       void* dqkv, int B, int N, int H, float scale, int dtype, sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole encoder = vit_pytorch.vit.Transformer(dim, depth, heads, dim_head=64, mlp_dim, dropout=0)
+ * as constructed at models/sit.py:57 and called at models/sit.py:76 / models/mpp.py:128:
+ * depth x [ x += to_out(attn(to_qkv(LN(x)))) ; x += W2 gelu(W1 LN(x) + b1) + b2 ].             */
+typedef struct {
+  int B, N, dim, depth, heads, mlp_dim; /* dim_head fixed at 64 */
+  int dtype;
+} sitk_encoder_cfg;
+
+/* Per-layer fp32 parameter (or gradient) pointers, in state-dict order. */
+typedef struct {
+  float* ln1_w; /* layers.i.0.norm.weight        (dim)            */
+  float* ln1_b; /* layers.i.0.norm.bias          (dim)            */
+  float* wqkv;  /* layers.i.0.fn.to_qkv.weight   (3*H*64, dim)    */
+  float* wo;    /* layers.i.0.fn.to_out.0.weight (dim, H*64)      */
+  float* bo;    /* layers.i.0.fn.to_out.0.bias   (dim)            */
+  float* ln2_w; /* layers.i.1.norm.weight        (dim)            */
+  float* ln2_b; /* layers.i.1.norm.bias          (dim)            */
+  float* w1;    /* layers.i.1.fn.net.0.weight    (mlp_dim, dim)   */
+  float* b1;    /* layers.i.1.fn.net.0.bias      (mlp_dim)        */
+  float* w2;    /* layers.i.1.fn.net.3.weight    (dim, mlp_dim)   */
+  float* b2;    /* layers.i.1.fn.net.3.bias      (dim)            */
+} sitk_layer_params;
+
+/* Bytes of the caller-provided workspaces. `acts` holds what backward needs (saved activations
+ * + staged weights) and must stay untouched between fwd and bwd; `scratch` is transient.      */
+size_t sitk_encoder_acts_bytes(const sitk_encoder_cfg* cfg);
+size_t sitk_encoder_scratch_bytes(const sitk_encoder_cfg* cfg);
+
+/* x_in (B*N, dim) fp32 -> x_out (B*N, dim) fp32.  save_for_backward = 0 runs the forward-only
+ * (inference) schedule that keeps no activations (acts then only needs the staged weights).   */
+int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* params, const float* x_in,
+                     float* x_out, void* acts, size_t acts_bytes, void* scratch, size_t scratch_bytes,
+                     int save_for_backward, sitk_stream_t stream);
+
+/* dx (B*N, dim) fp32: on entry d(loss)/d(x_out), on exit d(loss)/d(x_in) (in place).
+ * grads: fp32, ACCUMULATED into (zero them or keep earlier micro-batches' sums).
+ * Layers are processed last to first; [layer_begin, layer_end) selects a slice so that the caller
+ * can interleave gradient all-reduce buckets with the rest of backward.                        */
+int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* params,
+                     const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
+                     size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,
+                     sitk_stream_t stream);
+
+/* Row 0 of every sample of the residual stream: x[b, 0, :] = cls_token + pos_embedding[0, :]
+ * (models/sit.py:70-73; rows 1..P come from the patch-embedding GEMM's BIAS_RES epilogue).      */
+int sitk_embed_cls_rows(float* x, const float* cls_token, const float* pos, int B, int N, int D,
+                        sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Pool + head: models/sit.py:78-82 (x[:,0] or mean over tokens; LayerNorm(dim); Linear(dim, classes)). */
+int sitk_head_fwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
+                  float* logits, int B, int N, int D, int n_classes, int pool_mean, sitk_stream_t stream);
+/* dx (B*N, D) fp32 is fully written (zeros outside the pooled rows); parameter grads accumulated. */
+int sitk_head_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* dlogits,
+                  float* dx, float* d_ln_w, float* d_ln_b, float* d_w, float* d_b, int B, int N, int D,
+                  int n_classes, int pool_mean, sitk_stream_t stream);
+
+/* Regression losses of tools/train.py:245-248 on (n) predictions: loss[0] (+)= mean (p-t)^2 or
+ * mean |p-t|; dpred = d loss / d pred.  loss must be zeroed by the caller.                      */
+int sitk_loss_fwd_bwd(const float* pred, const float* target, float* loss, float* dpred, int n, int l1,
+                      sitk_stream_t stream);
+
+/* column sums: out[c] += sum_r in[r][c]  (d_pos_embedding / d_cls_token over the batch) */
+int sitk_colsum_f32(const float* in, int64_t rows, int cols, int ld, float* out, sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Masked patch pre-training, models/mpp.py:85-112 and :132.
+ *   tokens (B*P, K) fp32 clean tokens; corrupted (B*P, ld) `dtype` (pad zeroed)
+ *   masked / swap_draw / replace_draw (B*P) uint8; random_patches (B*P) int32 in [0, P)
+ *   swap = masked & swap_draw (source row: clean tokens of random_patches, same sample);
+ *   replace = masked & replace_draw (applied second, wins): row = mask_token (K) fp32.          */
+int sitk_mpp_corrupt(const float* tokens, const uint8_t* masked, const uint8_t* swap_draw,
+                     const int32_t* random_patches, const uint8_t* replace_draw, const float* mask_token,
+                     void* corrupted, int B, int P, int K, int ld, int dtype, sitk_stream_t stream);
+/* loss[0] += sum_{masked rows} (out - tokens)^2 / (n_masked_total * K); dout likewise (0 elsewhere). */
+int sitk_mpp_loss_fwd_bwd(const float* out, const float* tokens, const uint8_t* masked, float* loss,
+                          float* dout, int64_t rows, int K, int64_t n_masked_total, sitk_stream_t stream);
+/* out[c] += sum over rows with flag[r] != 0 of in[r][c]   (mask_token gradient, stage 1) */
+int sitk_masked_colsum(const void* in, int ld, int in_is_f32, int dtype, const uint8_t* flag_a,
+                       const uint8_t* flag_b, int64_t rows, int cols, float* out, sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer of tools/train.py:228-243,291: SGD(momentum, weight_decay, nesterov) / Adam / AdamW
+ * over one flat fp32 parameter buffer.  grad_scale multiplies the gradient first (1/world).    */
+int sitk_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                  float weight_decay, int nesterov, float grad_scale, sitk_stream_t stream);
+int sitk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
+                   float grad_scale, sitk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SITK_H */

@@ -1,0 +1,378 @@
+// sitk fused multi-head self-attention (dim_head = 64) for gfx950, forward and backward.
+// softmax((q k^T) * scale) v without materialising the (B, H, N, N) score matrix
+// (vit_pytorch.vit.Attention as used by models/sit.py:57,76 and models/mpp.py:128).
+//
+// All three kernels are built from two MFMA products over 64-row LDS tiles ([rows][64] of T):
+//   row_mma : S[t](16 tile rows x 16 lanes) = sum_d tile[16t+i][d] * frag(lane)[d]      (row reads)
+//   tr_mma64: O[dt][d=16dt+i][lane] += sum_r tile[r][16dt+i] * P[r][lane]                (transposed reads)
+// where P is the accumulator of a row_mma (lane l holds rows 16t + 4*(l>>4) + jj of column l&15):
+// the accumulator is reused in registers as the next product's B operand, the LDS tile supplies the
+// A operand through ds_read_b64_tr_b16 (bf16) or ds_read_b32 (f32), so the query (forward, dQ) or
+// key (dK/dV) index stays on lane&15 through the whole kernel and per-row softmax state is per-lane.
+#include "common.h"
+
+namespace sitk {
+
+template <typename T>
+struct AttnGeom {
+  static constexpr int RB = 64 * (int)sizeof(T);  // bytes per head row: 128 (bf16) / 256 (f32)
+  static constexpr int KS = RB / 64;              // mma steps across dim_head
+  static constexpr int NPAN = RB / 128;           // 128-byte panels per row
+  static constexpr int CPR = RB / 16;             // 16-byte chunks per row
+  static constexpr int CH = 64 * CPR / 256;       // chunks per thread per 64-row tile
+  static constexpr int EPV = 16 / (int)sizeof(T);
+  static constexpr int TILE_BYTES = 64 * RB;
+};
+
+// stage 64 rows x 64 elements (row r <- src + r*ld, zero when row0 + r >= nrows) into an LDS tile
+template <typename T>
+SITK_DEV void stage_tile(char* tile, const T* __restrict__ src, size_t ld, int row0, int nrows, int tid) {
+  using G = AttnGeom<T>;
+#pragma unroll
+  for (int i = 0; i < G::CH; ++i) {
+    const int c = tid + 256 * i, row = c / G::CPR, cc = c % G::CPR;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row0 + row < nrows) v = *reinterpret_cast<const u32x4*>(src + (size_t)(row0 + row) * ld + cc * G::EPV);
+    *reinterpret_cast<u32x4*>(tile + ((cc * 16) / 128) * (64 * 128) + lds_off(row, (cc * 16) % 128)) = v;
+  }
+}
+
+template <typename T>
+SITK_DEV u32x4 row_frag(const char* tile, int row, int ks, int fq) {
+  return *reinterpret_cast<const u32x4*>(tile + (ks >> 1) * (64 * 128) + lds_off(row, (ks & 1) * 64 + fq * 16));
+}
+
+// s[t] += tile rows (16t + i) . frag       (frag: this lane's 16-byte chunks of its own row)
+template <typename T>
+SITK_DEV void row_mma(f32x4 (&s)[4], const char* tile, const u32x4 (&frag)[AttnGeom<T>::KS], int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < AttnGeom<T>::KS; ++ks)
+      s[t] = Mma<T>::mma(row_frag<T>(tile, 16 * t + fr, ks, fq), frag[ks], s[t]);
+}
+
+template <typename T>
+struct TrMma;
+
+template <>
+struct TrMma<bf16> {
+  static SITK_DEV void run(f32x4 (&o)[4], const f32x4 (&p)[4], const char* tile, int lane) {
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 pb;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pb[e] = (bf16)p[2 * s2][e]; pb[e + 4] = (bf16)p[2 * s2 + 1][e]; }
+      const u32x4 pf = __builtin_bit_cast(u32x4, pb);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int row = 32 * s2 + 4 * g + q, cb = (16 * dt + 4 * pp) * 2;
+        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) i16x4*)(tile + lds_off(row, cb)));
+        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) i16x4*)(tile + lds_off(row + 16, cb)));
+        u32x4 vf;
+        vf[0] = __builtin_bit_cast(u32x2, lo)[0];
+        vf[1] = __builtin_bit_cast(u32x2, lo)[1];
+        vf[2] = __builtin_bit_cast(u32x2, hi)[0];
+        vf[3] = __builtin_bit_cast(u32x2, hi)[1];
+        o[dt] = Mma<bf16>::mma(vf, pf, o[dt]);
+      }
+    }
+  }
+};
+
+template <>
+struct TrMma<float> {
+  static SITK_DEV void run(f32x4 (&o)[4], const f32x4 (&p)[4], const char* tile, int lane) {
+    const int g = lane >> 4, fr = lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int row = 16 * t + 4 * g + jj;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int col = 16 * dt + fr;  // 32 floats per panel
+          const float a = *reinterpret_cast<const float*>(tile + (col >> 5) * (64 * 128) + lds_off(row, (col & 31) * 4));
+          o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, p[t][jj], o[dt], 0, 0, 0);
+        }
+      }
+  }
+};
+
+SITK_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+SITK_DEV float xor_max4(float v) {  // reduce over the 4 lanes sharing lane&15
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+SITK_DEV float xor_sum4(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// ------------------------------------------------------------------------------------------
+// forward: grid (ceil(N/64), H, B); wave w owns query rows 64*bx + 16w + (lane&15)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ o,
+                                                       float* __restrict__ lse, int N, int H, float scale) {
+  using G = AttnGeom<T>;
+  __shared__ __attribute__((aligned(256))) char smem[2 * G::TILE_BYTES];
+  char* sK = smem;
+  char* sV = smem + G::TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, I = H * 64;
+  const size_t ld = (size_t)3 * I;
+  const int q = blockIdx.x * 64 + 16 * wave + fr, qc = min(q, N - 1);
+  const T* base = qkv + (size_t)b * N * ld;
+
+  u32x4 qf[G::KS];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks)
+    qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + (ks * 64 + fq * 16) / (int)sizeof(T));
+
+  const float c = scale * kLog2e;
+  float m = -1e30f, l = 0.f;
+  f32x4 oacc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    __syncthreads();
+    stage_tile<T>(sK, base + I + h * 64, ld, k0, N, tid);
+    stage_tile<T>(sV, base + 2 * I + h * 64, ld, k0, N, tid);
+    __syncthreads();
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    row_mma<T>(s, sK, qf, lane);
+    float mx = -1e30f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int key = k0 + 16 * t + 4 * fq + jj;
+        s[t][jj] = key < N ? s[t][jj] * c : -INFINITY;
+        mx = fmaxf(mx, s[t][jj]);
+      }
+    mx = xor_max4(mx);
+    const float mn = fmaxf(m, mx);
+    const float alpha = fast_exp2(m - mn);
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float pv = fast_exp2(s[t][jj] - mn);
+        s[t][jj] = pv;
+        ps += pv;
+      }
+    l = l * alpha + ps;
+    m = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+    TrMma<T>::run(oacc, s, sV, lane);
+  }
+  const float lt = xor_sum4(l);
+  const float inv = 1.0f / lt;
+  if (q < N) {
+    T* orow = o + ((size_t)b * N + q) * I + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt + 4 * fq, oacc[dt] * inv);
+    if (fq == 0) lse[((size_t)b * H + h) * N + q] = (m + __log2f(lt)) * kLn2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, query side: dQ (and delta = rowsum(dO * O), written for the key-side kernel).
+// Same decomposition as forward.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ o,
+                                                          const T* __restrict__ d_o, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, T* __restrict__ dqkv, int N,
+                                                          int H, float scale) {
+  using G = AttnGeom<T>;
+  __shared__ __attribute__((aligned(256))) char smem[2 * G::TILE_BYTES];
+  char* sK = smem;
+  char* sV = smem + G::TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, I = H * 64;
+  const size_t ld = (size_t)3 * I;
+  const int q = blockIdx.x * 64 + 16 * wave + fr, qc = min(q, N - 1);
+  const T* base = qkv + (size_t)b * N * ld;
+
+  u32x4 qf[G::KS], dof[G::KS];
+  float dpart = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) {
+    const int eo = (ks * 64 + fq * 16) / (int)sizeof(T);
+    qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
+    const T* dop = d_o + ((size_t)b * N + qc) * I + h * 64 + eo;
+    const T* op = o + ((size_t)b * N + qc) * I + h * 64 + eo;
+    dof[ks] = *reinterpret_cast<const u32x4*>(dop);
+#pragma unroll
+    for (int e = 0; e < G::EPV; ++e) dpart += to_f32(dop[e]) * to_f32(op[e]);
+  }
+  const float dl = xor_sum4(dpart);
+  const size_t ridx = ((size_t)b * H + h) * N + qc;
+  if (q < N && fq == 0) delta[ridx] = dl;
+  const float Lq = lse[ridx] * kLog2e;
+  const float c = scale * kLog2e;
+
+  f32x4 dq[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    __syncthreads();
+    stage_tile<T>(sK, base + I + h * 64, ld, k0, N, tid);
+    stage_tile<T>(sV, base + 2 * I + h * 64, ld, k0, N, tid);
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    row_mma<T>(s, sK, qf, lane);
+    row_mma<T>(dp, sV, dof, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int key = k0 + 16 * t + 4 * fq + jj;
+        const float pv = key < N ? fast_exp2(s[t][jj] * c - Lq) : 0.f;
+        s[t][jj] = pv * (dp[t][jj] - dl) * scale;
+      }
+    TrMma<T>::run(dq, s, sK, lane);
+  }
+  if (q < N) {
+    T* row = dqkv + ((size_t)b * N + q) * ld + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt + 4 * fq, dq[dt]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, key side: dK, dV.  grid (ceil(N/64), H, B); wave w owns keys 64*bx + 16w + (lane&15)
+// and sweeps all queries in 64-row stages (Q and dO tiles in LDS, K and V fragments in registers).
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ d_o,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           T* __restrict__ dqkv, int N, int H, float scale) {
+  using G = AttnGeom<T>;
+  __shared__ __attribute__((aligned(256))) char smem[2 * G::TILE_BYTES + 2 * 64 * 4];
+  char* sQ = smem;
+  char* sDO = smem + G::TILE_BYTES;
+  float* sL = reinterpret_cast<float*>(smem + 2 * G::TILE_BYTES);
+  float* sD = sL + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z, I = H * 64;
+  const size_t ld = (size_t)3 * I;
+  const int key = blockIdx.x * 64 + 16 * wave + fr, kc = min(key, N - 1);
+  const T* base = qkv + (size_t)b * N * ld;
+  const T* dobase = d_o + (size_t)b * N * I;
+
+  u32x4 kf[G::KS], vf[G::KS];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks) {
+    const int eo = (ks * 64 + fq * 16) / (int)sizeof(T);
+    kf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo);
+    vf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + eo);
+  }
+  const float c = scale * kLog2e;
+  f32x4 dk[4], dv[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int q0 = 0; q0 < N; q0 += 64) {
+    __syncthreads();
+    stage_tile<T>(sQ, base + h * 64, ld, q0, N, tid);
+    stage_tile<T>(sDO, dobase + h * 64, (size_t)I, q0, N, tid);
+    if (tid < 64) {
+      const int qq = q0 + tid;
+      const size_t ridx = ((size_t)b * H + h) * N + min(qq, N - 1);
+      sL[tid] = qq < N ? lse[ridx] * kLog2e : INFINITY;
+      sD[tid] = qq < N ? delta[ridx] : 0.f;
+    }
+    __syncthreads();
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    row_mma<T>(s, sQ, kf, lane);
+    row_mma<T>(dp, sDO, vf, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 Lr = *reinterpret_cast<const f32x4*>(sL + 16 * t + 4 * fq);
+      const f32x4 Dr = *reinterpret_cast<const f32x4*>(sD + 16 * t + 4 * fq);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float pv = fast_exp2(s[t][jj] * c - Lr[jj]);
+        s[t][jj] = pv;
+        dp[t][jj] = pv * (dp[t][jj] - Dr[jj]) * scale;
+      }
+    }
+    TrMma<T>::run(dv, s, sDO, lane);
+    TrMma<T>::run(dk, dp, sQ, lane);
+  }
+  if (key < N) {
+    T* row = dqkv + ((size_t)b * N + key) * ld + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      store4(row + I + 16 * dt + 4 * fq, dk[dt]);
+      store4(row + 2 * I + 16 * dt + 4 * fq, dv[dt]);
+    }
+  }
+}
+
+template <typename T>
+static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
+  dim3 grid(cdiv(N, 64), H, B);
+  hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
+                     reinterpret_cast<T*>(o), lse, N, H, scale);
+  return check_launch("attention_fwd");
+}
+
+template <typename T>
+static int run_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
+                   int B, int N, int H, float scale, hipStream_t s) {
+  dim3 grid(cdiv(N, 64), H, B);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
+                     reinterpret_cast<const T*>(o), reinterpret_cast<const T*>(d_o), lse, delta,
+                     reinterpret_cast<T*>(dqkv), N, H, scale);
+  SITK_LAUNCH_CHECK("attention_bwd_dq");
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
+                     reinterpret_cast<const T*>(d_o), lse, delta, reinterpret_cast<T*>(dqkv), N, H, scale);
+  return check_launch("attention_bwd_dkv");
+}
+
+}  // namespace sitk
+
+extern "C" int sitk_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int dtype,
+                                  sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(qkv && o && lse, "attention_fwd: null pointer");
+  SITK_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attention_fwd: bad shape B=%d N=%d H=%d", B, N, H);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16) return run_fwd<bf16>(qkv, o, lse, B, N, H, scale, s);
+  if (dtype == SITK_F32) return run_fwd<float>(qkv, o, lse, B, N, H, scale, s);
+  set_error("attention_fwd: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
+}
+
+extern "C" int sitk_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
+                                  void* dqkv, int B, int N, int H, float scale, int dtype, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(qkv && o && d_o && lse && delta && dqkv, "attention_bwd: null pointer");
+  SITK_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16) return run_bwd<bf16>(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, s);
+  if (dtype == SITK_F32) return run_bwd<float>(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, s);
+  set_error("attention_bwd: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
+}

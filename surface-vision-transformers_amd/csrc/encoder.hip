@@ -1,0 +1,270 @@
+// sitk encoder: the whole vit_pytorch.vit.Transformer (models/sit.py:57,76; models/mpp.py:128) as
+// one host call per direction.  The host side only sequences kernel launches on the caller's stream
+// (no allocation, no sync): 7 launches per layer forward, 13 backward, plus one weight-staging
+// launch per 12 layers.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace sitk {
+
+// ---- weight staging: fp32 master -> compute-dtype copy and its transpose, all matrices of up to
+// STAGE_MAX_MAT Linears in one launch (32x32 tiles through LDS) ------------------------------------
+constexpr int STAGE_MAX_MAT = 48;
+struct StageMat {
+  const float* src;
+  void* dst_c;  // (rows, cols) or null
+  void* dst_t;  // (cols, rows)
+  int rows, cols, tile_begin, tiles_c;
+};
+struct StageArgs {
+  StageMat m[STAGE_MAX_MAT];
+  int count;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void stage_weights_kernel(StageArgs a) {
+  __shared__ float tile[32][33];
+  int mi = 0;
+  const int bid = blockIdx.x;
+  while (mi + 1 < a.count && bid >= a.m[mi + 1].tile_begin) ++mi;
+  const StageMat& M = a.m[mi];
+  const int t = bid - M.tile_begin;
+  const int r0 = (t / M.tiles_c) * 32, c0 = (t % M.tiles_c) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  T* dc = reinterpret_cast<T*>(M.dst_c);
+  T* dt = reinterpret_cast<T*>(M.dst_t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    const bool ok = r < M.rows && c < M.cols;
+    const float v = ok ? M.src[(size_t)r * M.cols + c] : 0.f;
+    tile[ty + 8 * i][tx] = v;
+    if (ok && dc) dc[(size_t)r * M.cols + c] = from_f32<T>(v);
+  }
+  __syncthreads();
+  if (dt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;
+      if (c < M.cols && r < M.rows) dt[(size_t)c * M.rows + r] = from_f32<T>(tile[tx][ty + 8 * i]);
+    }
+  }
+}
+
+template <typename T>
+static int launch_stage(const StageArgs& a, int total_tiles, hipStream_t s) {
+  hipLaunchKernelGGL((stage_weights_kernel<T>), dim3(total_tiles), dim3(256), 0, s, a);
+  return check_launch("stage_weights");
+}
+
+// ---- workspace layout --------------------------------------------------------------------------
+struct LayerActs {
+  char *wqkv_c, *wqkv_t, *wo_c, *wo_t, *w1_c, *w1_t, *w2_c, *w2_t;  // compute dtype
+  float *x_in;                                                       // (R, D) fp32 (layers >= 1)
+  float *mean1, *rstd1, *mean2, *rstd2, *lse, *xmid;
+  char *h1, *qkv, *o, *h2, *u, *g;
+};
+struct Scratch {
+  char *du, *dh, *d_o, *dqkv;
+  float *delta, *ping, *pong;
+};
+
+struct Layout {
+  std::vector<LayerActs> layers;
+  Scratch scratch;
+  size_t acts_bytes = 0, scratch_bytes = 0;
+};
+
+static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) {
+  Layout L;
+  const size_t es = c.dtype == SITK_BF16 ? 2 : 4;
+  const size_t R = (size_t)c.B * c.N, D = c.dim, I = (size_t)c.heads * 64, M = c.mlp_dim;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = acts ? acts + off : nullptr; off += align_up(bytes, 256); return p; };
+  L.layers.resize(c.depth);
+  for (int l = 0; l < c.depth; ++l) {
+    LayerActs& a = L.layers[l];
+    a.wqkv_c = take(3 * I * D * es); a.wqkv_t = take(3 * I * D * es);
+    a.wo_c = take(D * I * es);       a.wo_t = take(D * I * es);
+    a.w1_c = take(M * D * es);       a.w1_t = take(M * D * es);
+    a.w2_c = take(M * D * es);       a.w2_t = take(M * D * es);
+  }
+  for (int l = 0; l < c.depth; ++l) {
+    LayerActs& a = L.layers[l];
+    a.x_in = l > 0 ? (float*)take(R * D * 4) : nullptr;
+    a.mean1 = (float*)take(R * 4); a.rstd1 = (float*)take(R * 4);
+    a.mean2 = (float*)take(R * 4); a.rstd2 = (float*)take(R * 4);
+    a.lse = (float*)take((size_t)c.B * c.heads * c.N * 4);
+    a.xmid = (float*)take(R * D * 4);
+    a.h1 = take(R * D * es); a.qkv = take(R * 3 * I * es); a.o = take(R * I * es);
+    a.h2 = take(R * D * es); a.u = take(R * M * es); a.g = take(R * M * es);
+  }
+  L.acts_bytes = off;
+  off = 0;
+  auto stake = [&](size_t bytes) { char* p = scratch ? scratch + off : nullptr; off += align_up(bytes, 256); return p; };
+  L.scratch.du = stake(R * M * es);
+  L.scratch.dh = stake(R * D * es);
+  L.scratch.d_o = stake(R * I * es);
+  L.scratch.dqkv = stake(R * 3 * I * es);
+  L.scratch.delta = (float*)stake((size_t)c.B * c.heads * c.N * 4);
+  L.scratch.ping = (float*)stake(R * D * 4);
+  L.scratch.pong = (float*)stake(R * D * 4);
+  L.scratch_bytes = off;
+  return L;
+}
+
+static int check_cfg(const sitk_encoder_cfg* c) {
+  SITK_REQUIRE(c != nullptr, "encoder: null config");
+  SITK_REQUIRE(c->B > 0 && c->N > 0 && c->depth > 0 && c->heads > 0, "encoder: bad shape");
+  SITK_REQUIRE(c->dim > 0 && c->dim % 8 == 0 && c->dim <= 1024, "encoder: dim=%d must be a multiple of 8 and <= 1024", c->dim);
+  SITK_REQUIRE(c->mlp_dim > 0 && c->mlp_dim % 8 == 0, "encoder: mlp_dim=%d must be a multiple of 8", c->mlp_dim);
+  SITK_REQUIRE(c->dtype == SITK_BF16 || c->dtype == SITK_F32, "encoder: bad dtype %d", c->dtype);
+  return SITK_OK;
+}
+
+static sitk_gemm_desc gemm_desc(int M, int N, int K, const void* A, int lda, int a_f32, const void* W, int epi,
+                                void* out, int ldo, int out_f32) {
+  sitk_gemm_desc d = {};
+  d.M = M; d.N = N; d.K = K; d.A = A; d.lda = lda; d.a_is_f32 = a_f32; d.W = W; d.ldw = K;
+  d.epilogue = epi; d.out = out; d.ldo = ldo; d.out_is_f32 = out_f32;
+  return d;
+}
+
+static sitk_wgrad_desc wgrad_desc(int M, int N, int K, const void* dY, int dy_f32, const void* X, float* dW, float* db) {
+  sitk_wgrad_desc d = {};
+  d.M = M; d.N = N; d.K = K; d.dY = dY; d.lddy = N; d.dy_is_f32 = dy_f32; d.X = X; d.ldx = K; d.dW = dW; d.lddw = K; d.db = db;
+  return d;
+}
+
+static int stage_all(const sitk_encoder_cfg& c, const sitk_layer_params* P, const Layout& L, hipStream_t s) {
+  const int D = c.dim, I = c.heads * 64, M = c.mlp_dim;
+  const bool f32 = c.dtype == SITK_F32;
+  StageArgs a;
+  a.count = 0;
+  int tiles = 0;
+  auto flush = [&]() -> int {
+    if (a.count == 0) return SITK_OK;
+    const int e = f32 ? launch_stage<float>(a, tiles, s) : launch_stage<bf16>(a, tiles, s);
+    a.count = 0;
+    tiles = 0;
+    return e;
+  };
+  auto add = [&](const float* src, void* dc, void* dt, int rows, int cols) {
+    StageMat& m = a.m[a.count++];
+    m.src = src; m.dst_c = f32 ? nullptr : dc; m.dst_t = dt; m.rows = rows; m.cols = cols;
+    m.tile_begin = tiles; m.tiles_c = cdiv(cols, 32);
+    tiles += cdiv(rows, 32) * m.tiles_c;
+  };
+  for (int l = 0; l < c.depth; ++l) {
+    if (a.count + 4 > STAGE_MAX_MAT) SITK_TRY(flush());
+    const LayerActs& w = L.layers[l];
+    add(P[l].wqkv, w.wqkv_c, w.wqkv_t, 3 * I, D);
+    add(P[l].wo, w.wo_c, w.wo_t, D, I);
+    add(P[l].w1, w.w1_c, w.w1_t, M, D);
+    add(P[l].w2, w.w2_c, w.w2_t, D, M);
+  }
+  return flush();
+}
+
+}  // namespace sitk
+
+using namespace sitk;
+
+extern "C" size_t sitk_encoder_acts_bytes(const sitk_encoder_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  return make_layout(*cfg, nullptr, nullptr).acts_bytes;
+}
+extern "C" size_t sitk_encoder_scratch_bytes(const sitk_encoder_cfg* cfg) {
+  if (check_cfg(cfg)) return 0;
+  return make_layout(*cfg, nullptr, nullptr).scratch_bytes;
+}
+
+extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const float* x_in, float* x_out,
+                                void* acts, size_t acts_bytes, void* scratch, size_t scratch_bytes, int save, sitk_stream_t stream) {
+  SITK_TRY(check_cfg(cfg));
+  SITK_REQUIRE(P && x_in && x_out && acts && scratch, "encoder_fwd: null pointer");
+  const sitk_encoder_cfg& c = *cfg;
+  Layout L = make_layout(c, (char*)acts, (char*)scratch);
+  SITK_REQUIRE(acts_bytes >= L.acts_bytes, "encoder_fwd: acts workspace %zu < %zu", acts_bytes, L.acts_bytes);
+  SITK_REQUIRE(scratch_bytes >= L.scratch_bytes, "encoder_fwd: scratch workspace %zu < %zu", scratch_bytes, L.scratch_bytes);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int R = c.B * c.N, D = c.dim, I = c.heads * 64, M = c.mlp_dim, dt = c.dtype;
+  const bool f32 = dt == SITK_F32;
+  const float scale = 0.125f;  // dim_head ** -0.5, dim_head = 64
+
+  SITK_TRY(stage_all(c, P, L, s));
+
+  const float* x = x_in;
+  for (int l = 0; l < c.depth; ++l) {
+    const LayerActs& a = L.layers[save ? l : 0];
+    const LayerActs& w = L.layers[l];
+    const void* wqkv = f32 ? (const void*)P[l].wqkv : w.wqkv_c;
+    const void* wo = f32 ? (const void*)P[l].wo : w.wo_c;
+    const void* w1 = f32 ? (const void*)P[l].w1 : w.w1_c;
+    const void* w2 = f32 ? (const void*)P[l].w2 : w.w2_c;
+    float* xnext = (l == c.depth - 1) ? x_out : (save ? L.layers[l + 1].x_in : ((l & 1) ? L.scratch.pong : L.scratch.ping));
+
+    SITK_TRY(sitk_layernorm_fwd(x, P[l].ln1_w, P[l].ln1_b, a.h1, a.mean1, a.rstd1, R, D, dt, stream));
+    sitk_gemm_desc g1 = gemm_desc(R, 3 * I, D, a.h1, D, 0, wqkv, SITK_EPI_STORE, a.qkv, 3 * I, 0);
+    SITK_TRY(sitk_gemm_nt(&g1, dt, stream));
+    SITK_TRY(sitk_attention_fwd(a.qkv, a.o, a.lse, c.B, c.N, c.heads, scale, dt, stream));
+    sitk_gemm_desc g2 = gemm_desc(R, D, I, a.o, I, 0, wo, SITK_EPI_BIAS_RES, a.xmid, D, 1);
+    g2.bias = P[l].bo; g2.aux = x; g2.ldaux = D;
+    SITK_TRY(sitk_gemm_nt(&g2, dt, stream));
+    SITK_TRY(sitk_layernorm_fwd(a.xmid, P[l].ln2_w, P[l].ln2_b, a.h2, a.mean2, a.rstd2, R, D, dt, stream));
+    sitk_gemm_desc g3 = gemm_desc(R, M, D, a.h2, D, 0, w1, SITK_EPI_BIAS_GELU, a.u, M, 0);
+    g3.bias = P[l].b1; g3.out2 = a.g;
+    SITK_TRY(sitk_gemm_nt(&g3, dt, stream));
+    sitk_gemm_desc g4 = gemm_desc(R, D, M, a.g, M, 0, w2, SITK_EPI_BIAS_RES, xnext, D, 1);
+    g4.bias = P[l].b2; g4.aux = a.xmid; g4.ldaux = D;
+    SITK_TRY(sitk_gemm_nt(&g4, dt, stream));
+    x = xnext;
+  }
+  (void)s;
+  return SITK_OK;
+}
+
+extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
+                                const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
+                                size_t scratch_bytes, int layer_begin, int layer_end, sitk_stream_t stream) {
+  SITK_TRY(check_cfg(cfg));
+  SITK_REQUIRE(P && G && x_in && dx && acts && scratch, "encoder_bwd: null pointer");
+  const sitk_encoder_cfg& c = *cfg;
+  SITK_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= c.depth, "encoder_bwd: bad layer range [%d, %d)", layer_begin, layer_end);
+  Layout L = make_layout(c, (char*)acts, (char*)scratch);
+  SITK_REQUIRE(acts_bytes >= L.acts_bytes, "encoder_bwd: acts workspace %zu < %zu", acts_bytes, L.acts_bytes);
+  SITK_REQUIRE(scratch_bytes >= L.scratch_bytes, "encoder_bwd: scratch workspace %zu < %zu", scratch_bytes, L.scratch_bytes);
+  const int R = c.B * c.N, D = c.dim, I = c.heads * 64, M = c.mlp_dim, dt = c.dtype;
+  const float scale = 0.125f;
+  const Scratch& S = L.scratch;
+
+  for (int l = layer_end - 1; l >= layer_begin; --l) {
+    const LayerActs& a = L.layers[l];
+    const float* xl = l == 0 ? x_in : a.x_in;
+    // ---- MLP branch: x_out = xmid + W2 gelu(W1 LN2(xmid) + b1) + b2 ----
+    sitk_wgrad_desc wg2 = wgrad_desc(R, D, M, dx, 1, a.g, G[l].w2, G[l].b2);
+    SITK_TRY(sitk_gemm_wgrad(&wg2, dt, stream));
+    sitk_gemm_desc d1 = gemm_desc(R, M, D, dx, D, 1, a.w2_t, SITK_EPI_DGELU, S.du, M, 0);
+    d1.aux = a.u; d1.ldaux = M;
+    SITK_TRY(sitk_gemm_nt(&d1, dt, stream));
+    sitk_wgrad_desc wg1 = wgrad_desc(R, M, D, S.du, 0, a.h2, G[l].w1, G[l].b1);
+    SITK_TRY(sitk_gemm_wgrad(&wg1, dt, stream));
+    sitk_gemm_desc d2 = gemm_desc(R, D, M, S.du, M, 0, a.w1_t, SITK_EPI_STORE, S.dh, D, 0);
+    SITK_TRY(sitk_gemm_nt(&d2, dt, stream));
+    SITK_TRY(sitk_layernorm_bwd(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, dx, G[l].ln2_w, G[l].ln2_b, R, D, dt, stream));
+    // ---- attention branch: xmid = x + Wo attn(Wqkv LN1(x)) + bo ----
+    sitk_wgrad_desc wgo = wgrad_desc(R, D, I, dx, 1, a.o, G[l].wo, G[l].bo);
+    SITK_TRY(sitk_gemm_wgrad(&wgo, dt, stream));
+    sitk_gemm_desc d3 = gemm_desc(R, I, D, dx, D, 1, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
+    SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
+    SITK_TRY(sitk_attention_bwd(a.qkv, a.o, S.d_o, a.lse, S.delta, S.dqkv, c.B, c.N, c.heads, scale, dt, stream));
+    sitk_wgrad_desc wgq = wgrad_desc(R, 3 * I, D, S.dqkv, 0, a.h1, G[l].wqkv, nullptr);
+    SITK_TRY(sitk_gemm_wgrad(&wgq, dt, stream));
+    sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, S.dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
+    SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
+    SITK_TRY(sitk_layernorm_bwd(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, dx, dx, G[l].ln1_w, G[l].ln1_b, R, D, dt, stream));
+  }
+  return SITK_OK;
+}

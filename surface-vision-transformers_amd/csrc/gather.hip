@@ -1,0 +1,189 @@
+// sitk patch gather / layout kernels (HBM-bound integer-indexed copies).
+//   gather_tokens : (B, 40962, C=4) channels-last surface + (P, V) vertex table -> tokens (B*P, ld)
+//                   tools/preprocessing.py:74-84 fused with Rearrange('b c n v -> b n (v c)')
+//   patchify      : reference input layout (B, C, P, V) -> tokens            (models/sit.py:47-49)
+//   cast_rows, stage_weight : fp32 -> compute dtype staging (with padding / transpose)
+#include <algorithm>
+
+#include "common.h"
+
+namespace sitk {
+
+// One thread per (token row, vertex slot): loads the vertex id (2 B, coalesced along v), one 16-byte
+// channels-last vertex record (4 fp32 channels) and writes 4 consecutive token features.  A surface
+// is 655 KB, so the 1.2x re-reads of shared edge/corner vertices are served by L2.
+template <typename T>
+__global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restrict__ x, const uint16_t* __restrict__ table,
+                                                            T* __restrict__ tokens, int64_t rows, int n_vertices, int P, int V, int ld) {
+  const int slots = ld >> 2;  // 4-element slots per token row, the first V carry data, the rest zero pad
+  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {  // row = b * P + p
+    const int p = (int)(row % P);
+    const int64_t b = row / P;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < slots; v += gridDim.x * 256) {
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (v < V) {
+        const int vid = table[(size_t)p * V + v];
+        val = *reinterpret_cast<const f32x4*>(x + ((size_t)b * n_vertices + vid) * 4);
+      }
+      store4(tokens + (size_t)row * ld + 4 * v, val);
+    }
+  }
+}
+
+// (B, C, P, V) -> (B*P, ld): thread per (row, v) reads C strided channels (coalesced along v for
+// each channel plane) and writes C consecutive features.
+template <typename T, int C>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, T* __restrict__ tokens, int64_t rows, int P, int V, int ld) {
+  const int K = V * C;
+  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+    const int p = (int)(row % P);
+    const int64_t b = row / P;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v * C < ld; v += gridDim.x * 256) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int f = v * C + c;
+        if (f < ld) {
+          const float val = f < K ? x[(((size_t)b * C + c) * P + p) * V + v] : 0.f;
+          tokens[(size_t)row * ld + f] = from_f32<T>(val);
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, int lds_, T* __restrict__ dst, int ldd,
+                                                        int64_t rows, int cols) {
+  const int slots = ldd >> 2;
+  const int64_t total = rows * slots;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / slots;
+    const int c = (int)(i % slots) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c + 3 < cols) {
+      v = load4(src + r * lds_ + c);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < cols) v[e] = src[r * lds_ + c + e];
+    }
+    store4(dst + r * ldd + c, v);
+  }
+}
+
+// 32x32 LDS tile transpose + cast: w (rows, cols) fp32 -> w_t (cols, ldt) T
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ w, int rows, int cols, T* __restrict__ wt, int ldt) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < rows && c < cols) ? w[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;  // output row = c, col = r
+    if (c < cols && r < ldt) wt[(size_t)c * ldt + r] = from_f32<T>(r < rows ? tile[tx][ty + 8 * i] : 0.f);
+  }
+}
+
+template <typename T>
+static int run_gather(const float* x, const uint16_t* table, void* tokens, int B, int nv, int P, int V, int ld, hipStream_t s) {
+  const int64_t rows = (int64_t)B * P;
+  dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
+  hipLaunchKernelGGL((gather_tokens_kernel<T>), grid, dim3(256), 0, s, x, table, reinterpret_cast<T*>(tokens), rows, nv, P, V, ld);
+  return check_launch("gather_tokens");
+}
+
+template <typename T>
+static int run_patchify(const float* x, void* tokens, int B, int C, int P, int V, int ld, hipStream_t s) {
+  const int64_t rows = (int64_t)B * P;
+  dim3 grid(cdiv(cdiv(ld, C), 256), (unsigned)std::min<int64_t>(rows, 65535));
+  T* t = reinterpret_cast<T*>(tokens);
+  switch (C) {
+    case 1: hipLaunchKernelGGL((patchify_kernel<T, 1>), grid, dim3(256), 0, s, x, t, rows, P, V, ld); break;
+    case 2: hipLaunchKernelGGL((patchify_kernel<T, 2>), grid, dim3(256), 0, s, x, t, rows, P, V, ld); break;
+    case 3: hipLaunchKernelGGL((patchify_kernel<T, 3>), grid, dim3(256), 0, s, x, t, rows, P, V, ld); break;
+    case 4: hipLaunchKernelGGL((patchify_kernel<T, 4>), grid, dim3(256), 0, s, x, t, rows, P, V, ld); break;
+    default: set_error("patchify: num_channels=%d unsupported (1..4)", C); return SITK_ERR_INVALID;
+  }
+  return check_launch("patchify");
+}
+
+template <typename T>
+static int run_cast_rows(const float* src, int lds_, void* dst, int ldd, int64_t rows, int cols, hipStream_t s) {
+  const int64_t total = rows * (ldd / 4);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(total, 256), 8192));
+  hipLaunchKernelGGL((cast_rows_kernel<T>), dim3(grid), dim3(256), 0, s, src, lds_, reinterpret_cast<T*>(dst), ldd, rows, cols);
+  return check_launch("cast_rows");
+}
+
+template <typename T>
+static int run_stage_weight(const float* w, int rows, int cols, void* wc, int ldc, void* wt, int ldt, hipStream_t s) {
+  if (wc) SITK_TRY(run_cast_rows<T>(w, cols, wc, ldc, rows, cols, s));
+  if (wt) {
+    dim3 grid(cdiv(cols, 32), cdiv(std::max(rows, ldt), 32));
+    hipLaunchKernelGGL((transpose_cast_kernel<T>), grid, dim3(256), 0, s, w, rows, cols, reinterpret_cast<T*>(wt), ldt);
+    SITK_LAUNCH_CHECK("stage_weight");
+  }
+  return SITK_OK;
+}
+
+}  // namespace sitk
+
+extern "C" int sitk_gather_tokens(const float* x_bvc, const uint16_t* table_pv, void* tokens, int B, int n_vertices,
+                                  int C, int P, int V, int ld, int dtype, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x_bvc && table_pv && tokens, "gather_tokens: null pointer");
+  SITK_REQUIRE(C == 4, "gather_tokens: channels-last gather is specialised for num_channels == 4 (got %d); use patchify", C);
+  SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "gather_tokens: bad shape");
+  SITK_REQUIRE(ld >= V * C && ld % 8 == 0, "gather_tokens: ld=%d must be >= V*C=%d and a multiple of 8", ld, V * C);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16) return run_gather<bf16>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, s);
+  if (dtype == SITK_F32) return run_gather<float>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, s);
+  set_error("gather_tokens: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
+}
+
+extern "C" int sitk_patchify(const float* x_bcpv, void* tokens, int B, int C, int P, int V, int ld, int dtype,
+                             sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x_bcpv && tokens, "patchify: null pointer");
+  SITK_REQUIRE(B > 0 && P > 0 && V > 0 && C > 0, "patchify: bad shape");
+  SITK_REQUIRE(ld >= V * C && ld % 8 == 0, "patchify: ld=%d must be >= V*C=%d and a multiple of 8", ld, V * C);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16) return run_patchify<bf16>(x_bcpv, tokens, B, C, P, V, ld, s);
+  if (dtype == SITK_F32) return run_patchify<float>(x_bcpv, tokens, B, C, P, V, ld, s);
+  set_error("patchify: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
+}
+
+extern "C" int sitk_cast_rows(const float* src, int lds_, void* dst, int ldd, int64_t rows, int cols, int dtype,
+                              sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(src && dst && rows > 0 && cols > 0, "cast_rows: bad arguments");
+  SITK_REQUIRE(ldd >= cols && ldd % 4 == 0, "cast_rows: ldd=%d must be >= cols=%d and a multiple of 4", ldd, cols);
+  SITK_REQUIRE(lds_ % 4 == 0, "cast_rows: source leading dim must be a multiple of 4");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16) return run_cast_rows<bf16>(src, lds_, dst, ldd, rows, cols, s);
+  if (dtype == SITK_F32) return run_cast_rows<float>(src, lds_, dst, ldd, rows, cols, s);
+  set_error("cast_rows: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
+}
+
+extern "C" int sitk_stage_weight(const float* w, int rows, int cols, void* w_c, int ldc, void* w_t, int ldt, int dtype,
+                                 sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(w && rows > 0 && cols > 0, "stage_weight: bad arguments");
+  SITK_REQUIRE(!w_c || (ldc >= cols && ldc % 8 == 0), "stage_weight: ldc=%d", ldc);
+  SITK_REQUIRE(!w_t || (ldt >= rows && ldt % 8 == 0), "stage_weight: ldt=%d", ldt);
+  SITK_REQUIRE(cols % 4 == 0, "stage_weight: cols %% 4 required");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16) return run_stage_weight<bf16>(w, rows, cols, w_c, ldc, w_t, ldt, s);
+  if (dtype == SITK_F32) return run_stage_weight<float>(w, rows, cols, w_c, ldc, w_t, ldt, s);
+  set_error("stage_weight: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
+}

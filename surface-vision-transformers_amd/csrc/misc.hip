@@ -1,0 +1,362 @@
+// sitk small kernels: pool + head (models/sit.py:78-82), regression losses (tools/train.py:245-248),
+// masked-patch-pretraining corruption and loss (models/mpp.py:85-112,132), fused optimizers
+// (tools/train.py:228-243,291).  All fp32, HBM- or latency-bound.
+#include <algorithm>
+
+#include "common.h"
+
+namespace sitk {
+
+constexpr int HEAD_MAXD = 1024;
+constexpr int HEAD_NV = HEAD_MAXD / 64;
+
+// pooled row of sample b into registers: lane owns d = lane + 64 i
+SITK_DEV void head_pool(const float* __restrict__ x, int b, int N, int D, int pool_mean, int lane, float (&v)[HEAD_NV]) {
+  const float* xb = x + (size_t)b * N * D;
+#pragma unroll
+  for (int i = 0; i < HEAD_NV; ++i) v[i] = 0.f;
+  if (pool_mean) {
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int i = 0; i < HEAD_NV; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) v[i] += xb[(size_t)n * D + d];
+      }
+    const float inv = 1.0f / (float)N;
+#pragma unroll
+    for (int i = 0; i < HEAD_NV; ++i) v[i] *= inv;
+  } else {
+#pragma unroll
+    for (int i = 0; i < HEAD_NV; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) v[i] = xb[d];
+    }
+  }
+}
+
+SITK_DEV void head_stats(const float (&v)[HEAD_NV], int D, int lane, float& mu, float& rs) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < HEAD_NV; ++i) s += (lane + 64 * i < D) ? v[i] : 0.f;
+  mu = wave_sum(s) / (float)D;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < HEAD_NV; ++i)
+    if (lane + 64 * i < D) { const float d = v[i] - mu; ss += d * d; }
+  rs = rsqrtf(wave_sum(ss) / (float)D + 1e-5f);
+}
+
+// one wave per sample
+__global__ __launch_bounds__(64) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
+                                                      const float* __restrict__ ln_b, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ logits, int N,
+                                                      int D, int n_classes, int pool_mean) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float v[HEAD_NV];
+  head_pool(x, b, N, D, pool_mean, lane, v);
+  float mu, rs;
+  head_stats(v, D, lane, mu, rs);
+#pragma unroll
+  for (int i = 0; i < HEAD_NV; ++i) {
+    const int d = lane + 64 * i;
+    v[i] = d < D ? (v[i] - mu) * rs * ln_w[d] + ln_b[d] : 0.f;
+  }
+  for (int c = 0; c < n_classes; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < HEAD_NV; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) s += v[i] * w[(size_t)c * D + d];
+    }
+    s = wave_sum(s);
+    if (lane == 0) logits[(size_t)b * n_classes + c] = s + bias[c];
+  }
+}
+
+// one wave per sample: parameter grads (atomics) and the pooled-row gradient written to dx[b, 0, :]
+__global__ __launch_bounds__(64) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
+                                                      const float* __restrict__ ln_b, const float* __restrict__ w,
+                                                      const float* __restrict__ dlogits, float* __restrict__ dx,
+                                                      float* __restrict__ d_ln_w, float* __restrict__ d_ln_b,
+                                                      float* __restrict__ d_w, float* __restrict__ d_b, int N, int D,
+                                                      int n_classes, int pool_mean) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float v[HEAD_NV], dh[HEAD_NV];
+  head_pool(x, b, N, D, pool_mean, lane, v);
+  float mu, rs;
+  head_stats(v, D, lane, mu, rs);
+#pragma unroll
+  for (int i = 0; i < HEAD_NV; ++i) { v[i] = (v[i] - mu) * rs; dh[i] = 0.f; }  // xhat
+  for (int c = 0; c < n_classes; ++c) {
+    const float dl = dlogits[(size_t)b * n_classes + c];
+    if (lane == 0) unsafeAtomicAdd(d_b + c, dl);
+#pragma unroll
+    for (int i = 0; i < HEAD_NV; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) {
+        dh[i] += dl * w[(size_t)c * D + d];
+        unsafeAtomicAdd(d_w + (size_t)c * D + d, dl * (v[i] * ln_w[d] + ln_b[d]));
+      }
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < HEAD_NV; ++i) {
+    const int d = lane + 64 * i;
+    if (d < D) {
+      unsafeAtomicAdd(d_ln_w + d, dh[i] * v[i]);
+      unsafeAtomicAdd(d_ln_b + d, dh[i]);
+      dh[i] *= ln_w[d];
+      s1 += dh[i];
+      s2 += dh[i] * v[i];
+    }
+  }
+  s1 = wave_sum(s1) / (float)D;
+  s2 = wave_sum(s2) / (float)D;
+  const float post = pool_mean ? 1.0f / (float)N : 1.0f;
+#pragma unroll
+  for (int i = 0; i < HEAD_NV; ++i) {
+    const int d = lane + 64 * i;
+    if (d < D) dx[(size_t)b * N * D + d] = rs * (dh[i] - s1 - v[i] * s2) * post;
+  }
+}
+
+// rows n >= 1 of every sample: copy of row 0 (mean pooling) or zeros (cls pooling)
+__global__ __launch_bounds__(256) void head_spread_kernel(float* __restrict__ dx, int64_t B, int N, int D, int pool_mean) {
+  const int nvec = D >> 2;
+  const int64_t total = B * (int64_t)(N - 1) * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % nvec);
+    const int64_t r = i / nvec;
+    const int64_t b = r / (N - 1);
+    const int n = (int)(r % (N - 1)) + 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (pool_mean) v = load4(dx + (size_t)b * N * D + 4 * c);
+    store4(dx + ((size_t)b * N + n) * D + 4 * c, v);
+  }
+}
+
+// x[b, 0, :] = cls + pos[0, :]   (models/sit.py:70-73: cls token row of the residual stream)
+__global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, int B, int N, int D) {
+  const int nvec = D >> 2;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B * nvec; i += gridDim.x * 256) {
+    const int b = i / nvec, c = i % nvec;
+    store4(x + (size_t)b * N * D + 4 * c, load4(cls + 4 * c) + load4(pos + 4 * c));
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                   float* __restrict__ loss, float* __restrict__ dpred, int n, int l1) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const float inv = 1.0f / (float)n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = pred[i] - target[i];
+    if (l1) {
+      s += fabsf(d);
+      dpred[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv;
+    } else {
+      s += d * d;
+      dpred[i] = 2.f * d * inv;
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+// ---- masked patch pre-training ---------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void mpp_corrupt_kernel(const float* __restrict__ tokens, const uint8_t* __restrict__ masked,
+                                                          const uint8_t* __restrict__ swap_draw,
+                                                          const int32_t* __restrict__ random_patches,
+                                                          const uint8_t* __restrict__ replace_draw,
+                                                          const float* __restrict__ mask_token, T* __restrict__ out,
+                                                          int64_t rows, int P, int K, int ld) {
+  const int slots = ld >> 2;
+  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+    const bool m = masked[row] != 0;
+    const bool rep = m && replace_draw[row] != 0;
+    const bool swp = m && swap_draw != nullptr && swap_draw[row] != 0;
+    const float* src = tokens + (size_t)row * K;
+    if (rep) src = mask_token;
+    else if (swp) src = tokens + ((size_t)(row / P) * P + random_patches[row]) * K;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < slots; v += gridDim.x * 256) {
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (4 * v < K) val = load4(src + 4 * v);
+      store4(out + (size_t)row * ld + 4 * v, val);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void mpp_loss_kernel(const float* __restrict__ out, const float* __restrict__ tokens,
+                                                       const uint8_t* __restrict__ masked, float* __restrict__ loss,
+                                                       float* __restrict__ dout, int64_t rows, int K, float inv_count) {
+  __shared__ float red[4];
+  const int nvec = K >> 2;
+  float s = 0.f;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const bool m = masked[row] != 0;
+    for (int c = threadIdx.x; c < nvec; c += 256) {
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (m) {
+        const f32x4 d = load4(out + (size_t)row * K + 4 * c) - load4(tokens + (size_t)row * K + 4 * c);
+        s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        g = d * (2.f * inv_count);
+      }
+      store4(dout + (size_t)row * K + 4 * c, g);
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
+}
+
+// ---- optimizers ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  int64_t n, float lr, float momentum, float wd, int nesterov, float gscale) {
+  const int64_t nvec = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    f32x4 pv = load4(p + 4 * i);
+    f32x4 gv = load4(g + 4 * i) * gscale + pv * wd;
+    if (momentum != 0.f) {
+      f32x4 bv = load4(buf + 4 * i) * momentum + gv;
+      store4(buf + 4 * i, bv);
+      gv = nesterov ? gv + bv * momentum : bv;
+    }
+    store4(p + 4 * i, pv - gv * lr);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = (nvec << 2) + threadIdx.x;
+    float gv = g[i] * gscale + p[i] * wd;
+    if (momentum != 0.f) {
+      const float bv = buf[i] * momentum + gv;
+      buf[i] = bv;
+      gv = nesterov ? gv + bv * momentum : bv;
+    }
+    p[i] -= lr * gv;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, int decoupled, float bc1, float bc2_sqrt, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float pv = p[i], gv = g[i] * gscale;
+    if (decoupled) pv *= (1.f - lr * wd);
+    else gv += wd * pv;
+    const float mv = b1 * m[i] + (1.f - b1) * gv;
+    const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = pv - (lr / bc1) * (mv / denom);
+  }
+}
+
+static int grid_for(int64_t work, int per_block, int cap) {
+  return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(work, per_block), cap));
+}
+
+}  // namespace sitk
+
+extern "C" int sitk_head_fwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
+                             float* logits, int B, int N, int D, int n_classes, int pool_mean, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x && ln_w && ln_b && w && b && logits, "head_fwd: null pointer");
+  SITK_REQUIRE(B > 0 && N > 0 && D > 0 && D <= HEAD_MAXD && n_classes > 0, "head_fwd: bad shape (D <= %d)", HEAD_MAXD);
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), x, ln_w, ln_b, w, b,
+                     logits, N, D, n_classes, pool_mean);
+  return check_launch("head_fwd");
+}
+
+extern "C" int sitk_head_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* dlogits,
+                             float* dx, float* d_ln_w, float* d_ln_b, float* d_w, float* d_b, int B, int N, int D,
+                             int n_classes, int pool_mean, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x && ln_w && ln_b && w && dlogits && dx && d_ln_w && d_ln_b && d_w && d_b, "head_bwd: null pointer");
+  SITK_REQUIRE(B > 0 && N > 0 && D > 0 && D <= HEAD_MAXD && D % 4 == 0 && n_classes > 0, "head_bwd: bad shape");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(64), 0, s, x, ln_w, ln_b, w, dlogits, dx, d_ln_w, d_ln_b, d_w, d_b, N,
+                     D, n_classes, pool_mean);
+  SITK_LAUNCH_CHECK("head_bwd");
+  if (N > 1) {
+    const int64_t total = (int64_t)B * (N - 1) * (D / 4);
+    hipLaunchKernelGGL(head_spread_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, dx, (int64_t)B, N, D, pool_mean);
+    SITK_LAUNCH_CHECK("head_spread");
+  }
+  return SITK_OK;
+}
+
+extern "C" int sitk_embed_cls_rows(float* x, const float* cls_token, const float* pos, int B, int N, int D,
+                                   sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x && cls_token && pos && B > 0 && N > 0 && D > 0 && D % 4 == 0, "embed_cls_rows: bad arguments");
+  hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for((int64_t)B * D / 4, 256, 1024)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, cls_token, pos, B, N, D);
+  return check_launch("embed_cls_rows");
+}
+
+extern "C" int sitk_loss_fwd_bwd(const float* pred, const float* target, float* loss, float* dpred, int n, int l1,
+                                 sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(pred && target && loss && dpred && n > 0, "loss_fwd_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred, target, loss, dpred, n, l1);
+  return check_launch("loss_fwd_bwd");
+}
+
+extern "C" int sitk_mpp_corrupt(const float* tokens, const uint8_t* masked, const uint8_t* swap_draw,
+                                const int32_t* random_patches, const uint8_t* replace_draw, const float* mask_token,
+                                void* corrupted, int B, int P, int K, int ld, int dtype, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(tokens && masked && replace_draw && mask_token && corrupted, "mpp_corrupt: null pointer");
+  SITK_REQUIRE((swap_draw == nullptr) == (random_patches == nullptr), "mpp_corrupt: swap_draw and random_patches go together");
+  SITK_REQUIRE(B > 0 && P > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 8 == 0, "mpp_corrupt: bad shape K=%d ld=%d", K, ld);
+  const int64_t rows = (int64_t)B * P;
+  dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16)
+    hipLaunchKernelGGL((mpp_corrupt_kernel<bf16>), grid, dim3(256), 0, s, tokens, masked, swap_draw, random_patches,
+                       replace_draw, mask_token, reinterpret_cast<bf16*>(corrupted), rows, P, K, ld);
+  else if (dtype == SITK_F32)
+    hipLaunchKernelGGL((mpp_corrupt_kernel<float>), grid, dim3(256), 0, s, tokens, masked, swap_draw, random_patches,
+                       replace_draw, mask_token, reinterpret_cast<float*>(corrupted), rows, P, K, ld);
+  else { set_error("mpp_corrupt: bad dtype %d", dtype); return SITK_ERR_INVALID; }
+  return check_launch("mpp_corrupt");
+}
+
+extern "C" int sitk_mpp_loss_fwd_bwd(const float* out, const float* tokens, const uint8_t* masked, float* loss,
+                                     float* dout, int64_t rows, int K, int64_t n_masked_total, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(out && tokens && masked && loss && dout, "mpp_loss: null pointer");
+  SITK_REQUIRE(rows > 0 && K > 0 && K % 4 == 0 && n_masked_total > 0, "mpp_loss: bad shape");
+  const float inv = 1.0f / ((float)n_masked_total * (float)K);
+  hipLaunchKernelGGL(mpp_loss_kernel, dim3(grid_for(rows, 1, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), out,
+                     tokens, masked, loss, dout, rows, K, inv);
+  return check_launch("mpp_loss");
+}
+
+extern "C" int sitk_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                             float weight_decay, int nesterov, float grad_scale, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(param && grad && n > 0, "sgd_step: bad arguments");
+  SITK_REQUIRE(momentum == 0.f || momentum_buf, "sgd_step: momentum needs a buffer");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     param, grad, momentum_buf, n, lr, momentum, weight_decay, nesterov, grad_scale);
+  return check_launch("sgd_step");
+}
+
+extern "C" int sitk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
+                              float grad_scale, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, "adam_step: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), param, grad,
+                     exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, decoupled_wd, bc1, bc2s, grad_scale);
+  return check_launch("adam_step");
+}

@@ -1,0 +1,143 @@
+"""torch.autograd bridges over the C ABI: each Function is one fused stage of the hot path
+(embedding, encoder, head, generic Linear), so `loss.backward()` of tools/train.py:290 /
+tools/pretrain.py:318 runs the HIP backward kernels.  No Function has a CPU branch."""
+import torch
+
+from . import ops
+from . import runtime as rt
+
+
+def _zeros_like_all(ts):
+    return [torch.zeros_like(t) for t in ts]
+
+
+class EmbedFn(torch.autograd.Function):
+    """tokens (B*P, ld) compute dtype -> residual stream (B, P+1, D) fp32:
+    rows 1..P = tokens @ W^T + b + pos[1:], row 0 = cls + pos[0]   (models/sit.py:50,70-73)."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight, bias, cls_token, pos_embedding, B, P, dtype):
+        D, K = weight.shape
+        ld = tokens.shape[1]
+        wc, _ = ops.stage_weight(weight.detach().contiguous(), dtype, ldc=ld, want_t=False)
+        x = torch.empty((B, P + 1, D), dtype=torch.float32, device=tokens.device)
+        pos = pos_embedding.detach().reshape(-1, D)[:P + 1].contiguous()
+        ops.gemm_nt(tokens, wc, x.view(B * (P + 1), D), dtype, M=B * P, N=D, K=ld, epilogue=ops.EPI_BIAS_RES,
+                    bias=bias.detach(), aux=pos, omap=(P, P + 1, 1), auxmap=(P, 0, 1))
+        ops.embed_cls_rows(x, cls_token.detach().reshape(-1).contiguous(), pos, B, P + 1, D)
+        ctx.save_for_backward(tokens)
+        ctx.meta = (B, P, D, K, ld, dtype, tuple(pos_embedding.shape))
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        (tokens,) = ctx.saved_tensors
+        B, P, D, K, ld, dtype, pos_shape = ctx.meta
+        dx = dx.contiguous()
+        dW_pad = torch.zeros((D, ld), dtype=torch.float32, device=dx.device)
+        db = torch.zeros((D,), dtype=torch.float32, device=dx.device)
+        ops.gemm_wgrad(dx.view(B * (P + 1), D), tokens, dW_pad, dtype, db=db, M=B * P, N=D, K=ld, dymap=(P, P + 1, 1))
+        dpos_used = torch.zeros(((P + 1) * D,), dtype=torch.float32, device=dx.device)
+        ops.colsum_f32(dx.view(B, (P + 1) * D), dpos_used)
+        dpos = torch.zeros(pos_shape, dtype=torch.float32, device=dx.device)
+        dpos.view(-1, D)[:P + 1] = dpos_used.view(P + 1, D)
+        dcls = dpos_used[:D].clone().view(1, 1, D)
+        return None, dW_pad[:, :K].contiguous(), db, dcls, dpos, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b for fp32 x of shape (..., K): the reach-through entry used by
+    models/mpp.py:115 (`transformer.to_patch_embedding[-1](corrupted_batch)`) and `to_original`
+    (models/mpp.py:129).  Output fp32."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dtype):
+        N, K = weight.shape
+        lead = x.shape[:-1]
+        x2 = x.detach().reshape(-1, K)
+        if x2.stride(-1) != 1 or x2.stride(0) % 4 != 0:
+            x2 = x2.contiguous()
+        ld = ops.pad8(K)
+        xc = ops.cast_rows(x2, dtype, ld=ld)
+        wc, wt = ops.stage_weight(weight.detach().contiguous(), dtype, ldc=ld, want_t=ctx.needs_input_grad[0])
+        y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
+        ops.gemm_nt(xc, wc, y, dtype, N=N, K=ld, bias=None if bias is None else bias.detach())
+        ctx.save_for_backward(xc, wt)
+        ctx.meta = (N, K, ld, dtype, lead, bias is not None)
+        return y.view(*lead, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wt = ctx.saved_tensors
+        N, K, ld, dtype, lead, has_bias = ctx.meta
+        dy2 = dy.reshape(-1, N).contiguous()
+        dW_pad = torch.zeros((N, ld), dtype=torch.float32, device=dy.device)
+        db = torch.zeros((N,), dtype=torch.float32, device=dy.device) if has_bias else None
+        ops.gemm_wgrad(dy2, xc, dW_pad, dtype, db=db, N=N, K=ld)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy.device)
+            ops.gemm_nt(dy2, wt, dx, dtype, N=K, K=wt.shape[1])
+            dx = dx.view(*lead, K)
+        return dx, dW_pad[:, :K].contiguous(), db, None
+
+
+class EncoderFn(torch.autograd.Function):
+    """vit_pytorch.vit.Transformer.forward (models/sit.py:76, models/mpp.py:128) as one call."""
+
+    @staticmethod
+    def forward(ctx, x, cfg_tuple, *params):
+        B, N, D = x.shape
+        dim, depth, heads, mlp_dim, dtype = cfg_tuple
+        assert D == dim
+        cfg = ops.encoder_cfg(B, N, dim, depth, heads, mlp_dim, dtype)
+        ps = [p.detach().contiguous() for p in params]
+        per_layer = [ps[11 * i:11 * (i + 1)] for i in range(depth)]
+        P = ops.layer_param_array(per_layer)
+        acts, scratch = ops.encoder_workspace(cfg, x.device)
+        xin = x.detach().contiguous()
+        out = torch.empty_like(xin)
+        need_grad = any(ctx.needs_input_grad)
+        ops.encoder_fwd(cfg, P, xin.view(B * N, D), out.view(B * N, D), acts, scratch, save=need_grad)
+        if need_grad:
+            ctx.save_for_backward(xin, acts, *ps)
+            ctx.cfg_tuple = cfg_tuple
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, acts, *ps = ctx.saved_tensors
+        dim, depth, heads, mlp_dim, dtype = ctx.cfg_tuple
+        B, N, D = xin.shape
+        cfg = ops.encoder_cfg(B, N, dim, depth, heads, mlp_dim, dtype)
+        grads = _zeros_like_all(ps)
+        P = ops.layer_param_array([ps[11 * i:11 * (i + 1)] for i in range(depth)])
+        G = ops.layer_param_array([grads[11 * i:11 * (i + 1)] for i in range(depth)])
+        _, scratch = None, torch.empty(rt.lib.sitk_encoder_scratch_bytes(cfg), dtype=torch.uint8, device=dy.device)
+        dx = dy.contiguous().clone()
+        ops.encoder_bwd(cfg, P, G, xin.view(B * N, D), dx.view(B * N, D), acts, scratch)
+        return (dx, None, *grads)
+
+
+class HeadFn(torch.autograd.Function):
+    """pool ('cls' / 'mean') -> LayerNorm -> Linear   (models/sit.py:78-82)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w, b, pool_mean):
+        B, N, D = x.shape
+        xin = x.detach().contiguous()
+        args = [t.detach().contiguous() for t in (ln_w, ln_b, w, b)]
+        out = ops.head_fwd(xin.view(B * N, D), *args, B, N, D, pool_mean)
+        ctx.save_for_backward(xin, *args)
+        ctx.pool_mean = pool_mean
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        xin, ln_w, ln_b, w, b = ctx.saved_tensors
+        B, N, D = xin.shape
+        dx = torch.empty_like(xin)
+        g = _zeros_like_all((ln_w, ln_b, w, b))
+        ops.head_bwd(xin.view(B * N, D), ln_w, ln_b, w, dlogits.contiguous().float(), dx.view(B * N, D), *g, B, N, D,
+                     ctx.pool_mean)
+        return (dx, *g, None)

@@ -1,0 +1,261 @@
+"""Thin tensor-level wrappers over the C ABI (runtime.py).  Allocation and stream selection are
+torch's; every computation happens in libsitk.so's HIP kernels."""
+import ctypes as C
+
+import torch
+
+from . import runtime as rt
+from .runtime import BF16, F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_STORE  # noqa: F401
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def pad64(n):
+    return (n + 63) // 64 * 64
+
+
+def _rowmap(rm):
+    return rt.RowMap(*rm) if rm else rt.RowMap(0, 0, 0)
+
+
+# ---- gather / layout -------------------------------------------------------------------------------
+def gather_tokens(x_bvc, table_pv, dtype, ld=None):
+    """(B, 40962, 4) fp32 + (P, V) uint16 table -> (B*P, ld) tokens of `dtype` (zero padded)."""
+    rt.require_cuda(x_bvc, table_pv)
+    B, nv, Cc = x_bvc.shape
+    P, V = table_pv.shape
+    assert x_bvc.dtype == torch.float32 and x_bvc.is_contiguous()
+    assert table_pv.dtype in (torch.uint16, torch.int16) and table_pv.is_contiguous()  # int16 = same bits
+    code = rt.dtype_code(dtype)
+    ld = ld or pad64(V * Cc)
+    out = torch.empty((B * P, ld), dtype=rt.torch_dtype(code), device=x_bvc.device)
+    rt.check(rt.lib.sitk_gather_tokens(x_bvc.data_ptr(), table_pv.data_ptr(), out.data_ptr(), B, nv, Cc, P, V, ld,
+                                       code, rt.stream_ptr()))
+    return out
+
+
+def patchify(x_bcpv, dtype, ld=None):
+    rt.require_cuda(x_bcpv)
+    B, Cc, P, V = x_bcpv.shape
+    assert x_bcpv.dtype == torch.float32
+    x_bcpv = x_bcpv.contiguous()
+    code = rt.dtype_code(dtype)
+    ld = ld or pad64(V * Cc)
+    out = torch.empty((B * P, ld), dtype=rt.torch_dtype(code), device=x_bcpv.device)
+    rt.check(rt.lib.sitk_patchify(x_bcpv.data_ptr(), out.data_ptr(), B, Cc, P, V, ld, code, rt.stream_ptr()))
+    return out
+
+
+def cast_rows(src, dtype, ld=None):
+    rt.require_cuda(src)
+    assert src.dtype == torch.float32 and src.dim() == 2 and src.stride(1) == 1
+    rows, cols = src.shape
+    code = rt.dtype_code(dtype)
+    ld = ld or pad8(cols)
+    out = torch.empty((rows, ld), dtype=rt.torch_dtype(code), device=src.device)
+    rt.check(rt.lib.sitk_cast_rows(src.data_ptr(), src.stride(0), out.data_ptr(), ld, rows, cols, code, rt.stream_ptr()))
+    return out
+
+
+def stage_weight(w, dtype, ldc=None, want_c=True, want_t=True):
+    rt.require_cuda(w)
+    assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
+    rows, cols = w.shape
+    code = rt.dtype_code(dtype)
+    td = rt.torch_dtype(code)
+    ldc = ldc or pad8(cols)
+    ldt = pad8(rows)
+    wc = torch.empty((rows, ldc), dtype=td, device=w.device) if want_c else None
+    wt = torch.empty((cols, ldt), dtype=td, device=w.device) if want_t else None
+    rt.check(rt.lib.sitk_stage_weight(w.data_ptr(), rows, cols, rt.ptr(wc), ldc, rt.ptr(wt), ldt, code, rt.stream_ptr()))
+    return wc, wt
+
+
+# ---- GEMMs -----------------------------------------------------------------------------------------
+def gemm_nt(A, W, out, dtype, M=None, N=None, K=None, epilogue=EPI_STORE, bias=None, aux=None, out2=None,
+            amap=None, omap=None, auxmap=None):
+    """out[m, n] = sum_k A[m, k] W[n, k] (+ epilogue).  A: compute dtype or fp32; W: compute dtype;
+    out: compute dtype or fp32.  2-D tensors with unit inner stride; leading dims from strides."""
+    rt.require_cuda(A, W, out, bias, aux, out2)
+    code = rt.dtype_code(dtype)
+    d = rt.GemmDesc()
+    d.M = M if M is not None else A.shape[0]
+    d.N = N if N is not None else W.shape[0]
+    d.K = K if K is not None else W.shape[1]
+    d.A, d.lda, d.a_is_f32, d.amap = A.data_ptr(), A.stride(0), int(A.dtype == torch.float32), _rowmap(amap)
+    d.W, d.ldw = W.data_ptr(), W.stride(0)
+    d.epilogue = epilogue
+    d.out, d.ldo, d.out_is_f32, d.omap = out.data_ptr(), out.stride(0), int(out.dtype == torch.float32), _rowmap(omap)
+    d.out2 = rt.ptr(out2)
+    d.bias = rt.ptr(bias)
+    d.aux, d.ldaux, d.auxmap = rt.ptr(aux), (aux.stride(0) if aux is not None else 0), _rowmap(auxmap)
+    rt.check(rt.lib.sitk_gemm_nt(C.byref(d), code, rt.stream_ptr()))
+    return out
+
+
+def gemm_wgrad(dY, X, dW, dtype, db=None, M=None, N=None, K=None, dymap=None, xmap=None):
+    """dW[n, k] += sum_m dY[m, n] X[m, k]; db[n] += sum_m dY[m, n]."""
+    rt.require_cuda(dY, X, dW, db)
+    code = rt.dtype_code(dtype)
+    d = rt.WgradDesc()
+    d.M = M if M is not None else dY.shape[0]
+    d.N = N if N is not None else dW.shape[0]
+    d.K = K if K is not None else dW.shape[1]
+    d.dY, d.lddy, d.dy_is_f32, d.dymap = dY.data_ptr(), dY.stride(0), int(dY.dtype == torch.float32), _rowmap(dymap)
+    d.X, d.ldx, d.xmap = X.data_ptr(), X.stride(0), _rowmap(xmap)
+    d.dW, d.lddw, d.db = dW.data_ptr(), dW.stride(0), rt.ptr(db)
+    assert dW.dtype == torch.float32
+    rt.check(rt.lib.sitk_gemm_wgrad(C.byref(d), code, rt.stream_ptr()))
+    return dW
+
+
+# ---- LayerNorm -------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, dtype):
+    rt.require_cuda(x, gamma, beta)
+    rows, D = x.shape
+    code = rt.dtype_code(dtype)
+    y = torch.empty((rows, D), dtype=rt.torch_dtype(code), device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rt.check(rt.lib.sitk_layernorm_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), rows, D, code, rt.stream_ptr()))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dtype, dx=None):
+    rows, D = x.shape
+    code = rt.dtype_code(dtype)
+    if dx is None:
+        dx = torch.empty_like(x)
+    rt.check(rt.lib.sitk_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                       rt.ptr(dres), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, code,
+                                       rt.stream_ptr()))
+    return dx
+
+
+# ---- attention -------------------------------------------------------------------------------------
+def attention_fwd(qkv, B, N, H, scale, dtype):
+    code = rt.dtype_code(dtype)
+    o = torch.empty((B * N, H * 64), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    rt.check(rt.lib.sitk_attention_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, scale, code, rt.stream_ptr()))
+    return o, lse
+
+
+def attention_bwd(qkv, o, d_o, lse, B, N, H, scale, dtype):
+    code = rt.dtype_code(dtype)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    rt.check(rt.lib.sitk_attention_bwd(qkv.data_ptr(), o.data_ptr(), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                       dqkv.data_ptr(), B, N, H, scale, code, rt.stream_ptr()))
+    return dqkv
+
+
+# ---- encoder ---------------------------------------------------------------------------------------
+def encoder_cfg(B, N, dim, depth, heads, mlp_dim, dtype):
+    return rt.EncoderCfg(B, N, dim, depth, heads, mlp_dim, rt.dtype_code(dtype))
+
+
+def layer_param_array(per_layer_tensors):
+    """per_layer_tensors: list (depth) of sequences of 11 fp32 tensors in rt.LAYER_FIELDS order."""
+    arr = (rt.LayerParams * len(per_layer_tensors))()
+    for i, ts in enumerate(per_layer_tensors):
+        assert len(ts) == len(rt.LAYER_FIELDS)
+        for k, t in zip(rt.LAYER_FIELDS, ts):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda, k
+            setattr(arr[i], k, t.data_ptr())
+    return arr
+
+
+def encoder_workspace(cfg, device):
+    ab = rt.lib.sitk_encoder_acts_bytes(C.byref(cfg))
+    sb = rt.lib.sitk_encoder_scratch_bytes(C.byref(cfg))
+    if ab == 0 or sb == 0:
+        raise rt.SitkError(f"encoder workspace query failed: {rt.lib.sitk_last_error().decode()}")
+    return (torch.empty(ab, dtype=torch.uint8, device=device), torch.empty(sb, dtype=torch.uint8, device=device))
+
+
+def encoder_fwd(cfg, params, x_in, x_out, acts, scratch, save=True):
+    rt.check(rt.lib.sitk_encoder_fwd(C.byref(cfg), params, x_in.data_ptr(), x_out.data_ptr(), acts.data_ptr(),
+                                     acts.numel(), scratch.data_ptr(), scratch.numel(), int(save), rt.stream_ptr()))
+    return x_out
+
+
+def encoder_bwd(cfg, params, grads, x_in, dx, acts, scratch, layer_begin=0, layer_end=None):
+    layer_end = cfg.depth if layer_end is None else layer_end
+    rt.check(rt.lib.sitk_encoder_bwd(C.byref(cfg), params, grads, x_in.data_ptr(), dx.data_ptr(), acts.data_ptr(),
+                                     acts.numel(), scratch.data_ptr(), scratch.numel(), layer_begin, layer_end,
+                                     rt.stream_ptr()))
+    return dx
+
+
+def embed_cls_rows(x, cls_token, pos, B, N, D):
+    rt.check(rt.lib.sitk_embed_cls_rows(x.data_ptr(), cls_token.data_ptr(), pos.data_ptr(), B, N, D, rt.stream_ptr()))
+    return x
+
+
+# ---- head / loss -----------------------------------------------------------------------------------
+def head_fwd(x, ln_w, ln_b, w, b, B, N, D, pool_mean):
+    ncls = w.shape[0]
+    logits = torch.empty((B, ncls), dtype=torch.float32, device=x.device)
+    rt.check(rt.lib.sitk_head_fwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                  logits.data_ptr(), B, N, D, ncls, int(pool_mean), rt.stream_ptr()))
+    return logits
+
+
+def head_bwd(x, ln_w, ln_b, w, dlogits, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, pool_mean):
+    ncls = w.shape[0]
+    rt.check(rt.lib.sitk_head_bwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w.data_ptr(), dlogits.data_ptr(),
+                                  dx.data_ptr(), d_ln_w.data_ptr(), d_ln_b.data_ptr(), d_w.data_ptr(), d_b.data_ptr(),
+                                  B, N, D, ncls, int(pool_mean), rt.stream_ptr()))
+    return dx
+
+
+def loss_fwd_bwd(pred, target, loss, dpred, l1=False):
+    rt.check(rt.lib.sitk_loss_fwd_bwd(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), dpred.data_ptr(),
+                                      pred.numel(), int(l1), rt.stream_ptr()))
+
+
+def colsum_f32(x2d, out):
+    rows, cols = x2d.shape
+    rt.check(rt.lib.sitk_colsum_f32(x2d.data_ptr(), rows, cols, x2d.stride(0), out.data_ptr(), rt.stream_ptr()))
+    return out
+
+
+def masked_colsum(x2d, flag_a, flag_b, out, dtype, cols=None):
+    rows = x2d.shape[0]
+    cols = cols or x2d.shape[1]
+    rt.check(rt.lib.sitk_masked_colsum(x2d.data_ptr(), x2d.stride(0), int(x2d.dtype == torch.float32),
+                                       rt.dtype_code(dtype), flag_a.data_ptr(), rt.ptr(flag_b), rows, cols,
+                                       out.data_ptr(), rt.stream_ptr()))
+    return out
+
+
+# ---- MPP -------------------------------------------------------------------------------------------
+def mpp_corrupt(tokens, masked, swap_draw, random_patches, replace_draw, mask_token, B, P, K, dtype, ld=None):
+    code = rt.dtype_code(dtype)
+    ld = ld or pad64(K)
+    out = torch.empty((B * P, ld), dtype=rt.torch_dtype(code), device=tokens.device)
+    rt.check(rt.lib.sitk_mpp_corrupt(tokens.data_ptr(), masked.data_ptr(), rt.ptr(swap_draw), rt.ptr(random_patches),
+                                     replace_draw.data_ptr(), mask_token.data_ptr(), out.data_ptr(), B, P, K, ld, code,
+                                     rt.stream_ptr()))
+    return out
+
+
+def mpp_loss_fwd_bwd(out, tokens, masked, loss, dout, n_masked_total):
+    rows, K = out.shape
+    rt.check(rt.lib.sitk_mpp_loss_fwd_bwd(out.data_ptr(), tokens.data_ptr(), masked.data_ptr(), loss.data_ptr(),
+                                          dout.data_ptr(), rows, K, n_masked_total, rt.stream_ptr()))
+
+
+# ---- optimizers ------------------------------------------------------------------------------------
+def sgd_step(param, grad, buf, lr, momentum=0.0, weight_decay=0.0, nesterov=False, grad_scale=1.0):
+    rt.check(rt.lib.sitk_sgd_step(param.data_ptr(), grad.data_ptr(), rt.ptr(buf), param.numel(), lr, momentum,
+                                  weight_decay, int(nesterov), grad_scale, rt.stream_ptr()))
+
+
+def adam_step(param, grad, m, v, lr, beta1, beta2, eps, weight_decay, decoupled, step, grad_scale=1.0):
+    rt.check(rt.lib.sitk_adam_step(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.numel(), lr,
+                                   beta1, beta2, eps, weight_decay, int(decoupled), step, grad_scale, rt.stream_ptr()))

@@ -1,0 +1,135 @@
+"""ctypes binding of libsitk.so (include/sitk.h) -- the only way the package reaches the GPU.
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved the import of
+this module raises, and every wrapper raises `SitkError` on a non-zero return code.
+Pointers come from `tensor.data_ptr()`, the stream from `torch.cuda.current_stream().cuda_stream`.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsitk.so")
+
+F32, BF16 = 0, 1
+EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
+ABI_VERSION = 1
+
+
+class SitkError(RuntimeError):
+    pass
+
+
+class RowMap(C.Structure):
+    _fields_ = [("group", C.c_int), ("stride", C.c_int), ("offset", C.c_int)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("a_is_f32", C.c_int), ("amap", RowMap),
+                ("W", C.c_void_p), ("ldw", C.c_int), ("epilogue", C.c_int),
+                ("out", C.c_void_p), ("ldo", C.c_int), ("out_is_f32", C.c_int), ("omap", RowMap),
+                ("out2", C.c_void_p), ("bias", C.c_void_p),
+                ("aux", C.c_void_p), ("ldaux", C.c_int), ("auxmap", RowMap)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("dY", C.c_void_p), ("lddy", C.c_int), ("dy_is_f32", C.c_int), ("dymap", RowMap),
+                ("X", C.c_void_p), ("ldx", C.c_int), ("xmap", RowMap),
+                ("dW", C.c_void_p), ("lddw", C.c_int), ("db", C.c_void_p)]
+
+
+class EncoderCfg(C.Structure):
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int),
+                ("mlp_dim", C.c_int), ("dtype", C.c_int)]
+
+
+LAYER_FIELDS = ("ln1_w", "ln1_b", "wqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
+
+
+class LayerParams(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in LAYER_FIELDS]
+
+
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_SIGS = {
+    "sitk_abi_version": (C.c_int, []),
+    "sitk_last_error": (C.c_char_p, []),
+    "sitk_dtype_size": (C.c_int, [_I]),
+    "sitk_gather_tokens": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sitk_patchify": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sitk_cast_rows": (C.c_int, [_P, _I, _P, _I, _L, _I, _I, _P]),
+    "sitk_stage_weight": (C.c_int, [_P, _I, _I, _P, _I, _P, _I, _I, _P]),
+    "sitk_gemm_nt": (C.c_int, [C.POINTER(GemmDesc), _I, _P]),
+    "sitk_gemm_wgrad": (C.c_int, [C.POINTER(WgradDesc), _I, _P]),
+    "sitk_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "sitk_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "sitk_attention_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "sitk_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "sitk_encoder_acts_bytes": (_Z, [C.POINTER(EncoderCfg)]),
+    "sitk_encoder_scratch_bytes": (_Z, [C.POINTER(EncoderCfg)]),
+    "sitk_encoder_fwd": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), _P, _P, _P, _Z, _P, _Z, _I, _P]),
+    "sitk_encoder_bwd": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,
+                                   _P, _Z, _P, _Z, _I, _I, _P]),
+    "sitk_embed_cls_rows": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
+    "sitk_head_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sitk_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sitk_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
+    "sitk_colsum_f32": (C.c_int, [_P, _L, _I, _I, _P, _P]),
+    "sitk_mpp_corrupt": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sitk_mpp_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _P]),
+    "sitk_masked_colsum": (C.c_int, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P]),
+    "sitk_sgd_step": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _I, _F, _P]),
+    "sitk_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _F, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise SitkError(
+            f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()' or "
+            f"`make -C {os.path.join(_HERE, 'csrc')}`). There is no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is missing
+        fn.restype, fn.argtypes = res, args
+    if lib.sitk_abi_version() != ABI_VERSION:
+        raise SitkError(f"libsitk ABI {lib.sitk_abi_version()} != expected {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc):
+    if rc != 0:
+        raise SitkError(f"libsitk error {rc}: {lib.sitk_last_error().decode()}")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dtype):
+    if dtype in (BF16, "bf16", torch.bfloat16):
+        return BF16
+    if dtype in (F32, "f32", "fp32", torch.float32):
+        return F32
+    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'bf16' or 'f32')")
+
+
+def torch_dtype(code):
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SitkError("sitk: tensors must live on a ROCm/HIP device (no CPU path in the product code)")

@@ -1,0 +1,422 @@
+"""GPU parity tests of every C-ABI kernel entry point against plain fp32 torch math / the oracle.
+
+Tolerances (relative L2 error  ||a - ref|| / ||ref||  unless a test says otherwise):
+  f32 mode  (v_mfma_f32_16x16x4_f32, exact fp32 products)  : 2e-5   -- well inside the 1e-3 north-star bar
+  bf16 mode (v_mfma_f32_16x16x32_bf16, fp32 accumulate)     : 1e-2   -- one bf16 rounding (2^-9) per operand
+Integer-valued inputs are checked bit-exactly in both modes (catches any operand-layout mistake).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detgen, sit_oracle  # noqa: E402
+
+DEV = "cuda:0"
+TOL = {"f32": 2e-5, "bf16": 1e-2}
+DTYPES = ["f32", "bf16"]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sitk  # noqa: F401
+    from sitk import ops as _ops
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _ops
+
+
+def tdt(dtype):
+    return torch.bfloat16 if dtype == "bf16" else torch.float32
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(name, shape, scale=1.0, seed=0):
+    return torch.from_numpy(detgen.normal(name, shape, std=scale, seed=seed)).to(DEV)
+
+
+def ints(name, shape, lo=-3, hi=4):
+    return torch.from_numpy(detgen.randint(name, shape, lo, hi).astype(np.float32)).to(DEV)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_gather_tokens_bit_exact(ops, dtype, k):
+    from sitk import tables
+    t = tables.load_table(*{1: (80, 561), 2: (320, 153), 3: (1280, 45)}[k])
+    B = 3
+    x = detgen.normal("g/x", (B, 40962, 4), seed=k)
+    ref = sit_oracle.gather_tokens(x, t)                      # (B, P, K) fp32
+    P, V = t.shape
+    out = ops.gather_tokens(torch.from_numpy(x).to(DEV), tables.table_tensor(t, DEV), dtype)
+    K = V * 4
+    assert out.shape == (B * P, ops.pad64(K))
+    got = out[:, :K].reshape(B, P, K)
+    want = torch.from_numpy(ref).to(DEV).to(tdt(dtype))
+    assert torch.equal(got, want)                            # integer-indexed copy: bit exact
+    assert float(out[:, K:].float().abs().max()) == 0.0     # zero padding
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [1, 3, 4])
+def test_patchify_bit_exact(ops, dtype, C):
+    B, P, V = 2, 80, 561
+    x = detgen.normal("p/x", (B, C, P, V), seed=C)
+    out = ops.patchify(torch.from_numpy(x).to(DEV), dtype)
+    K = V * C
+    want = torch.from_numpy(sit_oracle.tokens_from_patches(x)).to(DEV).to(tdt(dtype))
+    assert torch.equal(out[:, :K].reshape(B, P, K), want)
+    assert float(out[:, K:].float().abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(321 * 2, 192, 192), (321 * 2 + 5, 576, 192), (640, 768, 192), (323, 192, 768), (2 * 320, 612, 192),
+               (2 * 320, 192, 640), (130, 64, 64), (17, 1536, 384)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_integer_exact(ops, dtype, M, N, K):
+    """Exact small-integer data with an asymmetric W: any row/col swap or k-slot mismatch fails."""
+    A = ints("gi/A", (M, K))
+    W = ints("gi/W", (N, K), -2, 3)
+    W[0, :] += 1.0                                            # break symmetry
+    out = torch.empty((M, N), dtype=tdt(dtype), device=DEV)
+    ops.gemm_nt(A.to(tdt(dtype)), W.to(tdt(dtype)), out, dtype)
+    ref = A @ W.t()
+    if dtype == "bf16":
+        ref = ref.to(torch.bfloat16)                         # |sums| can exceed 256: compare after the same rounding
+    assert torch.equal(out, ref.to(out.dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES[:6])
+def test_gemm_nt_epilogues(ops, dtype, M, N, K):
+    td = tdt(dtype)
+    A = rnd("ge/A", (M, K))
+    W = rnd("ge/W", (N, K), 1 / math.sqrt(K))
+    bias = rnd("ge/b", (N,), 0.1)
+    res = rnd("ge/r", (M, N))
+    Ad, Wd = A.to(td), W.to(td)
+    base = Ad.float() @ Wd.float().t()
+    tol = TOL[dtype]
+    # STORE, A fp32 (converted on load), out fp32 with bias
+    o = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A, Wd, o, dtype, bias=bias)
+    assert rel(o, base + bias) < tol
+    # STORE, out in compute dtype
+    o2 = torch.empty((M, N), dtype=td, device=DEV)
+    ops.gemm_nt(Ad, Wd, o2, dtype)
+    assert rel(o2, base) < tol
+    # BIAS_RES
+    o3 = torch.empty((M, N), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(Ad, Wd, o3, dtype, epilogue=ops.EPI_BIAS_RES, bias=bias, aux=res)
+    assert rel(o3, base + bias + res) < tol
+    # BIAS_GELU
+    u = torch.empty((M, N), dtype=td, device=DEV)
+    g = torch.empty((M, N), dtype=td, device=DEV)
+    ops.gemm_nt(Ad, Wd, u, dtype, epilogue=ops.EPI_BIAS_GELU, bias=bias, out2=g)
+    assert rel(u, base + bias) < tol
+    assert rel(g, torch.nn.functional.gelu(base + bias)) < tol
+    # DGELU (A fp32)
+    o4 = torch.empty((M, N), dtype=td, device=DEV)
+    ops.gemm_nt(A, Wd, o4, dtype, epilogue=ops.EPI_DGELU, aux=u)
+    uf = u.float().requires_grad_(True)
+    torch.nn.functional.gelu(uf).backward(torch.ones_like(uf))
+    assert rel(o4, base * uf.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_rowmaps(ops, dtype):
+    """Embedding layout: token row b*P+p -> residual row b*(P+1)+1+p, + bias + pos[1+p]."""
+    td = tdt(dtype)
+    B, P, K, D = 3, 80, 128, 192
+    A = rnd("gm/A", (B * P, K)).to(td)
+    W = rnd("gm/W", (D, K), 0.1).to(td)
+    bias = rnd("gm/b", (D,), 0.1)
+    pos = rnd("gm/pos", (P + 1, D))
+    out = torch.zeros((B * (P + 1), D), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A, W, out, dtype, epilogue=ops.EPI_BIAS_RES, bias=bias, aux=pos, omap=(P, P + 1, 1), auxmap=(P, 0, 1))
+    ref = (A.float() @ W.float().t() + bias).reshape(B, P, D) + pos[1:]
+    got = out.reshape(B, P + 1, D)
+    assert rel(got[:, 1:], ref) < TOL[dtype]
+    assert float(got[:, 0].abs().max()) == 0.0               # cls rows untouched
+    # A-side map: read rows b*(P+1)+1+p of a (B*(P+1), K) buffer
+    A2 = rnd("gm/A2", (B * (P + 1), K)).to(td)
+    o2 = torch.empty((B * P, D), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A2, W, o2, dtype, M=B * P, amap=(P, P + 1, 1))
+    ref2 = A2.float().reshape(B, P + 1, K)[:, 1:].reshape(B * P, K) @ W.float().t()
+    assert rel(o2, ref2) < TOL[dtype]
+
+
+WGRAD_SHAPES = [(321 * 4, 576, 192), (321 * 4 + 3, 192, 192), (1000, 768, 192), (700, 192, 768), (640, 192, 640),
+                (640, 616, 192), (100, 64, 64)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", WGRAD_SHAPES)
+def test_wgrad_integer_exact(ops, dtype, M, N, K):
+    """Transposed LDS fragment reads (ds_read_b64_tr_b16 in bf16 mode) checked with exact integers."""
+    td = tdt(dtype)
+    dY = ints("wi/dY", (M, N), -2, 3)
+    X = ints("wi/X", (M, K), -2, 3)
+    X[:, 0] += 1.0
+    dW = torch.zeros((N, K), dtype=torch.float32, device=DEV)
+    db = torch.zeros((N,), dtype=torch.float32, device=DEV)
+    ops.gemm_wgrad(dY.to(td), X.to(td), dW, dtype, db=db)
+    assert torch.equal(dW, dY.t() @ X)                       # integer sums < 2^24: exact in fp32
+    assert torch.equal(db, dY.sum(0))
+    # accumulate semantics + fp32 dY
+    ops.gemm_wgrad(dY, X.to(td), dW, dtype)
+    assert torch.equal(dW, 2 * (dY.t() @ X))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_random_and_rowmap(ops, dtype):
+    td = tdt(dtype)
+    B, P, N, K = 3, 80, 192, 128
+    dY = rnd("wr/dY", (B * P, N))
+    X = rnd("wr/X", (B * (P + 1), K)).to(td)
+    dW = torch.zeros((N, K), dtype=torch.float32, device=DEV)
+    ops.gemm_wgrad(dY, X, dW, dtype, M=B * P, xmap=(P, P + 1, 1))
+    Xs = X.float().reshape(B, P + 1, K)[:, 1:].reshape(B * P, K)
+    dYr = dY.to(td).float()
+    assert rel(dW, dYr.t() @ Xs) < TOL[dtype]
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [192, 384, 768, 200])
+def test_layernorm_fwd_bwd(ops, dtype, D):
+    rows = 321 * 2 + 3
+    x = rnd("ln/x", (rows, D), 2.0) + 0.5
+    g = 1 + 0.1 * rnd("ln/g", (D,))
+    b = 0.1 * rnd("ln/b", (D,))
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, dtype)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-5)
+    tol = 1e-5 if dtype == "f32" else 4e-3
+    assert rel(y, yr) < tol
+    assert rel(mean, x.mean(1)) < 1e-5 and rel(rstd, (x.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    dy = rnd("ln/dy", (rows, D))
+    dres = rnd("ln/dres", (rows, D))
+    dyd = dy.to(tdt(dtype))
+    yr.backward(dyd.float())
+    dgam = torch.zeros(D, device=DEV)
+    dbet = torch.zeros(D, device=DEV)
+    dx = ops.layernorm_bwd(dyd, x, mean, rstd, g, dres, dgam, dbet, dtype)
+    assert rel(dx, xr.grad + dres) < 2e-5
+    assert rel(dgam, gr.grad) < 2e-5 and rel(dbet, br.grad) < 2e-5
+    # in place on the residual-gradient buffer
+    buf = dres.clone()
+    ops.layernorm_bwd(dyd, x, mean, rstd, g, buf, dgam, dbet, dtype, dx=buf)
+    assert rel(buf, xr.grad + dres) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, B, N, H, scale):
+    q, k, v = qkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * scale
+    p = s.softmax(-1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * N, H * 64)
+    return o, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,H", [(2, 321, 3), (1, 81, 6), (2, 64, 1), (1, 130, 2), (1, 1281, 2)])
+def test_attention_fwd_bwd(ops, dtype, B, N, H):
+    td = tdt(dtype)
+    qkv = rnd("at/qkv", (B * N, 3 * H * 64), 1.0).to(td)
+    scale = 0.125
+    o, lse = ops.attention_fwd(qkv, B, N, H, scale, dtype)
+    qr = qkv.float().requires_grad_(True)
+    oref, lref = _attn_ref(qr, B, N, H, scale)
+    tol = TOL[dtype]
+    assert rel(o, oref) < tol
+    assert rel(lse, lref) < (1e-5 if dtype == "f32" else 2e-3)
+    do = rnd("at/do", (B * N, H * 64)).to(td)
+    oref.backward(do.float())
+    dqkv = ops.attention_bwd(qkv, o, do, lse, B, N, H, scale, dtype)
+    I = H * 64
+    for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
+        e = rel(dqkv[:, sl], qr.grad[:, sl])
+        assert e < (5e-5 if dtype == "f32" else 2e-2), (name, e)
+
+
+def test_attention_large_scores_online_softmax(ops):
+    """Forces the running-max rescale: one key per row dominates in a late tile."""
+    B, N, H = 1, 200, 1
+    qkv = rnd("at2/qkv", (N, 192), 0.3)
+    qkv[:, 0:64] *= 4.0
+    qkv[150, 64:128] = 6.0 * qkv[10, 0:64]                   # key 150 aligned with query 10 (third tile)
+    o, lse = ops.attention_fwd(qkv, B, N, H, 0.125, "f32")
+    oref, lref = _attn_ref(qkv, B, N, H, 0.125)
+    assert rel(o, oref) < 2e-5 and rel(lse, lref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+def _encoder_params(enc):
+    per_layer = []
+    for attn, ff in enc.layers:
+        per_layer.append([attn.norm.weight, attn.norm.bias, attn.fn.to_qkv.weight, attn.fn.to_out[0].weight,
+                          attn.fn.to_out[0].bias, ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias,
+                          ff.fn.net[3].weight, ff.fn.net[3].bias])
+    return per_layer
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("dim,heads,mlp,N,depth", [(192, 3, 768, 321, 2), (384, 6, 1536, 81, 1), (192, 3, 768, 1281, 1)])
+def test_encoder_fwd_bwd_vs_oracle(ops, dtype, dim, heads, mlp, N, depth):
+    B = 2
+    enc = sit_oracle.Encoder(dim, depth, heads, 64, mlp)
+    vals = detgen.fill_state_dict(enc.state_dict(), seed=21)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+    x = detgen.normal("enc/x", (B, N, dim), seed=1)
+    dy = detgen.normal("enc/dy", (B, N, dim), seed=2)
+    xr = torch.from_numpy(x).requires_grad_(True)
+    yr = enc(xr)
+    yr.backward(torch.from_numpy(dy))
+
+    dev_params = [[p.detach().to(DEV).contiguous() for p in layer] for layer in _encoder_params(enc)]
+    dev_grads = [[torch.zeros_like(p) for p in layer] for layer in dev_params]
+    cfg = ops.encoder_cfg(B, N, dim, depth, heads, mlp, dtype)
+    acts, scratch = ops.encoder_workspace(cfg, DEV)
+    P, G = ops.layer_param_array(dev_params), ops.layer_param_array(dev_grads)
+    xin = torch.from_numpy(x).to(DEV).reshape(B * N, dim).contiguous()
+    xout = torch.empty_like(xin)
+    ops.encoder_fwd(cfg, P, xin, xout, acts, scratch, save=True)
+    tol_f, tol_g = (1e-4, 5e-4) if dtype == "f32" else (1e-2, 4e-2)
+    assert rel(xout.reshape(B, N, dim), yr.detach()) < tol_f
+    # forward-only schedule gives the same output
+    xo2 = torch.empty_like(xin)
+    acts2, scratch2 = ops.encoder_workspace(cfg, DEV)
+    ops.encoder_fwd(cfg, P, xin, xo2, acts2, scratch2, save=False)
+    assert torch.equal(xo2, xout)
+    dx = torch.from_numpy(dy).to(DEV).reshape(B * N, dim).contiguous()
+    if depth > 1:    # two slices == one call
+        ops.encoder_bwd(cfg, P, G, xin, dx, acts, scratch, layer_begin=1, layer_end=depth)
+        ops.encoder_bwd(cfg, P, G, xin, dx, acts, scratch, layer_begin=0, layer_end=1)
+    else:
+        ops.encoder_bwd(cfg, P, G, xin, dx, acts, scratch)
+    assert rel(dx.reshape(B, N, dim), xr.grad) < tol_g
+    worst = 0.0
+    for layer_ref, layer_g in zip(_encoder_params(enc), dev_grads):
+        for name, pr, g in zip(("ln1_w", "ln1_b", "wqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2"), layer_ref, layer_g):
+            e = rel(g, pr.grad)
+            worst = max(worst, e)
+            assert e < tol_g, (name, e)
+    print(f"encoder {dtype} dim={dim} N={N}: fwd {rel(xout.reshape(B, N, dim), yr.detach()):.2e} worst grad {worst:.2e}")
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pool_mean", [0, 1])
+@pytest.mark.parametrize("ncls", [1, 3])
+def test_head_fwd_bwd(ops, pool_mean, ncls):
+    B, N, D = 5, 81, 192
+    x = rnd("hd/x", (B, N, D))
+    lw, lb = 1 + 0.1 * rnd("hd/lw", (D,)), 0.1 * rnd("hd/lb", (D,))
+    w, b = rnd("hd/w", (ncls, D), 0.1), rnd("hd/b", (ncls,), 0.1)
+    leaves = [t.clone().requires_grad_(True) for t in (x, lw, lb, w, b)]
+    xr, lwr, lbr, wr, br = leaves
+    pooled = xr.mean(1) if pool_mean else xr[:, 0]
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(pooled, (D,), lwr, lbr, 1e-5), wr, br)
+    out = ops.head_fwd(x.reshape(B * N, D), lw, lb, w, b, B, N, D, pool_mean)
+    assert rel(out, ref) < 1e-5
+    dl = rnd("hd/dl", (B, ncls))
+    ref.backward(dl)
+    dx = torch.full((B * N, D), 7.0, device=DEV)
+    grads = [torch.zeros_like(t) for t in (lw, lb, w, b)]
+    ops.head_bwd(x.reshape(B * N, D), lw, lb, w, dl, dx, *grads, B, N, D, pool_mean)
+    assert rel(dx.reshape(B, N, D), xr.grad) < 1e-5
+    for g, r in zip(grads, (lwr, lbr, wr, br)):
+        assert rel(g, r.grad) < 1e-5
+
+
+@pytest.mark.parametrize("l1", [0, 1])
+def test_loss(ops, l1):
+    p, t = rnd("ls/p", (64,)), rnd("ls/t", (64,))
+    pr = p.clone().requires_grad_(True)
+    ref = torch.nn.functional.l1_loss(pr, t) if l1 else torch.nn.functional.mse_loss(pr, t)
+    ref.backward()
+    loss = torch.zeros(1, device=DEV)
+    dp = torch.empty_like(p)
+    ops.loss_fwd_bwd(p, t, loss, dp, l1=bool(l1))
+    assert rel(loss, ref.detach().reshape(1)) < 1e-6 and rel(dp, pr.grad) < 1e-6
+
+
+def test_colsum_and_masked_colsum(ops):
+    x = rnd("cs/x", (700, 192))
+    out = torch.zeros(192, device=DEV)
+    ops.colsum_f32(x, out)
+    assert rel(out, x.sum(0)) < 1e-5
+    fa = (torch.from_numpy(detgen.uniform01("cs/fa", (700,))) < 0.5).to(DEV).to(torch.uint8)
+    fb = (torch.from_numpy(detgen.uniform01("cs/fb", (700,))) < 0.5).to(DEV).to(torch.uint8)
+    out2 = torch.zeros(192, device=DEV)
+    ops.masked_colsum(x, fa, fb, out2, "f32")
+    assert rel(out2, (x * (fa & fb).float()[:, None]).sum(0)) < 1e-5
+    xb = x.to(torch.bfloat16)
+    out3 = torch.zeros(192, device=DEV)
+    ops.masked_colsum(xb, fa, None, out3, "bf16")
+    assert rel(out3, (xb.float() * fa.float()[:, None]).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mpp_corrupt_and_loss(ops, dtype):
+    B, P, K = 3, 80, 612
+    tok = rnd("mp/tok", (B * P, K))
+    torch.manual_seed(5)
+    rndm = sit_oracle.draw_mpp_randoms(B, P, 0.5, 0.5, 0.3)
+    mt = rnd("mp/mt", (K,))
+    model = sit_oracle.MaskedPatchPretraining(torch.nn.Identity(), 8, 8, mask_prob=0.5, replace_prob=0.5, swap_prob=0.3,
+                                              channels=4, num_vertices=153)
+    with torch.no_grad():
+        model.mask_token.copy_(mt.cpu().reshape(1, 1, K))
+    ref = model.corrupt(tok.cpu().reshape(B, P, K), rndm).detach()
+    u8 = lambda t: t.to(DEV).to(torch.uint8).reshape(-1).contiguous()  # noqa: E731
+    out = ops.mpp_corrupt(tok, u8(rndm["corrupted_sequence"]), u8(rndm["swap_draw"]),
+                          rndm["random_patches"].to(DEV).to(torch.int32).reshape(-1).contiguous(),
+                          u8(rndm["replace_draw"]), mt, B, P, K, dtype)
+    assert torch.equal(out[:, :K], ref.reshape(B * P, K).to(DEV).to(tdt(dtype)))
+    assert float(out[:, K:].float().abs().max()) == 0.0
+    # masked MSE
+    pred = rnd("mp/pred", (B * P, K))
+    masked = rndm["corrupted_sequence"].reshape(-1)
+    pr = pred.cpu().clone().requires_grad_(True)
+    lref = torch.nn.functional.mse_loss(pr[masked], tok.cpu()[masked])
+    lref.backward()
+    loss = torch.zeros(1, device=DEV)
+    dout = torch.empty_like(pred)
+    ops.mpp_loss_fwd_bwd(pred, tok, u8(rndm["corrupted_sequence"]), loss, dout, int(masked.sum()))
+    assert rel(loss, lref.detach().reshape(1)) < 1e-5 and rel(dout, pr.grad) < 1e-5
+
+
+def test_optimizers_match_torch(ops):
+    n = 10007
+    p0, g = rnd("op/p", (n,)), rnd("op/g", (n,))
+    for kw in (dict(momentum=0.9), dict(momentum=0.9, weight_decay=0.01, nesterov=True), dict(momentum=0.0)):
+        pr = p0.clone().requires_grad_(True)
+        opt = torch.optim.SGD([pr], lr=0.01, **kw)
+        p, buf = p0.clone(), torch.zeros(n, device=DEV)
+        for _ in range(3):
+            pr.grad = g.clone()
+            opt.step()
+            ops.sgd_step(p, g, buf, 0.01, kw.get("momentum", 0.0), kw.get("weight_decay", 0.0), kw.get("nesterov", False))
+        assert rel(p, pr.detach()) < 1e-6
+    for cls, dec in ((torch.optim.Adam, False), (torch.optim.AdamW, True)):
+        pr = p0.clone().requires_grad_(True)
+        opt = cls([pr], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+        p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for step in range(1, 4):
+            pr.grad = g.clone()
+            opt.step()
+            ops.adam_step(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, dec, step)
+        assert rel(p, pr.detach()) < 1e-6
