@@ -320,6 +320,18 @@ struct TrFrag<float> {
   }
 };
 
+// tail chunk of a row whose length is not a multiple of the 16-byte vector: element-wise, zero filled
+template <typename T, typename TS>
+SITK_DEV u32x4 vec_load_partial(const TS* p, int nvalid) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  T tmp[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) tmp[e] = from_f32<T>(e < nvalid ? to_f32(p[e]) : 0.f);
+  u32x4 r;
+  __builtin_memcpy(&r, tmp, 16);
+  return r;
+}
+
 template <typename T, typename TDY>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int EPV = Mma<T>::EPV;
@@ -351,7 +363,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       const int c = tid + 256 * i, row = c / CPR, cc = c % CPR, m = mt + row;
       const int n = n0 + cc * EPV, k = k0 + cc * EPV;
       const bool ok = m < mend;
-      ry[i] = (ok && n < p.N) ? VecLoad<T, TDY>::load(dY + (size_t)map_row(p.dymap, m) * p.lddy + n) : zero;
+      ry[i] = zero;
+      if (ok && n < p.N) {
+        const TDY* src = dY + (size_t)map_row(p.dymap, m) * p.lddy + n;
+        ry[i] = (n + EPV <= p.N) ? VecLoad<T, TDY>::load(src) : vec_load_partial<T, TDY>(src, p.N - n);
+      }
       rx[i] = (ok && k < p.K) ? VecLoad<T, T>::load(X + (size_t)map_row(p.xmap, m) * p.ldx + k) : zero;
     }
   };
@@ -463,7 +479,7 @@ extern "C" int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_
   using namespace sitk;
   SITK_REQUIRE(d != nullptr, "gemm_wgrad: null descriptor");
   SITK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_wgrad: empty problem");
-  SITK_REQUIRE(d->N % 8 == 0 && d->K % 8 == 0, "gemm_wgrad: N, K multiples of 8 required (N=%d K=%d)", d->N, d->K);
+  SITK_REQUIRE(d->N % 4 == 0 && d->K % 8 == 0, "gemm_wgrad: N %% 4 and K %% 8 required (N=%d K=%d)", d->N, d->K);
   SITK_REQUIRE(d->lddy % 4 == 0 && d->ldx % 8 == 0, "gemm_wgrad: leading dims must keep 16-byte alignment");
   SITK_REQUIRE(d->dY && d->X && d->dW, "gemm_wgrad: null operand");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -1,0 +1,173 @@
+"""Surface Vision Transformer on the MI355X-native kernels.
+
+Host-side mirror of the reference's models/sit.py:26-82: same keyword-only constructor, same
+attribute names (`to_patch_embedding`, `pos_embedding`, `cls_token`, `dropout`, `transformer`,
+`pool`, `to_latent`, `mlp_head` -- the first five are reached from models/mpp.py:115-128), same
+state-dict keys (pinned by utils/utils.py:13-33), same forward signature.  The
+third-party `vit_pytorch.vit.Transformer` the reference constructs at models/sit.py:57 is
+replaced by `Transformer` below, whose parameters keep the PreNorm-generation layout
+(layers.i.0.norm / .0.fn.to_qkv / .0.fn.to_out.0 / .1.norm / .1.fn.net.0 / .1.fn.net.3).
+
+All arithmetic runs in libsitk.so (HIP, gfx950).  Additions over the reference API:
+  * `compute_dtype` ('bf16' default | 'f32'): MFMA operand type (see include/sitk.h);
+  * forward also accepts a raw channels-last surface (B, 40962, C) and gathers the patches on the
+    GPU (tools/preprocessing.py:74-84) with the table registered for (num_patches, num_vertices).
+There is no CPU forward: tensors must be on the GPU.
+"""
+import torch
+from torch import nn
+
+from .. import functional as Fn
+from .. import ops, tables
+from ..runtime import SitkError
+
+
+class PreNorm(nn.Module):
+    """Parameter container: LayerNorm(dim) applied before `fn` (keys `.norm.*`, `.fn.*`)."""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads, dim_head, dropout):
+        super().__init__()
+        if dim_head != 64:
+            raise SitkError(f"dim_head={dim_head}: the attention kernels are specialised for dim_head=64 "
+                            "(every reference config: config/SiT/training/hparams.yml:33-45)")
+        inner = heads * dim_head
+        self.heads, self.dim_head = heads, dim_head
+        self.scale = dim_head ** -0.5
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+
+class Transformer(nn.Module):
+    """depth x [x += to_out(softmax(q k^T * scale) v); x += W2 gelu(W1 LN(x) + b1) + b2], positional
+    ctor (dim, depth, heads, dim_head, mlp_dim, dropout) as at models/sit.py:57."""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.0, compute_dtype="bf16"):
+        super().__init__()
+        self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, mlp_dim
+        self.p_dropout = float(dropout)
+        self.compute_dtype = compute_dtype
+        self.layers = nn.ModuleList([
+            nn.ModuleList([PreNorm(dim, Attention(dim, heads, dim_head, dropout)),
+                           PreNorm(dim, FeedForward(dim, mlp_dim, dropout))])
+            for _ in range(depth)])
+
+    def layer_tensors(self):
+        """Per layer, the 11 parameters in the C ABI's sitk_layer_params order."""
+        out = []
+        for attn, ff in self.layers:
+            out.append([attn.norm.weight, attn.norm.bias, attn.fn.to_qkv.weight, attn.fn.to_out[0].weight,
+                        attn.fn.to_out[0].bias, ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight,
+                        ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias])
+        return out
+
+    def forward(self, x):
+        if self.training and self.p_dropout > 0:
+            raise SitkError("dropout > 0 inside the encoder is not implemented on the HIP path "
+                            "(every reference config uses dropout 0.0: config/SiT/*/hparams.yml)")
+        if not x.is_cuda:
+            raise SitkError("sitk Transformer: input must be on the GPU (no CPU path)")
+        flat = [p for layer in self.layer_tensors() for p in layer]
+        cfg = (self.dim, self.depth, self.heads, self.mlp_dim, self.compute_dtype)
+        return Fn.EncoderFn.apply(x.float(), cfg, *flat)
+
+
+class ToTokens(nn.Module):
+    """Index 0 of `to_patch_embedding`: 'b c n v -> b n (v c)' (models/sit.py:49). Returns fp32
+    tokens (B, P, V*C) so that external callers (models/mpp.py:82-83 style) see the reference layout."""
+
+    def forward(self, x):
+        B, C, P, V = x.shape
+        if not x.is_cuda:
+            raise SitkError("sitk: input must be on the GPU (no CPU path)")
+        K = V * C
+        return ops.patchify(x.float(), "f32", ld=ops.pad8(K))[:, :K].reshape(B, P, K)
+
+
+class PatchLinear(nn.Linear):
+    """Index 1 of `to_patch_embedding` (key `to_patch_embedding.1.*`): callable on (B, P, K) fp32
+    exactly like the nn.Linear the reference reaches into at models/mpp.py:115."""
+
+    compute_dtype = "bf16"
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise SitkError("sitk: input must be on the GPU (no CPU path)")
+        return Fn.LinearFn.apply(x.float(), self.weight, self.bias, self.compute_dtype)
+
+
+class SiT(nn.Module):
+    def __init__(self, *, dim, depth, heads, mlp_dim, pool="cls", num_patches=20, num_classes=1, num_channels=4,
+                 num_vertices=2145, dim_head=64, dropout=0.0, emb_dropout=0.0, compute_dtype="bf16"):
+        super().__init__()
+        assert pool in {"cls", "mean"}, "pool type must be either cls (cls token) or mean (mean pooling)"
+        patch_dim = num_channels * num_vertices
+        self.num_patches, self.num_vertices, self.num_channels = num_patches, num_vertices, num_channels
+        self.dim, self.patch_dim = dim, patch_dim
+        self.compute_dtype = compute_dtype
+
+        self.to_patch_embedding = nn.Sequential(ToTokens(), PatchLinear(patch_dim, dim))
+        self.to_patch_embedding[1].compute_dtype = compute_dtype
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.dropout = nn.Dropout(emb_dropout)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout, compute_dtype=compute_dtype)
+        self.pool = pool
+        self.to_latent = nn.Identity()
+        self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
+        self._table = None           # numpy (P, V) uint16
+        self._table_dev = {}
+
+    # ---- patch table for the raw-surface entry ---------------------------------------------------
+    def set_patch_table(self, table_pv):
+        """Use a custom (num_patches, num_vertices) table of ico-6 vertex ids."""
+        assert tuple(table_pv.shape) == (self.num_patches, self.num_vertices)
+        self._table, self._table_dev = table_pv, {}
+
+    def patch_table(self, device):
+        if self._table is None:
+            self._table = tables.load_table(self.num_patches, self.num_vertices)
+        key = str(device)
+        if key not in self._table_dev:
+            self._table_dev[key] = tables.table_tensor(self._table, device)
+        return self._table_dev[key]
+
+    # ---- stages -------------------------------------------------------------------------------------
+    def tokens(self, img):
+        """(B, C, P, V) pre-patched [reference layout] or (B, 40962, C) raw surface -> (B*P, ld)
+        tokens in the compute dtype, zero padded to a multiple of 64 features."""
+        if not img.is_cuda:
+            raise SitkError("sitk SiT: input must be on the GPU (no CPU path)")
+        if img.dim() == 4:
+            return ops.patchify(img.float(), self.compute_dtype), img.shape[0]
+        if img.dim() == 3:
+            if img.shape[1] != tables.ICO6_VERTICES or img.shape[2] != self.num_channels:
+                raise SitkError(f"raw surface must be (B, {tables.ICO6_VERTICES}, {self.num_channels}), got {tuple(img.shape)}")
+            return ops.gather_tokens(img.float().contiguous(), self.patch_table(img.device), self.compute_dtype), img.shape[0]
+        raise SitkError(f"SiT.forward expects (B, C, P, V) or (B, 40962, C), got {tuple(img.shape)}")
+
+    def embed(self, tokens, B):
+        lin = self.to_patch_embedding[1]
+        x = Fn.EmbedFn.apply(tokens, lin.weight, lin.bias, self.cls_token, self.pos_embedding, B, self.num_patches,
+                             self.compute_dtype)
+        return self.dropout(x)
+
+    def forward(self, img):
+        tokens, B = self.tokens(img)
+        x = self.embed(tokens, B)
+        x = self.transformer(x)
+        ln, fc = self.mlp_head[0], self.mlp_head[1]
+        return Fn.HeadFn.apply(self.to_latent(x), ln.weight, ln.bias, fc.weight, fc.bias, self.pool == "mean")

@@ -1,0 +1,106 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/sitk.h
+declares, the modules keep the reference's constructor / attribute / state-dict surface, and the
+product refuses to run without a GPU instead of falling back."""
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import sit_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sitk_pkg():
+    lib = os.path.join(ROOT, "surface-vision-transformers_amd", "libsitk.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+        __graft_entry__.build()
+    import sitk
+    return sitk
+
+
+def test_library_exports_every_declared_symbol(sitk_pkg):
+    from sitk import runtime
+    header = open(os.path.join(ROOT, "include", "sitk.h")).read()
+    declared = set(re.findall(r"\b(sitk_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(runtime.EXPORTED_SYMBOLS), declared ^ set(runtime.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(runtime.lib, name)
+    assert runtime.lib.sitk_abi_version() == runtime.ABI_VERSION
+    assert runtime.lib.sitk_dtype_size(runtime.BF16) == 2 and runtime.lib.sitk_dtype_size(runtime.F32) == 4
+
+
+def test_argument_validation_without_gpu(sitk_pkg):
+    """Validation errors are raised before any launch, so they are testable on CPU."""
+    import ctypes as C
+    from sitk import runtime as rt
+    d = rt.GemmDesc()
+    d.M, d.N, d.K = 4, 6, 8                       # N % 4 != 0
+    assert rt.lib.sitk_gemm_nt(C.byref(d), rt.BF16, None) == -1
+    assert b"N % 4" in rt.lib.sitk_last_error()
+    cfg = rt.EncoderCfg(2, 321, 190, 12, 3, 768, rt.BF16)   # dim not a multiple of 8
+    assert rt.lib.sitk_encoder_acts_bytes(C.byref(cfg)) == 0
+    cfg = rt.EncoderCfg(64, 321, 192, 12, 3, 768, rt.BF16)
+    assert rt.lib.sitk_encoder_acts_bytes(C.byref(cfg)) > 10 ** 9
+
+
+@pytest.mark.parametrize("size,P,V", [("tiny", 320, 153), ("small", 80, 561), ("base", 1280, 45)])
+def test_state_dict_surface_matches_reference_layout(sitk_pkg, size, P, V):
+    from sitk.models.sit import SiT
+    kw = dict(sit_oracle.MODEL_SIZES[size], num_patches=P, num_vertices=V, num_channels=4, depth=2)
+    ours, ref = SiT(**kw), sit_oracle.SiT(**kw)
+    so, sr = ours.state_dict(), ref.state_dict()
+    assert list(so.keys()) == list(sr.keys())
+    assert all(so[k].shape == sr[k].shape for k in so)
+    ours.load_state_dict(sr)                                   # reference-layout checkpoints load strictly
+    # keys addressed by utils/utils.py:13-33
+    for k in ("mlp_head.0.weight", "transformer.layers.1.0.norm.bias", "transformer.layers.0.0.fn.to_qkv.weight",
+              "transformer.layers.0.0.fn.to_out.0.bias", "transformer.layers.1.1.fn.net.0.weight",
+              "transformer.layers.1.1.fn.net.3.bias", "to_patch_embedding.1.weight", "pos_embedding", "cls_token"):
+        assert k in so
+    assert "transformer.layers.0.0.fn.to_qkv.bias" not in so
+    for attr in ("to_patch_embedding", "cls_token", "pos_embedding", "dropout", "transformer", "pool", "to_latent", "mlp_head"):
+        assert hasattr(ours, attr)
+
+
+def test_mpp_surface(sitk_pkg):
+    from sitk.models.mpp import masked_patch_pretraining
+    from sitk.models.sit import SiT
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], num_patches=320, num_vertices=153, depth=1)
+    ssl = masked_patch_pretraining(SiT(**kw), 192, 612, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
+                                   channels=4, num_vertices=153)
+    ref = sit_oracle.MaskedPatchPretraining(sit_oracle.SiT(**kw), 192, 612, channels=4, num_vertices=153)
+    assert list(ssl.state_dict().keys()) == list(ref.state_dict().keys())
+    assert ssl.mask_token.shape == (1, 1, 612) and ssl.to_original.weight.shape == (612, 192)
+
+
+def test_ctor_validation(sitk_pkg):
+    from sitk.models.sit import SiT
+    from sitk.runtime import SitkError
+    with pytest.raises(AssertionError):
+        SiT(dim=192, depth=1, heads=3, mlp_dim=768, pool="max")
+    with pytest.raises(SitkError):
+        SiT(dim=192, depth=1, heads=3, mlp_dim=768, dim_head=32)
+    with pytest.raises(TypeError):
+        SiT(192, 1, 3, 768)                                     # keyword-only, like models/sit.py:26
+
+
+def test_no_cpu_fallback(sitk_pkg):
+    from sitk.models.sit import SiT
+    from sitk.runtime import SitkError
+    m = SiT(dim=192, depth=1, heads=3, mlp_dim=768, num_patches=80, num_vertices=561)
+    with pytest.raises(SitkError):
+        m(torch.zeros(1, 4, 80, 561))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "surface-vision-transformers_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f
