@@ -51,7 +51,7 @@ int sitk_dtype_size(int dtype);
  *   x_bvc     (B, n_vertices, C) fp32, channels last (C == 4)
  *   table_pv  (P, V) uint16, PATCH-major vertex ids (ids < n_vertices)
  *   tokens    (B*P, ld) `dtype`; columns [0, V*C) are written as f = v*C + c, columns
- *             [V*C, ld) are zero-filled (ld >= V*C, multiple of 8) so GEMM K-tiles need no tail.
+ *             [V*C, ld) are zero-filled (ld >= V*C, multiple of 4; of 8 when it feeds a bf16 GEMM).
  * Integer-indexed copy: bit exact in SITK_F32; one RNE rounding per element in SITK_BF16.      */
 int sitk_gather_tokens(const float* x_bvc, const uint16_t* table_pv, void* tokens, int B, int n_vertices,
                        int C, int P, int V, int ld, int dtype, sitk_stream_t stream);

@@ -140,7 +140,7 @@ extern "C" int sitk_gather_tokens(const float* x_bvc, const uint16_t* table_pv, 
   SITK_REQUIRE(x_bvc && table_pv && tokens, "gather_tokens: null pointer");
   SITK_REQUIRE(C == 4, "gather_tokens: channels-last gather is specialised for num_channels == 4 (got %d); use patchify", C);
   SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "gather_tokens: bad shape");
-  SITK_REQUIRE(ld >= V * C && ld % 8 == 0, "gather_tokens: ld=%d must be >= V*C=%d and a multiple of 8", ld, V * C);
+  SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "gather_tokens: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SITK_BF16) return run_gather<bf16>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, s);
   if (dtype == SITK_F32) return run_gather<float>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, s);
@@ -153,7 +153,7 @@ extern "C" int sitk_patchify(const float* x_bcpv, void* tokens, int B, int C, in
   using namespace sitk;
   SITK_REQUIRE(x_bcpv && tokens, "patchify: null pointer");
   SITK_REQUIRE(B > 0 && P > 0 && V > 0 && C > 0, "patchify: bad shape");
-  SITK_REQUIRE(ld >= V * C && ld % 8 == 0, "patchify: ld=%d must be >= V*C=%d and a multiple of 8", ld, V * C);
+  SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "patchify: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SITK_BF16) return run_patchify<bf16>(x_bcpv, tokens, B, C, P, V, ld, s);
   if (dtype == SITK_F32) return run_patchify<float>(x_bcpv, tokens, B, C, P, V, ld, s);

@@ -81,6 +81,18 @@ SITK_DEV void gemm_epilogue(const GemmParams& p, int m, int n, f32x4 v) {
   }
 }
 
+// tail chunk of a row whose length is not a multiple of the 16-byte vector: element-wise, zero filled
+template <typename T, typename TS>
+SITK_DEV u32x4 vec_load_partial(const TS* p, int nvalid) {
+  constexpr int EPV = 16 / (int)sizeof(T);
+  T tmp[EPV];
+#pragma unroll
+  for (int e = 0; e < EPV; ++e) tmp[e] = from_f32<T>(e < nvalid ? to_f32(p[e]) : 0.f);
+  u32x4 r;
+  __builtin_memcpy(&r, tmp, 16);
+  return r;
+}
+
 // ------------------------------------------------------------------------------------------
 // NT GEMM.  256 threads = 4 waves arranged WM (token) x WN (feature).
 // ------------------------------------------------------------------------------------------
@@ -124,12 +136,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int k = kb + ((tid + 256 * i) & 7) * EPV;
-      ra[i] = (a_ok[i] && k < p.K) ? VecLoad<T, TA>::load(A + a_base[i] + kb) : zero;
+      ra[i] = zero;
+      if (a_ok[i] && k < p.K)
+        ra[i] = (k + EPV <= p.K) ? VecLoad<T, TA>::load(A + a_base[i] + kb) : vec_load_partial<T, TA>(A + a_base[i] + kb, p.K - k);
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       const int k = kb + ((tid + 256 * i) & 7) * EPV;
-      rw[i] = (w_ok[i] && k < p.K) ? VecLoad<T, T>::load(W + w_base[i] + kb) : zero;
+      rw[i] = zero;
+      if (w_ok[i] && k < p.K)
+        rw[i] = (k + EPV <= p.K) ? VecLoad<T, T>::load(W + w_base[i] + kb) : vec_load_partial<T, T>(W + w_base[i] + kb, p.K - k);
     }
   };
   auto lstore = [&]() {
@@ -320,18 +336,6 @@ struct TrFrag<float> {
   }
 };
 
-// tail chunk of a row whose length is not a multiple of the 16-byte vector: element-wise, zero filled
-template <typename T, typename TS>
-SITK_DEV u32x4 vec_load_partial(const TS* p, int nvalid) {
-  constexpr int EPV = 16 / (int)sizeof(T);
-  T tmp[EPV];
-#pragma unroll
-  for (int e = 0; e < EPV; ++e) tmp[e] = from_f32<T>(e < nvalid ? to_f32(p[e]) : 0.f);
-  u32x4 r;
-  __builtin_memcpy(&r, tmp, 16);
-  return r;
-}
-
 template <typename T, typename TDY>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   constexpr int EPV = Mma<T>::EPV;
@@ -465,8 +469,12 @@ extern "C" int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t st
   using namespace sitk;
   SITK_REQUIRE(d != nullptr, "gemm_nt: null descriptor");
   SITK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: empty problem %d %d %d", d->M, d->N, d->K);
-  SITK_REQUIRE(d->N % 4 == 0 && d->K % 8 == 0, "gemm_nt: N %% 4 and K %% 8 required (N=%d K=%d)", d->N, d->K);
-  SITK_REQUIRE(d->lda % 4 == 0 && d->ldw % 8 == 0 && d->ldo % 4 == 0, "gemm_nt: leading dims must keep 16-byte alignment");
+  SITK_REQUIRE(d->N % 4 == 0 && d->K % 4 == 0, "gemm_nt: N %% 4 and K %% 4 required (N=%d K=%d)", d->N, d->K);
+  {
+    const int vec_a = (d->a_is_f32 || dtype == SITK_F32) ? 4 : 8, vec_w = dtype == SITK_F32 ? 4 : 8;
+    SITK_REQUIRE(d->lda % vec_a == 0 && d->ldw % vec_w == 0 && d->ldo % 4 == 0,
+                 "gemm_nt: leading dims must keep rows 16-byte aligned (lda=%d ldw=%d ldo=%d)", d->lda, d->ldw, d->ldo);
+  }
   SITK_REQUIRE(d->A && d->W && d->out, "gemm_nt: null operand");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SITK_BF16) return dispatch_gemm_nt<bf16>(d, s);

@@ -314,7 +314,7 @@ extern "C" int sitk_mpp_corrupt(const float* tokens, const uint8_t* masked, cons
   using namespace sitk;
   SITK_REQUIRE(tokens && masked && replace_draw && mask_token && corrupted, "mpp_corrupt: null pointer");
   SITK_REQUIRE((swap_draw == nullptr) == (random_patches == nullptr), "mpp_corrupt: swap_draw and random_patches go together");
-  SITK_REQUIRE(B > 0 && P > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 8 == 0, "mpp_corrupt: bad shape K=%d ld=%d", K, ld);
+  SITK_REQUIRE(B > 0 && P > 0 && K > 0 && K % 4 == 0 && ld >= K && ld % 4 == 0, "mpp_corrupt: bad shape K=%d ld=%d", K, ld);
   const int64_t rows = (int64_t)B * P;
   dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -1,0 +1,335 @@
+"""Fused training step for the SiT hot path: the throughput counterpart of the reference's inner loops
+(tools/train.py:280-291 and tools/pretrain.py:309-319):
+
+    zero_grad -> forward -> loss -> backward -> [gradient all-reduce] -> optimizer.step
+
+It drives the same C-ABI kernels as the drop-in modules, but without autograd: parameters, gradients
+and optimizer state live in three flat fp32 buffers (the module's nn.Parameters are re-pointed at
+views of them, so state_dict()/checkpoints keep working), every activation buffer is allocated
+once, and the whole step is enqueued with ~30 host calls and replayed from a hipGraph.  With
+data parallelism the backward is cut into layer slices; each finished slice's gradient range is
+all-reduced (RCCL, on the process group's own stream) while the remaining slices run.
+
+Unlike tools/train.py:293-296 nothing here synchronises with the host: `step()` returns a device
+scalar (the loss) and never calls .item().
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import ops
+from . import runtime as rt
+from .models.mpp import masked_patch_pretraining
+from .models.sit import SiT
+
+_ALIGN = 64  # floats (256 B): every parameter view is 16-byte aligned with room to spare
+
+
+class FlatParams:
+    """Flat fp32 storage for parameters / gradients / optimizer state of a module."""
+
+    def __init__(self, module, device):
+        self.params = []
+        seen = set()
+        for p in module.parameters():
+            if id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        self.offsets, off = {}, 0
+        for p in self.params:
+            self.offsets[id(p)] = (off, p.numel())
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.total = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        for p in self.params:
+            o, n = self.offsets[id(p)]
+            view = self.flat[o:o + n].view(p.shape)
+            view.copy_(p.data.to(device=device, dtype=torch.float32))
+            p.data = view
+            p.grad = self.grad[o:o + n].view(p.shape)
+
+    def g(self, p):
+        o, n = self.offsets[id(p)]
+        return self.grad[o:o + n].view(p.shape)
+
+    def offset(self, p):
+        return self.offsets[id(p)][0]
+
+    def still_flat(self):
+        return all(p.data.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[id(p)][0] for p in self.params)
+
+
+class TrainEngine:
+    """One fused train step of a SiT (task='regression') or of masked patch pre-training (task='mpp').
+
+    input_layout: 'surface' -> step(x) takes raw channels-last surfaces (B, 40962, C) and gathers the
+                  patches on the GPU; 'patched' -> the reference's (B, C, P, V) layout.
+    """
+
+    def __init__(self, model, batch_size, *, task="regression", input_layout="surface", loss="mse", optimizer="sgd",
+                 lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
+                 process_group=None, bwd_slices=None, use_graph=True, device=None):
+        if task == "mpp":
+            assert isinstance(model, masked_patch_pretraining)
+            self.ssl, self.sit = model, model.transformer
+        else:
+            assert isinstance(model, SiT)
+            self.ssl, self.sit = None, model
+        sit = self.sit
+        self.task, self.layout, self.loss_kind = task, input_layout, loss
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.module = model.to(self.device)
+        self.B, self.P, self.V, self.Cc = batch_size, sit.num_patches, sit.num_vertices, sit.num_channels
+        self.N, self.D, self.K = self.P + 1, sit.dim, sit.patch_dim
+        self.dtype = rt.dtype_code(sit.compute_dtype)
+        self.tdt = rt.torch_dtype(self.dtype)
+        self.ld = ops.pad64(self.K)
+        self.ncls = sit.mlp_head[1].weight.shape[0]
+        self.pool_mean = int(sit.pool == "mean")
+        tr = sit.transformer
+        if tr.p_dropout > 0 or sit.dropout.p > 0:
+            raise rt.SitkError("TrainEngine: dropout > 0 is not implemented on the fused path")
+        self.depth = tr.depth
+        self.opt = dict(kind=optimizer, lr=lr, momentum=momentum, wd=weight_decay, nesterov=nesterov, betas=betas, eps=eps)
+        self.pg = process_group
+        self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        self.nsteps = 0
+
+        self.fp = FlatParams(self.module, self.device)
+        dev, f32 = self.device, torch.float32
+        B, P, N, D, K, ld = self.B, self.P, self.N, self.D, self.K, self.ld
+        self.cfg = ops.encoder_cfg(B, N, D, tr.depth, tr.heads, tr.mlp_dim, self.dtype)
+        self.acts, self.scratch = ops.encoder_workspace(self.cfg, dev)
+        layers = tr.layer_tensors()
+        self.Pa = ops.layer_param_array([[p.data for p in layer] for layer in layers])
+        self.Ga = ops.layer_param_array([[self.fp.g(p) for p in layer] for layer in layers])
+        self.inp = torch.zeros((B, 40962, self.Cc) if input_layout == "surface" else (B, self.Cc, P, self.V), dtype=f32, device=dev)
+        self.table = sit.patch_table(dev) if input_layout == "surface" else None
+        self.tokens = torch.zeros((B * P, ld), dtype=self.tdt, device=dev)
+        self.w_embed = torch.zeros((D, ld), dtype=self.tdt, device=dev)
+        self.x0 = torch.empty((B * N, D), dtype=f32, device=dev)
+        self.xL = torch.empty((B * N, D), dtype=f32, device=dev)
+        self.dx = torch.empty((B * N, D), dtype=f32, device=dev)
+        self.dW_embed = torch.zeros((D, ld), dtype=f32, device=dev)
+        self.loss = torch.zeros((1,), dtype=f32, device=dev)
+        if task == "regression":
+            self.target = torch.zeros((B, self.ncls), dtype=f32, device=dev)
+            self.logits = torch.empty((B, self.ncls), dtype=f32, device=dev)
+            self.dlogits = torch.empty((B, self.ncls), dtype=f32, device=dev)
+        else:
+            ssl = self.ssl
+            self.n_mask = math.ceil(ssl.mask_prob * P)
+            self.tok32 = torch.zeros((B * P, K), dtype=f32, device=dev)
+            self.enc_out = torch.empty((B * P, D), dtype=self.tdt, device=dev)
+            self.wo_c = torch.empty((K, D), dtype=self.tdt, device=dev)      # to_original, (K, D)
+            self.wo_t = torch.empty((D, ops.pad8(K)), dtype=self.tdt, device=dev)
+            self.we_t = torch.empty((K, D), dtype=self.tdt, device=dev)      # embedding weight^T (for d mask_token)
+            self.out = torch.empty((B * P, K), dtype=f32, device=dev)
+            self.dout = torch.empty((B * P, K), dtype=f32, device=dev)
+            self.masked = torch.zeros((B * P,), dtype=torch.uint8, device=dev)
+            self.replaced_full = torch.zeros((B, N), dtype=torch.uint8, device=dev)
+            self.rsum = torch.zeros((1, D), dtype=f32, device=dev)
+            self.dmt = torch.zeros((1, K), dtype=f32, device=dev)
+        if optimizer == "sgd":
+            self.state = [torch.zeros_like(self.fp.flat)] if momentum != 0 else [None]
+        elif optimizer in ("adam", "adamw"):
+            self.state = [torch.zeros_like(self.fp.flat), torch.zeros_like(self.fp.flat)]
+            use_graph = False  # bias correction is a host scalar that changes every step
+        else:
+            raise ValueError(optimizer)
+
+        # backward slices (last layer first) and the gradient ranges that become final after each
+        if bwd_slices is None:
+            bwd_slices = 1 if self.world == 1 else min(4, tr.depth)
+        bounds = [round(i * tr.depth / bwd_slices) for i in range(bwd_slices + 1)]
+        self.slices = [(bounds[i], bounds[i + 1]) for i in range(bwd_slices)][::-1]
+        self.use_graph = use_graph
+        self._graphs = None
+        self._pending = []
+
+    # ---------------------------------------------------------------------------------------------
+    def _s(self):
+        return rt.stream_ptr()
+
+    def _forward_regression(self):
+        sit, L, s = self.sit, rt.lib, self._s()
+        B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
+        lin = sit.to_patch_embedding[1]
+        self.fp.grad.zero_()
+        self.loss.zero_()
+        self.dW_embed.zero_()
+        if self.layout == "surface":
+            rt.check(L.sitk_gather_tokens(self.inp.data_ptr(), self.table.data_ptr(), self.tokens.data_ptr(), B, 40962,
+                                          self.Cc, P, self.V, ld, dt, s))
+        else:
+            rt.check(L.sitk_patchify(self.inp.data_ptr(), self.tokens.data_ptr(), B, self.Cc, P, self.V, ld, dt, s))
+        self._embed_forward(self.tokens)
+        ops.encoder_fwd(self.cfg, self.Pa, self.x0, self.xL, self.acts, self.scratch, save=True)
+        ln, fc = sit.mlp_head[0], sit.mlp_head[1]
+        rt.check(L.sitk_head_fwd(self.xL.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), fc.weight.data_ptr(),
+                                 fc.bias.data_ptr(), self.logits.data_ptr(), B, N, D, self.ncls, self.pool_mean, s))
+        rt.check(L.sitk_loss_fwd_bwd(self.logits.data_ptr(), self.target.data_ptr(), self.loss.data_ptr(),
+                                     self.dlogits.data_ptr(), B * self.ncls, int(self.loss_kind == "l1"), s))
+        g = self.fp.g
+        rt.check(L.sitk_head_bwd(self.xL.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), fc.weight.data_ptr(),
+                                 self.dlogits.data_ptr(), self.dx.data_ptr(), g(ln.weight).data_ptr(), g(ln.bias).data_ptr(),
+                                 g(fc.weight).data_ptr(), g(fc.bias).data_ptr(), B, N, D, self.ncls, self.pool_mean, s))
+
+    def _embed_forward(self, tokens):
+        sit, L, s = self.sit, rt.lib, self._s()
+        B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
+        lin = sit.to_patch_embedding[1]
+        rt.check(L.sitk_stage_weight(lin.weight.data_ptr(), D, K, self.w_embed.data_ptr(), ld, None, 0, dt, s))
+        pos = sit.pos_embedding.data.view(-1, D)
+        ops.gemm_nt(tokens, self.w_embed, self.x0, dt, M=B * P, N=D, K=ld, epilogue=ops.EPI_BIAS_RES, bias=lin.bias.data,
+                    aux=pos, omap=(P, N, 1), auxmap=(P, 0, 1))
+        rt.check(L.sitk_embed_cls_rows(self.x0.data_ptr(), sit.cls_token.data_ptr(), pos.data_ptr(), B, N, D, s))
+
+    def _embed_backward(self, tokens):
+        sit = self.sit
+        B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
+        lin = sit.to_patch_embedding[1]
+        g = self.fp.g
+        ops.gemm_wgrad(self.dx, tokens, self.dW_embed, dt, db=g(lin.bias), M=B * P, N=D, K=ld, dymap=(P, N, 1))
+        g(lin.weight).copy_(self.dW_embed[:, :K])
+        gpos = g(sit.pos_embedding).view(-1)[:N * D]
+        ops.colsum_f32(self.dx.view(B, N * D), gpos)
+        g(sit.cls_token).view(-1).copy_(gpos[:D])
+
+    def _forward_mpp(self):
+        ssl, sit, L, s = self.ssl, self.sit, rt.lib, self._s()
+        B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
+        self.fp.grad.zero_()
+        self.loss.zero_()
+        self.dW_embed.zero_()
+        self.rsum.zero_()
+        if self.layout == "surface":
+            rt.check(L.sitk_gather_tokens(self.inp.data_ptr(), self.table.data_ptr(), self.tok32.data_ptr(), B, 40962,
+                                          self.Cc, P, self.V, K, rt.F32, s))
+        else:
+            rt.check(L.sitk_patchify(self.inp.data_ptr(), self.tok32.data_ptr(), B, self.Cc, P, self.V, K, rt.F32, s))
+        # on-device draws (statistically equivalent to models/mpp.py:25-43; the parity path replays
+        # the reference's CPU/GPU generator order through sitk.models.mpp instead)
+        dev = self.device
+        scores = torch.rand((B, P), device=dev)
+        picked = scores.topk(self.n_mask, dim=-1).indices
+        masked = torch.zeros((B, P), device=dev).scatter_(1, picked, 1).bool()
+        self.masked.copy_(masked.reshape(-1))
+        swap = rpatch = None
+        if ssl.swap_prob > 0:
+            swap = (torch.rand((B, P), device=dev) < ssl.swap_prob / (1 - ssl.replace_prob)).reshape(-1).to(torch.uint8)
+            rpatch = torch.randint(0, P, (B * P,), device=dev, dtype=torch.int32)
+        repl = torch.rand((B, P), device=dev) < ssl.replace_prob
+        self.replaced_full[:, 1:] = (masked & repl).to(torch.uint8)
+        self.last_randoms = {"corrupted_sequence": masked, "replace_draw": repl}
+        if swap is not None:
+            self.last_randoms.update(swap_draw=swap.view(B, P).bool(), random_patches=rpatch.view(B, P))
+        rt.check(L.sitk_mpp_corrupt(self.tok32.data_ptr(), self.masked.data_ptr(), rt.ptr(swap), rt.ptr(rpatch),
+                                    repl.reshape(-1).to(torch.uint8).data_ptr(), ssl.mask_token.data_ptr(),
+                                    self.tokens.data_ptr(), B, P, K, ld, dt, s))
+        self._embed_forward(self.tokens)
+        ops.encoder_fwd(self.cfg, self.Pa, self.x0, self.xL, self.acts, self.scratch, save=True)
+        # to_original on tokens 1..P (models/mpp.py:129) and masked MSE (models/mpp.py:132)
+        lo = ssl.to_original
+        rt.check(L.sitk_stage_weight(lo.weight.data_ptr(), K, D, self.wo_c.data_ptr(), D, self.wo_t.data_ptr(),
+                                     self.wo_t.shape[1], dt, s))
+        ops.gemm_nt(self.xL, self.wo_c, self.out, dt, M=B * P, N=K, K=D, bias=lo.bias.data, amap=(P, N, 1))
+        rt.check(L.sitk_mpp_loss_fwd_bwd(self.out.data_ptr(), self.tok32.data_ptr(), self.masked.data_ptr(),
+                                         self.loss.data_ptr(), self.dout.data_ptr(), B * P, K, B * self.n_mask, s))
+        g = self.fp.g
+        # d to_original: X = encoder output rows 1..P (fp32 -> compute dtype copy)
+        rt.check(L.sitk_cast_rows(self.xL.data_ptr() + 4 * D, N * D, self.enc_out.data_ptr(), P * D, B, P * D, dt, s))
+        ops.gemm_wgrad(self.dout, self.enc_out, g(lo.weight), dt, db=g(lo.bias), M=B * P, N=K, K=D)
+        self.dx.zero_()
+        ops.gemm_nt(self.dout, self.wo_t, self.dx, dt, M=B * P, N=D, K=K, omap=(P, N, 1))
+
+    def _backward_slice(self, lb, le):
+        ops.encoder_bwd(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, layer_begin=lb, layer_end=le)
+
+    def _finish_backward(self):
+        self._embed_backward(self.tokens)
+        if self.task == "mpp":
+            ssl, sit, L, s = self.ssl, self.sit, rt.lib, self._s()
+            D, K, dt = self.D, self.K, self.dtype
+            lin = sit.to_patch_embedding[1]
+            ops.masked_colsum(self.dx, self.replaced_full.view(-1), None, self.rsum, "f32")
+            rt.check(L.sitk_stage_weight(lin.weight.data_ptr(), D, K, None, 0, self.we_t.data_ptr(), D, dt, s))
+            ops.gemm_nt(self.rsum, self.we_t, self.dmt, dt, M=1, N=K, K=D)
+            self.fp.g(ssl.mask_token).view(-1).copy_(self.dmt.view(-1))
+
+    def _optimizer(self):
+        o, fp = self.opt, self.fp
+        scale = 1.0 / self.world
+        if o["kind"] == "sgd":
+            ops.sgd_step(fp.flat, fp.grad, self.state[0], o["lr"], o["momentum"], o["wd"], o["nesterov"], scale)
+        else:
+            ops.adam_step(fp.flat, fp.grad, self.state[0], self.state[1], o["lr"], o["betas"][0], o["betas"][1], o["eps"],
+                          o["wd"], o["kind"] == "adamw", self.nsteps + 1, scale)
+
+    # ---- segments: [fwd + loss + head/backward slice 0], [slice 1], ..., [finish + optimizer] ------------
+    def _segment_fns(self):
+        fwd = self._forward_mpp if self.task == "mpp" else self._forward_regression
+        segs = []
+        for i, (lb, le) in enumerate(self.slices):
+            if i == 0:
+                segs.append(lambda lb=lb, le=le: (fwd(), self._backward_slice(lb, le)))
+            else:
+                segs.append(lambda lb=lb, le=le: self._backward_slice(lb, le))
+        return segs
+
+    def _grad_range_after(self, i):
+        """Flat gradient range that is final once backward slice i is done (slices run last->first)."""
+        tr = self.sit.transformer
+        lb, _ = self.slices[i]
+        lo = self.fp.offset(tr.layers[lb][0].norm.weight)
+        hi = self.fp.total if i == 0 else self.fp.offset(tr.layers[self.slices[i - 1][0]][0].norm.weight)
+        return lo, hi
+
+    def _allreduce(self, lo, hi):
+        if self.world > 1:
+            self._pending.append(torch.distributed.all_reduce(self.fp.grad[lo:hi], group=self.pg, async_op=True))
+
+    def _run(self, fn, idx):
+        if not self.use_graph:
+            fn()
+            return
+        if self._graphs is None:
+            self._graphs = {}
+        if idx not in self._graphs:
+            fn()                                   # eager warm-up (also validates arguments)
+            torch.cuda.current_stream().synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                fn()
+            self._graphs[idx] = gr
+            return                                 # the eager run above already did this step's work
+        self._graphs[idx].replay()
+
+    def load_batch(self, x, target=None):
+        self.inp.copy_(x, non_blocking=True)
+        if target is not None:
+            self.target.copy_(target.reshape(self.target.shape), non_blocking=True)
+
+    def step(self, x=None, target=None):
+        """Runs one optimisation step on the batch in the static input buffers (or on x/target if
+        given).  Returns the device tensor holding the loss of this step (no host sync)."""
+        if x is not None:
+            self.load_batch(x, target)
+        segs = self._segment_fns()
+        for i, fn in enumerate(segs):
+            self._run(fn, i)
+            if self.world > 1:
+                lo, hi = self._grad_range_after(i)
+                if i < len(segs) - 1:
+                    self._allreduce(lo, hi)
+        self._run(self._finish_backward, "finish")
+        if self.world > 1:
+            self._allreduce(0, self._grad_range_after(len(segs) - 1)[1])
+            for w in self._pending:
+                w.wait()
+            self._pending.clear()
+        self._run(self._optimizer, "opt")
+        self.nsteps += 1
+        return self.loss

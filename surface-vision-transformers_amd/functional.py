@@ -77,7 +77,7 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy.device)
-            ops.gemm_nt(dy2, wt, dx, dtype, N=K, K=wt.shape[1])
+            ops.gemm_nt(dy2, wt, dx, dtype, N=K, K=N)        # wt = W^T (K, pad8(N)); contraction over N
             dx = dx.view(*lead, K)
         return dx, dW_pad[:, :K].contiguous(), db, None
 

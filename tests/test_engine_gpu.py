@@ -1,0 +1,115 @@
+"""GPU tests of the fused train step (sitk.engine.TrainEngine): one step == autograd modules +
+torch.optim.SGD on the same batch; hipGraph replay == eager; MPP engine gradients == autograd path
+replaying the engine's own random draws."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detgen, sit_oracle  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _load(module, seed):
+    vals = detgen.fill_state_dict(module.state_dict(), seed=seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+
+
+@pytest.fixture(scope="module")
+def pk():
+    import sitk  # noqa: F401
+    from sitk import engine
+    from sitk.models import mpp, sit
+    return sit, mpp, engine
+
+
+@pytest.mark.parametrize("dtype,layout,pool", [("f32", "surface", "cls"), ("bf16", "patched", "mean"), ("bf16", "surface", "cls")])
+def test_engine_step_equals_autograd_plus_sgd(pk, dtype, layout, pool):
+    sit, _, engine = pk
+    B = 4
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=2, num_patches=320, num_vertices=153, num_channels=4, pool=pool)
+    m1 = sit.SiT(**kw, compute_dtype=dtype)
+    _load(m1, 11)
+    m2 = copy.deepcopy(m1)
+    m1.to(DEV)
+    if layout == "surface":
+        x = torch.from_numpy(detgen.normal("en/xs", (B, 40962, 4), seed=1)).to(DEV)
+    else:
+        x = torch.from_numpy(detgen.normal("en/xp", (B, 4, 320, 153), seed=1)).to(DEV)
+    y = torch.from_numpy(detgen.normal("en/y", (B,), seed=1)).to(DEV)
+    lr = 0.05
+    opt = torch.optim.SGD(m1.parameters(), lr=lr, momentum=0.9)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(m1(x).squeeze(), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    for use_graph in (False, True):
+        m = copy.deepcopy(m2)
+        eng = engine.TrainEngine(m, B, input_layout=layout, lr=lr, momentum=0.9, use_graph=use_graph)
+        got = [float(eng.step(x, y)) for _ in range(3)]
+        tol = 1e-4 if dtype == "f32" else 2e-2
+        assert np.allclose(got, losses, rtol=tol), (got, losses)
+        for (k, p), (_, q) in zip(m.named_parameters(), m1.named_parameters()):
+            assert rel(p.data, q.data) < (1e-5 if dtype == "f32" else 2e-3), k
+        assert eng.fp.still_flat()
+        sd = m.state_dict()
+        assert rel(sd["pos_embedding"], m1.state_dict()["pos_embedding"]) < 1e-3
+
+
+def test_engine_backward_slices_match_single_slice(pk):
+    sit, _, engine = pk
+    B = 2
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=4, num_patches=80, num_vertices=561, num_channels=4)
+    base = sit.SiT(**kw, compute_dtype="f32")
+    _load(base, 5)
+    x = torch.from_numpy(detgen.normal("sl/x", (B, 4, 80, 561), seed=1)).to(DEV)
+    y = torch.from_numpy(detgen.normal("sl/y", (B,), seed=1)).to(DEV)
+    flats = []
+    for slices in (1, 3):
+        eng = engine.TrainEngine(copy.deepcopy(base), B, input_layout="patched", lr=0.1, bwd_slices=slices, use_graph=False)
+        eng.step(x, y)
+        flats.append(eng.fp.flat.clone())
+    assert rel(flats[1], flats[0]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_mpp_engine_gradients_match_autograd_path(pk, dtype):
+    sit, mpp, engine = pk
+    B, P, V = 3, 320, 153
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=2, num_patches=P, num_vertices=V, num_channels=4)
+    ssl = mpp.masked_patch_pretraining(sit.SiT(**kw, compute_dtype=dtype), 192, 4 * V, "cpu", mask_prob=0.75,
+                                       replace_prob=0.8, swap_prob=0.02, channels=4, num_vertices=V)
+    _load(ssl, 5)
+    ref = copy.deepcopy(ssl).to(DEV)
+    x = torch.from_numpy(detgen.normal("me/x", (B, 40962, 4), seed=1)).to(DEV)
+    eng = engine.TrainEngine(ssl, B, task="mpp", input_layout="surface", lr=0.0, momentum=0.0, use_graph=False)
+    torch.manual_seed(0)
+    loss = float(eng.step(x))
+    rnd = {k: v.clone() for k, v in eng.last_randoms.items()}
+    assert int(rnd["corrupted_sequence"].sum()) == B * 240
+    l2, _ = ref(x, randoms=rnd)
+    l2.backward()
+    tol = 2e-4 if dtype == "f32" else 3e-2
+    assert abs(loss - float(l2)) / float(l2) < tol
+    for (k, p), (_, q) in zip(ssl.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert rel(p.grad, q.grad) < tol, (k, rel(p.grad, q.grad))
+    # graph-captured MPP steps run and reduce the loss
+    ssl2 = copy.deepcopy(ref).cpu()
+    eng2 = engine.TrainEngine(ssl2, B, task="mpp", input_layout="surface", lr=0.02, momentum=0.9, use_graph=True)
+    ls = [float(eng2.step(x)) for _ in range(12)]
+    assert all(np.isfinite(ls)) and np.mean(ls[-3:]) < np.mean(ls[:3]), ls
