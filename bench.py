@@ -1,0 +1,191 @@
+"""Headline benchmark: surfaces/s, forward + backward (+ SGD step), SiT-tiny, 320 patches, B = 64 per
+GPU, bf16 MFMA, on N MI355X (BASELINE.json).  One "step" = one pass of the hot path over one batch
+of synthetic surfaces already resident in HBM:
+
+    gather (B,40962,4) -> patch embedding -> 12-layer encoder -> head -> MSE -> full backward
+    -> [RCCL gradient all-reduce, N > 1] -> fused SGD(momentum 0.9) update
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     : the dominant kernel (by time share in profiles/) timed live with HIP events on the launch
+                 stream, with its algorithmic FLOPs per launch
+  cpu_baseline : the CPU oracle (oracle/sit_oracle.py, "port") on this host's cores, config
+                 BASELINE configs[0] (B = 4), bounded to ~15 s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MODELS = {
+    "tiny": dict(dim=192, depth=12, heads=3, mlp_dim=768, dim_head=64),
+    "small": dict(dim=384, depth=12, heads=6, mlp_dim=1536, dim_head=64),
+    "base": dict(dim=768, depth=12, heads=12, mlp_dim=3072, dim_head=64),
+}
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def step_gflop_per_sample(dim, depth, heads, mlp_dim, P, K, n_classes=1, mpp=False):
+    """Algorithmic GEMM FLOPs fwd+bwd per sample: bwd = 2x fwd except the patch
+    embedding, which needs no input gradient."""
+    N, I = P + 1, heads * 64
+    embed = 2 * P * K * dim
+    layer = 2 * N * dim * 3 * I + 2 * 2 * heads * N * N * 64 + 2 * N * I * dim + 4 * N * dim * mlp_dim
+    head = 2 * P * dim * K if mpp else 2 * dim * n_classes
+    fwd = embed + depth * layer + head
+    return (fwd + 2 * (fwd - embed) + embed) / 1e9
+
+
+def cpu_baseline(seconds=15.0):
+    """BASELINE configs[0]: SiT-tiny, 320 patches, B = 4, fp32, MSE, SGD(momentum 0.9) on the host."""
+    import numpy as np
+    from oracle import sit_oracle
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:  # cgroup CPU quota (the GPU box exposes 256 logical CPUs but grants a 16-CPU share)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(cores)
+    B = 4
+    model = sit_oracle.SiT(**MODELS["tiny"], num_patches=320, num_vertices=153, num_channels=4)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-5, momentum=0.9)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((B, 4, 320, 153), generator=g)
+    y = torch.randn((B,), generator=g)
+    times = []
+    t_end = time.perf_counter() + seconds
+    it = 0
+    while True:
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(model(x).squeeze(), y)
+        loss.backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if it >= 2:
+            times.append(dt)
+        it += 1
+        if (time.perf_counter() > t_end and len(times) >= 3) or len(times) >= 200:
+            break
+    med = float(np.median(times))
+    return {"value": B / med, "unit": "surfaces/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/sit_oracle.py SiT-tiny 320x153x4, B=4 fp32 fwd+bwd+SGD, median of {len(times)} steps "
+                      f"({med * 1e3:.1f} ms/step), torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="tiny", choices=list(MODELS))
+    ap.add_argument("--patches", type=int, default=320, choices=[80, 320, 1280])
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--task", default="regression", choices=["regression", "mpp"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    import sitk  # noqa: F401
+    from sitk import engine
+    from sitk.models.mpp import masked_patch_pretraining
+    from sitk.models.sit import SiT
+
+    V = {80: 561, 320: 153, 1280: 45}[args.patches]
+    P, K, B = args.patches, 4 * V, args.batch
+    mk = MODELS[args.model]
+    torch.manual_seed(1234)                       # identical initial weights on every rank
+    model = SiT(**mk, num_patches=P, num_vertices=V, num_channels=4, compute_dtype=args.dtype)
+    if args.task == "mpp":
+        model = masked_patch_pretraining(model, mk["dim"], K, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
+                                         channels=4, num_vertices=V)
+    eng = engine.TrainEngine(model, B, task=args.task, input_layout="surface", lr=1e-5, momentum=0.9,
+                             process_group=pg, use_graph=not args.no_graph, device=dev)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)   # every rank its own synthetic shard
+    x = torch.randn((B, 40962, 4), device=dev, generator=g)
+    y = torch.randn((B,), device=dev, generator=g) * 2 + 40 if args.task == "regression" else None
+    eng.load_batch(x, y)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):          # >= 2: first call runs eagerly, second captures nothing new
+        eng.step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(eng.loss)
+    ms = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+    gf = step_gflop_per_sample(mk["dim"], mk["depth"], mk["heads"], mk["mlp_dim"], P, K, mpp=args.task == "mpp")
+
+    out = {
+        "metric": "surfaces/sec fwd+bwd, SiT-tiny 320-patch, B=64, 1/2/4/8 MI355X",
+        "value": round(value, 1), "unit": "surfaces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"SiT-{args.model} {P} patches x {V} vertices x 4 channels, B={B}/GPU, {args.task}: "
+                               f"gather(B,40962,4) + fwd + {'masked MSE' if args.task == 'mpp' else 'MSE'} + bwd + "
+                               f"SGD(m=0.9), bf16 MFMA / fp32 accumulate" if args.dtype == "bf16" else
+                               f"SiT-{args.model} {P}x{V}x4 B={B}/GPU {args.task} f32 MFMA",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                   "loss_after": round(loss, 6)},
+        "step_gflop_per_sample": round(gf, 3),
+        "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+    }
+    if rank == 0:
+        if not args.no_probe:
+            from sitk import probe
+            out["roofline"] = probe.dominant_kernel_roofline(eng, PEAK_BF16_TFLOPS, PEAK_HBM_GBS)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

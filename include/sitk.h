@@ -125,6 +125,8 @@ typedef struct {
 } sitk_wgrad_desc;
 
 int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_t stream);
+/* Up to 4 independent weight gradients (the four Linears of one encoder layer) in ONE launch. */
+int sitk_gemm_wgrad_group(const sitk_wgrad_desc* d, int count, int dtype, sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps 1e-5, biased variance, affine): the PreNorm norms of the
@@ -132,10 +134,15 @@ int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_t stream);
  *   x (rows, D) fp32 -> y (rows, D) `dtype`; mean/rstd (rows) fp32 saved for backward.          */
 int sitk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
                        float* rstd, int64_t rows, int D, int dtype, sitk_stream_t stream);
-/* dx_out (fp32) = dres (fp32, may be NULL, may alias dx_out) + LN'(dy); dgamma/dbeta accumulated. */
+/* dx_out (fp32) = dres (fp32, may be NULL, may alias dx_out) + LN'(dy); dgamma/dbeta accumulated.
+ *   dx_out_c : optional second copy of dx_out in `dtype` (feeds the next GEMMs' LDS-DMA path)
+ *   partials : optional scratch of sitk_layernorm_bwd_partial_floats(rows, D) floats; when given the
+ *              per-workgroup dgamma/dbeta sums are stored there and reduced by a second small kernel
+ *              instead of contended float atomics on 2*D addresses.                                */
+size_t sitk_layernorm_bwd_partial_floats(int64_t rows, int D);
 int sitk_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
-                       const float* gamma, const float* dres, float* dx_out, float* dgamma, float* dbeta,
-                       int64_t rows, int D, int dtype, sitk_stream_t stream);
+                       const float* gamma, const float* dres, float* dx_out, void* dx_out_c, float* dgamma,
+                       float* dbeta, float* partials, int64_t rows, int D, int dtype, sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head self-attention core of vit_pytorch.vit.Attention (dim_head = 64):

@@ -113,6 +113,17 @@ SITK_DEV float xor_sum4(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+// 1-D grid, XCD-aware: the ceil(N/64) blocks of one (batch, head) are consecutive logical ids, so
+// they run on one XCD and its L2 serves their shared K/V (or Q/dO) tiles.
+struct BlockCoord {
+  int x, h, b;
+};
+SITK_DEV BlockCoord attn_block(int N, int H) {
+  const int nb = (N + 63) / 64;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  return BlockCoord{L % nb, (L / nb) % H, L / (nb * H)};
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -127,9 +138,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
   char* sK = smem;
   char* sV = smem + G::TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z, I = H * 64;
+  const BlockCoord bc = attn_block(N, H);
+  const int h = bc.h, b = bc.b, I = H * 64;
   const size_t ld = (size_t)3 * I;
-  const int q = blockIdx.x * 64 + 16 * wave + fr, qc = min(q, N - 1);
+  const int q = bc.x * 64 + 16 * wave + fr, qc = min(q, N - 1);
   const T* base = qkv + (size_t)b * N * ld;
 
   u32x4 qf[G::KS];
@@ -203,9 +215,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
   char* sK = smem;
   char* sV = smem + G::TILE_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z, I = H * 64;
+  const BlockCoord bc = attn_block(N, H);
+  const int h = bc.h, b = bc.b, I = H * 64;
   const size_t ld = (size_t)3 * I;
-  const int q = blockIdx.x * 64 + 16 * wave + fr, qc = min(q, N - 1);
+  const int q = bc.x * 64 + 16 * wave + fr, qc = min(q, N - 1);
   const T* base = qkv + (size_t)b * N * ld;
 
   u32x4 qf[G::KS], dof[G::KS];
@@ -272,9 +285,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
   float* sL = reinterpret_cast<float*>(smem + 2 * G::TILE_BYTES);
   float* sD = sL + 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  const int h = blockIdx.y, b = blockIdx.z, I = H * 64;
+  const BlockCoord bc = attn_block(N, H);
+  const int h = bc.h, b = bc.b, I = H * 64;
   const size_t ld = (size_t)3 * I;
-  const int key = blockIdx.x * 64 + 16 * wave + fr, kc = min(key, N - 1);
+  const int key = bc.x * 64 + 16 * wave + fr, kc = min(key, N - 1);
   const T* base = qkv + (size_t)b * N * ld;
   const T* dobase = d_o + (size_t)b * N * I;
 
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
 
 template <typename T>
 static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
-  dim3 grid(cdiv(N, 64), H, B);
+  dim3 grid(cdiv(N, 64) * H * B);
   hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
                      reinterpret_cast<T*>(o), lse, N, H, scale);
   return check_launch("attention_fwd");
@@ -341,7 +355,7 @@ static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, fl
 template <typename T>
 static int run_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                    int B, int N, int H, float scale, hipStream_t s) {
-  dim3 grid(cdiv(N, 64), H, B);
+  dim3 grid(cdiv(N, 64) * H * B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
                      reinterpret_cast<const T*>(o), reinterpret_cast<const T*>(d_o), lse, delta,
                      reinterpret_cast<T*>(dqkv), N, H, scale);

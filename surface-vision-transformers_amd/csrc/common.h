@@ -80,6 +80,18 @@ SITK_DEV int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Row remapping of a 2-D operand: physical_row(m) = (m / group) * stride + offset + m % group
+// (group == 0: identity).  Lets GEMMs read/write "tokens 1..P of every sample" in place.
+namespace sitk {
+struct RowMap {
+  int group, stride, offset;
+};
+SITK_DEV int map_row(const RowMap& r, int m) {
+  return r.group ? (m / r.group) * r.stride + r.offset + (m % r.group) : m;
+}
+static inline RowMap to_rowmap(const sitk_rowmap& r) { return RowMap{r.group, r.stride, r.offset}; }
+}  // namespace sitk
+
 // ------------------------------------------------------------------------------------------
 // LDS tile image: rows of 128 bytes, 32-byte windows XOR-swizzled by a key of the row.
 // With key(row) = bit1(row) | bit3(row)<<1 the image is conflict-free BOTH for ds_read_b128 row

@@ -69,6 +69,10 @@ struct LayerActs {
 struct Scratch {
   char *du, *dh, *d_o, *dqkv;
   float *delta, *ping, *pong;
+  // backward: residual-gradient ping-pong (fp32 dxB besides the caller's dx) and compute-dtype copies
+  float* dxB;
+  char *dxAc, *dxBc;
+  float* ln_partials;
 };
 
 struct Layout {
@@ -111,6 +115,10 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
   L.scratch.delta = (float*)stake((size_t)c.B * c.heads * c.N * 4);
   L.scratch.ping = (float*)stake(R * D * 4);
   L.scratch.pong = (float*)stake(R * D * 4);
+  L.scratch.dxB = (float*)stake(R * D * 4);
+  L.scratch.dxAc = stake(R * D * es);
+  L.scratch.dxBc = stake(R * D * es);
+  L.scratch.ln_partials = (float*)stake(sitk_layernorm_bwd_partial_floats((int64_t)R, (int)D) * 4);
   L.scratch_bytes = off;
   return L;
 }
@@ -240,31 +248,38 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   const float scale = 0.125f;
   const Scratch& S = L.scratch;
 
+  // The residual gradient lives in two fp32 buffers (A = the caller's dx, B = scratch) plus a copy of
+  // each in the compute dtype (Ac, Bc) that feeds the GEMMs' operand loads: LN2' reads A and writes
+  // B, LN1' reads B and writes A, so d(x_out) [A] and d(x_mid) [B] both survive until the layer's
+  // four weight gradients run as ONE grouped launch.
+  SITK_TRY(sitk_cast_rows(dx, D, S.dxAc, D, R, D, dt, stream));
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const LayerActs& a = L.layers[l];
     const float* xl = l == 0 ? x_in : a.x_in;
     // ---- MLP branch: x_out = xmid + W2 gelu(W1 LN2(xmid) + b1) + b2 ----
-    sitk_wgrad_desc wg2 = wgrad_desc(R, D, M, dx, 1, a.g, G[l].w2, G[l].b2);
-    SITK_TRY(sitk_gemm_wgrad(&wg2, dt, stream));
-    sitk_gemm_desc d1 = gemm_desc(R, M, D, dx, D, 1, a.w2_t, SITK_EPI_DGELU, S.du, M, 0);
+    sitk_gemm_desc d1 = gemm_desc(R, M, D, S.dxAc, D, 0, a.w2_t, SITK_EPI_DGELU, S.du, M, 0);
     d1.aux = a.u; d1.ldaux = M;
     SITK_TRY(sitk_gemm_nt(&d1, dt, stream));
-    sitk_wgrad_desc wg1 = wgrad_desc(R, M, D, S.du, 0, a.h2, G[l].w1, G[l].b1);
-    SITK_TRY(sitk_gemm_wgrad(&wg1, dt, stream));
     sitk_gemm_desc d2 = gemm_desc(R, D, M, S.du, M, 0, a.w1_t, SITK_EPI_STORE, S.dh, D, 0);
     SITK_TRY(sitk_gemm_nt(&d2, dt, stream));
-    SITK_TRY(sitk_layernorm_bwd(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, dx, G[l].ln2_w, G[l].ln2_b, R, D, dt, stream));
+    SITK_TRY(sitk_layernorm_bwd(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, S.dxB, S.dxBc, G[l].ln2_w, G[l].ln2_b,
+                                S.ln_partials, R, D, dt, stream));
     // ---- attention branch: xmid = x + Wo attn(Wqkv LN1(x)) + bo ----
-    sitk_wgrad_desc wgo = wgrad_desc(R, D, I, dx, 1, a.o, G[l].wo, G[l].bo);
-    SITK_TRY(sitk_gemm_wgrad(&wgo, dt, stream));
-    sitk_gemm_desc d3 = gemm_desc(R, I, D, dx, D, 1, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
+    sitk_gemm_desc d3 = gemm_desc(R, I, D, S.dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
     SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
     SITK_TRY(sitk_attention_bwd(a.qkv, a.o, S.d_o, a.lse, S.delta, S.dqkv, c.B, c.N, c.heads, scale, dt, stream));
-    sitk_wgrad_desc wgq = wgrad_desc(R, 3 * I, D, S.dqkv, 0, a.h1, G[l].wqkv, nullptr);
-    SITK_TRY(sitk_gemm_wgrad(&wgq, dt, stream));
+    // ---- the four weight (+ bias) gradients of the layer, one launch ----
+    sitk_wgrad_desc wg[4] = {
+        wgrad_desc(R, D, M, S.dxAc, 0, a.g, G[l].w2, G[l].b2),
+        wgrad_desc(R, M, D, S.du, 0, a.h2, G[l].w1, G[l].b1),
+        wgrad_desc(R, D, I, S.dxBc, 0, a.o, G[l].wo, G[l].bo),
+        wgrad_desc(R, 3 * I, D, S.dqkv, 0, a.h1, G[l].wqkv, nullptr),
+    };
+    SITK_TRY(sitk_gemm_wgrad_group(wg, 4, dt, stream));
     sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, S.dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
     SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
-    SITK_TRY(sitk_layernorm_bwd(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, dx, dx, G[l].ln1_w, G[l].ln1_b, R, D, dt, stream));
+    SITK_TRY(sitk_layernorm_bwd(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, G[l].ln1_w, G[l].ln1_b,
+                                S.ln_partials, R, D, dt, stream));
   }
   return SITK_OK;
 }

@@ -8,17 +8,12 @@
 // consecutive output features: epilogues read bias/residual and write results as 8/16-byte vectors.
 // Operand tiles are staged global -> registers -> LDS ([rows][128 B] swizzled image, common.h) with
 // the next tile's loads issued before the current tile's MFMAs.
+#include <algorithm>
+#include <type_traits>
+
 #include "common.h"
 
 namespace sitk {
-
-struct RowMap {
-  int group, stride, offset;
-};
-SITK_DEV int map_row(const RowMap& r, int m) {
-  return r.group ? (m / r.group) * r.stride + r.offset + (m % r.group) : m;
-}
-static RowMap to_rowmap(const sitk_rowmap& r) { return RowMap{r.group, r.stride, r.offset}; }
 
 struct GemmParams {
   int M, N, K;
@@ -206,8 +201,129 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small-K NT GEMM (K <= 192 bf16: to_qkv, to_out.0, net.0 and their input gradients for dim 192):
+// weight-resident, token-streaming, barrier-free main loop.
+//   * a workgroup (8 waves, 2 per SIMD) owns one BN-column tile of W for the whole kernel: its
+//     (BN x K) panel is brought into LDS once by LDS-DMA;
+//   * every WAVE streams its own 32-token strips of A through a private LDS slot
+//     (global_load_lds_dwordx4, 12 KiB per strip): wait own DMA -> 2 x (BN/16) x K/32 MFMAs ->
+//     issue the next strip's DMA -> epilogue (bias / GELU / residual, 8-16 byte stores) while that
+//     DMA is in flight.  No workgroup barrier after the prologue; the second wave of each SIMD fills
+//     the MFMA, VALU and memory gaps of the first.
+//   * strips of the same tokens for the different column tiles run on one XCD (xcd_remap), so A is
+//     fetched from HBM once and re-served by that XCD's L2.
+// ------------------------------------------------------------------------------------------
+__device__ u32x4 g_zero_page_nt[4];
+
+template <typename TO, int EPI, int BN, int KT>
+__global__ __launch_bounds__(512) void gemm_nt_wres_kernel(GemmParams p, int groups) {
+  using T = bf16;
+  constexpr int NT = BN / 16;                 // MFMA column tiles per strip
+  constexpr int WB = KT * BN * 128;           // weight panel bytes
+  constexpr int SB = KT * 32 * 128;           // one strip slot: 32 rows x KT panels of 128 B
+  __shared__ __attribute__((aligned(256))) char smem[WB + 8 * SB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int g = L / tiles_n, n0 = (L % tiles_n) * BN;
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_nt);
+  const int r8 = lane >> 3;                                          // row within an 8-row DMA piece
+  // ---- weight panel: KT panels x BN rows, pieces of 8 rows; 8 waves share the pieces ----
+  for (int q = wave; q < KT * BN / 8; q += 8) {
+    const int kt = q / (BN / 8), row = (q % (BN / 8)) * 8 + r8;
+    const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    const int k = kt * 64 + ((lane & 7) ^ (key << 1)) * 8;
+    const int n = n0 + row;
+    const T* src = (n < p.N && k < p.K) ? W + (size_t)n * p.ldw + k : reinterpret_cast<const T*>(zero);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + kt * BN * 128 + (q % (BN / 8)) * 1024), 16, 0, 0);
+  }
+  char* slot = smem + WB + wave * SB;
+  const int nstrips = (p.M + 31) / 32;
+  const int unit = g * 8 + wave, nunits = groups * 8;
+  auto issue = [&](int strip) {
+#pragma unroll
+    for (int q = 0; q < KT * 4; ++q) {
+      const int kt = q / 4, row = (q % 4) * 8 + r8;
+      const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+      const int k = kt * 64 + ((lane & 7) ^ (key << 1)) * 8;
+      const int m = strip * 32 + row;
+      const bool ok = m < p.M && k < p.K;
+      const T* src = ok ? A + (size_t)map_row(p.amap, ok ? m : 0) * p.lda + k : reinterpret_cast<const T*>(zero);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(slot + kt * 32 * 128 + (q % 4) * 1024), 16, 0, 0);
+    }
+  };
+  int strip = unit;
+  if (strip < nstrips) issue(strip);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                                    // weight panel visible to all waves
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (; strip < nstrips; strip += nunits) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's strip has landed
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fa[2], fw[NT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          fa[j] = *reinterpret_cast<const u32x4*>(slot + kt * 32 * 128 + lds_off(16 * j + fr, ks * 64 + fq * 16));
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          fw[i] = *reinterpret_cast<const u32x4*>(smem + kt * BN * 128 + lds_off(16 * i + fr, ks * 64 + fq * 16));
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mma(fw[i], fa[j], acc[i][j]);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // slot fully read: refill it
+    if (strip + nunits < nstrips) issue(strip + nunits);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = strip * 32 + 16 * j + fr;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = n0 + 16 * i + 4 * fq;
+        if (m < p.M && n < p.N) gemm_epilogue<T, TO, EPI>(p, m, n, acc[i][j]);
+      }
+    }
+  }
+}
+
+template <typename TO, int EPI>
+static int launch_gemm_nt_wres(const GemmParams& p, hipStream_t s) {
+  const int KT = cdiv(p.K, 64);
+  const bool wide = p.N % 128 == 0;
+  const int tiles_n = cdiv(p.N, wide ? 128 : 64);
+  const int nstrips = cdiv(p.M, 32);
+  int groups = std::max(1, 256 / tiles_n);
+  groups = std::min(groups, cdiv(nstrips, 8));
+  const dim3 grid(groups * tiles_n), block(512);
+#define SITK_WRES(BN_, KT_) hipLaunchKernelGGL((gemm_nt_wres_kernel<TO, EPI, BN_, KT_>), grid, block, 0, s, p, groups)
+  if (wide) {
+    if (KT == 1) SITK_WRES(128, 1); else if (KT == 2) SITK_WRES(128, 2); else SITK_WRES(128, 3);
+  } else {
+    if (KT == 1) SITK_WRES(64, 1); else if (KT == 2) SITK_WRES(64, 2); else SITK_WRES(64, 3);
+  }
+#undef SITK_WRES
+  return check_launch("gemm_nt_wres");
+}
+
 template <typename T, typename TA, typename TO, int EPI>
 static int launch_gemm_nt(const GemmParams& p, hipStream_t s) {
+  if constexpr (std::is_same<T, bf16>::value && std::is_same<TA, bf16>::value) {
+    // weight-resident streaming kernel: K up to 192, 16-byte aligned rows, enough tokens to stream
+    if (p.K <= 192 && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.M >= 1024)
+      return launch_gemm_nt_wres<TO, EPI>(p, s);
+  }
   const bool wide = (p.N % 128 == 0) || p.N > 1024;
   if (wide) {
     constexpr int BM = 128, BN = 128;
@@ -352,8 +468,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;  // 2 x 2 waves over (n, k); each 32 x 32
   const int tiles_k = (p.K + 63) / 64;
-  const int tile = blockIdx.x, n0 = (tile / tiles_k) * 64, k0 = (tile % tiles_k) * 64;
-  const int mbeg = blockIdx.y * p.chunk, mend = min(p.M, mbeg + p.chunk);
+  const int ntiles = tiles_k * ((p.N + 63) / 64);
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);   // token-chunk major: a chunk's tiles share an XCD's L2
+  const int tile = lid % ntiles, n0 = (tile / tiles_k) * 64, k0 = (tile % tiles_k) * 64;
+  const int mbeg = (lid / ntiles) * p.chunk, mend = min(p.M, mbeg + p.chunk);
   const TDY* __restrict__ dY = reinterpret_cast<const TDY*>(p.dY);
   const T* __restrict__ X = reinterpret_cast<const T*>(p.X);
   const bool do_bias = p.db != nullptr && k0 == 0;
@@ -454,7 +572,7 @@ static int dispatch_wgrad(const sitk_wgrad_desc* d, hipStream_t s) {
   splits = std::max(1, std::min(splits, cdiv(d->M, 256)));
   p.chunk = cdiv(cdiv(d->M, splits), 64) * 64;
   splits = cdiv(d->M, p.chunk);
-  dim3 grid(tiles, splits);
+  dim3 grid(tiles * splits);
   constexpr bool is_f32 = sizeof(T) == 4;
   if (d->dy_is_f32 && !is_f32)
     hipLaunchKernelGGL((wgrad_kernel<T, float>), grid, dim3(256), 0, s, p);
@@ -463,7 +581,262 @@ static int dispatch_wgrad(const sitk_wgrad_desc* d, hipStream_t s) {
   return check_launch("gemm_wgrad");
 }
 
+// ------------------------------------------------------------------------------------------
+// Grouped weight gradient, LDS-DMA pipeline (the fast path; operands in the compute dtype).
+//   * up to WG_MAX_PROBLEMS independent problems (the four Linears of an encoder layer) in ONE launch;
+//   * output tile 64 (n) x 64 (k) per workgroup.  The 4 waves split the TOKENS of a stage (wave w
+//     owns mma step w), each accumulating the whole 64x64 tile (4x4 MFMA tiles): one transposed
+//     fragment read per MFMA, half the LDS traffic of splitting the tile over the waves;
+//   * stages (4 steps of tokens x 64 columns of dY and of X) go global -> LDS by
+//     global_load_lds_dwordx4 (per-lane source address = swizzle + row map + zero page for
+//     out-of-range rows), double buffered, counted vmcnt + raw s_barrier;
+//   * the four partial tiles are summed through LDS and added to dW with full-row float atomics;
+//     db comes from one extra MFMA per n-block against a ones fragment (k-tile 0 only).
+// ------------------------------------------------------------------------------------------
+constexpr int WG_MAX_PROBLEMS = 4;
+struct WgProblem {
+  const void* dY;
+  const void* X;
+  float* dW;
+  float* db;
+  int M, N, K, lddy, ldx, lddw;
+  RowMap dymap, xmap;
+  int tiles_k, block_begin, splits, chunk;
+};
+struct WgGroup {
+  WgProblem p[WG_MAX_PROBLEMS];
+  int count;
+};
+
+__device__ u32x4 g_zero_page[4];  // 64 zero bytes: source of out-of-range LDS-DMA lanes
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(WgGroup grp) {
+  constexpr int EPV = Mma<T>::EPV;
+  constexpr int TS = Mma<T>::KSTEP;            // tokens per mma step: 32 (bf16) / 16 (f32)
+  constexpr int BT = 4 * TS;                   // tokens per stage
+  constexpr int PC = 128 / (int)sizeof(T);     // columns per 128-byte panel
+  constexpr int NP = 64 / PC;                  // panels per operand: 1 / 2
+  constexpr int OPB = NP * BT * 128;           // bytes per operand stage = 16 KB
+  constexpr int GL = 2 * OPB / 1024 / 4;       // LDS-DMA instructions per wave per stage = 8
+  __shared__ __attribute__((aligned(256))) char smem[4 * OPB];   // 2 buffers x (dY, X) = 64 KB
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int pi = 0;
+  // XCD-aware order: logical ids that are consecutive run on the same XCD, and the logical order
+  // is token-chunk major, so all output tiles of one token chunk share that XCD's L2 (the chunk of
+  // dY and X is then fetched from HBM/MALL once instead of once per tile).
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+#pragma unroll
+  for (int i = 1; i < WG_MAX_PROBLEMS; ++i)
+    if (i < grp.count && bid >= grp.p[i].block_begin) pi = i;
+  const WgProblem P = grp.p[pi];   // one scalar load of the selected problem into SGPRs
+  const int local = bid - P.block_begin;
+  const int tiles = P.tiles_k * ((P.N + 63) / 64);
+  const int split = local / tiles, tile = local % tiles;
+  const int n0 = (tile / P.tiles_k) * 64, k0 = (tile % P.tiles_k) * 64;
+  const int mbeg = split * P.chunk, mend = min(P.M, mbeg + P.chunk);
+  const T* __restrict__ dY = reinterpret_cast<const T*>(P.dY);
+  const T* __restrict__ X = reinterpret_cast<const T*>(P.X);
+  const bool do_bias = P.db != nullptr && k0 == 0;
+  const char* zero = reinterpret_cast<const char*>(g_zero_page);
+  // LDS byte addresses of this lane's transposed-read blocks (bf16 fast path): rows wave*TS + 8g + q
+  // (+4 for the second read), column block i at 32 * (i ^ key(row)) + 8 * (lane & 3)  [= lds_off()]
+  uint32_t tr_base = 0, tr_off[4] = {0u, 0u, 0u, 0u};
+  if constexpr (sizeof(T) == 2) {
+    static_assert(sizeof(T) != 2 || OPB == 16384, "asm offsets assume 16 KB operand stages");
+    tr_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int rowl = wave * TS + 8 * (lane >> 4) + ((lane >> 2) & 3);
+    const int key = ((rowl >> 1) & 1) | (((rowl >> 3) & 1) << 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tr_off[i] = rowl * 128 + 32 * (i ^ key) + 8 * (lane & 3);
+  }
+
+  // LDS-DMA roles: one instruction moves 1 KiB = 8 rows x 128 B of one panel.  An operand stage is
+  // PPO = 16 pieces; waves 0,1 fetch dY, waves 2,3 fetch X (operand choice is wave-uniform and hoisted).
+  constexpr int PPO = OPB / 1024;
+  static_assert(2 * GL == PPO, "two waves per operand");
+  const int op = wave >> 1;
+  const T* __restrict__ obase = op ? X : dY;
+  const int old_ = op ? P.ldx : P.lddy, oc0 = op ? k0 : n0, oclim = op ? P.K : P.N;
+  const RowMap omap = op ? P.xmap : P.dymap;
+  auto issue = [&](int mt, int buf) {
+#pragma unroll
+    for (int i = 0; i < GL; ++i) {
+      const int w = (wave & 1) * GL + i;
+      const int panel = w / (BT / 8), rb = w % (BT / 8);
+      const int row = rb * 8 + (lane >> 3);                          // token within the stage
+      const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+      const int chunk = (lane & 7) ^ (key << 1);                     // logical 16-byte chunk this lane fetches
+      const int col = oc0 + panel * PC + chunk * EPV;
+      const int m = mt + row;
+      const bool ok = m < mend && col < oclim;
+      const T* src = ok ? obase + (size_t)map_row(omap, ok ? m : 0) * old_ + col : reinterpret_cast<const T*>(zero);
+      char* dst = smem + buf * 2 * OPB + op * OPB + panel * BT * 128 + rb * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4], accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  u32x4 ones;
+  {
+    T one[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) one[e] = from_f32<T>(1.0f);
+    __builtin_memcpy(&ones, one, 16);
+  }
+
+  const int nstage = (mend - mbeg + BT - 1) / BT;
+  if (nstage > 0) issue(mbeg, 0);
+  for (int s = 0; s < nstage; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nstage) {
+      issue(mbeg + (s + 1) * BT, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GL) : "memory");     // stage s landed, s+1 in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* sY = smem + buf * 2 * OPB;
+    const char* sX = sY + OPB;
+    u32x4 fy[4], fx[4];
+    if constexpr (sizeof(T) == 2) {
+      // The 16 transposed reads go through ONE asm statement (with their lgkmcnt wait): a read
+      // the compiler can see would make it drain the in-flight LDS-DMA of the next stage
+      // (s_waitcnt vmcnt(0)) before every stage.
+      const uint32_t b = tr_base + buf * 2 * OPB;
+      const uint32_t a0 = b + tr_off[0], a1 = b + tr_off[1], a2 = b + tr_off[2], a3 = b + tr_off[3];
+      u32x2 y0l, y0h, y1l, y1h, y2l, y2h, y3l, y3h, x0l, x0h, x1l, x1h, x2l, x2h, x3l, x3h;
+      asm volatile(
+          "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:512\n\t"
+          "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:512\n\t"
+          "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:512\n\t"
+          "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:512\n\t"
+          "ds_read_b64_tr_b16 %8, %16 offset:16384\n\tds_read_b64_tr_b16 %9, %16 offset:16896\n\t"
+          "ds_read_b64_tr_b16 %10, %17 offset:16384\n\tds_read_b64_tr_b16 %11, %17 offset:16896\n\t"
+          "ds_read_b64_tr_b16 %12, %18 offset:16384\n\tds_read_b64_tr_b16 %13, %18 offset:16896\n\t"
+          "ds_read_b64_tr_b16 %14, %19 offset:16384\n\tds_read_b64_tr_b16 %15, %19 offset:16896\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(y0l), "=&v"(y0h), "=&v"(y1l), "=&v"(y1h), "=&v"(y2l), "=&v"(y2h), "=&v"(y3l), "=&v"(y3h),
+            "=&v"(x0l), "=&v"(x0h), "=&v"(x1l), "=&v"(x1h), "=&v"(x2l), "=&v"(x2h), "=&v"(x3l), "=&v"(x3h)
+          : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+      __builtin_amdgcn_sched_barrier(0);
+      fy[0] = u32x4{y0l[0], y0l[1], y0h[0], y0h[1]};
+      fy[1] = u32x4{y1l[0], y1l[1], y1h[0], y1h[1]};
+      fy[2] = u32x4{y2l[0], y2l[1], y2h[0], y2h[1]};
+      fy[3] = u32x4{y3l[0], y3l[1], y3h[0], y3h[1]};
+      fx[0] = u32x4{x0l[0], x0l[1], x0h[0], x0h[1]};
+      fx[1] = u32x4{x1l[0], x1l[1], x1h[0], x1h[1]};
+      fx[2] = u32x4{x2l[0], x2l[1], x2h[0], x2h[1]};
+      fx[3] = u32x4{x3l[0], x3l[1], x3h[0], x3h[1]};
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fy[i] = TrFrag<T>::load_k8(sY + ((16 * i) / PC) * BT * 128, wave * TS, (16 * i) % PC, lane);
+        fx[i] = TrFrag<T>::load_k8(sX + ((16 * i) / PC) * BT * 128, wave * TS, (16 * i) % PC, lane);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = Mma<T>::mma(fy[i], fx[j], acc[i][j]);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accb[i] = Mma<T>::mma(fy[i], ones, accb[i]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                     // buffer may be refilled
+  }
+
+  // ---- sum the 4 waves' partial tiles through LDS (fp32 64x64 = 16 KB each), then atomics ----
+  float* red = reinterpret_cast<float*>(smem);
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) red[wave * 4096 + (16 * i + 4 * fq + jj) * 64 + 16 * j + fr] = acc[i][j][jj];
+  __syncthreads();
+  // one wave-instruction adds 64 consecutive floats (256 contiguous bytes) of one dW row: the
+  // full-rate float-atomic shape (4 x 64-byte requests, no partial lines)
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int row = it * 4 + wave, c = lane;
+    const float v = red[row * 64 + c] + red[4096 + row * 64 + c] + red[8192 + row * 64 + c] + red[12288 + row * 64 + c];
+    const int n = n0 + row, k = k0 + c;
+    if (n < P.N && k < P.K) unsafeAtomicAdd(P.dW + (size_t)n * P.lddw + k, v);
+  }
+  if (do_bias && fr == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int n = n0 + 16 * i + 4 * fq + jj;
+        if (n < P.N) unsafeAtomicAdd(P.db + n, accb[i][jj]);
+      }
+  }
+}
+
+static bool wgrad_fast_ok(const sitk_wgrad_desc* d, int dtype) {
+  const int epv = dtype == SITK_BF16 ? 8 : 4;
+  return !(d->dy_is_f32 && dtype != SITK_F32) && d->N % epv == 0 && d->K % epv == 0 && d->lddy % epv == 0 &&
+         d->ldx % epv == 0;
+}
+
+template <typename T>
+static int launch_wgrad_group(const sitk_wgrad_desc* d, int count, hipStream_t s) {
+  constexpr int BT = 4 * Mma<T>::KSTEP;
+  WgGroup g;
+  g.count = count;
+  int tiles_total = 0;
+  for (int i = 0; i < count; ++i) tiles_total += cdiv(d[i].N, 64) * cdiv(d[i].K, 64);
+  // ~2 workgroups per CU in flight over the whole group; every problem gets the same token chunking
+  int blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    WgProblem& p = g.p[i];
+    p.dY = d[i].dY; p.X = d[i].X; p.dW = d[i].dW; p.db = d[i].db;
+    p.M = d[i].M; p.N = d[i].N; p.K = d[i].K; p.lddy = d[i].lddy; p.ldx = d[i].ldx; p.lddw = d[i].lddw;
+    p.dymap = to_rowmap(d[i].dymap); p.xmap = to_rowmap(d[i].xmap);
+    p.tiles_k = cdiv(p.K, 64);
+    int splits = std::max(1, cdiv(512, tiles_total));
+    splits = std::min(splits, std::max(1, p.M / (2 * BT)));
+    p.chunk = cdiv(cdiv(p.M, splits), BT) * BT;
+    p.splits = cdiv(p.M, p.chunk);
+    p.block_begin = blocks;
+    blocks += cdiv(p.N, 64) * p.tiles_k * p.splits;
+  }
+  hipLaunchKernelGGL((wgrad_group_kernel<T>), dim3(blocks), dim3(256), 0, s, g);
+  return check_launch("gemm_wgrad_group");
+}
+
 }  // namespace sitk
+
+extern "C" int sitk_gemm_wgrad_group(const sitk_wgrad_desc* d, int count, int dtype, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(d != nullptr && count >= 1 && count <= WG_MAX_PROBLEMS, "gemm_wgrad_group: 1..%d problems", WG_MAX_PROBLEMS);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  bool fast = true;
+  for (int i = 0; i < count; ++i) {
+    SITK_REQUIRE(d[i].M > 0 && d[i].N > 0 && d[i].K > 0 && d[i].dY && d[i].X && d[i].dW, "gemm_wgrad_group: bad problem %d", i);
+    fast = fast && wgrad_fast_ok(&d[i], dtype);
+  }
+  if (!fast) {  // generic path, one launch per problem
+    for (int i = 0; i < count; ++i) SITK_TRY(sitk_gemm_wgrad(&d[i], dtype, stream));
+    return SITK_OK;
+  }
+  if (dtype == SITK_BF16) return launch_wgrad_group<bf16>(d, count, s);
+  if (dtype == SITK_F32) return launch_wgrad_group<float>(d, count, s);
+  set_error("gemm_wgrad_group: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
+}
 
 extern "C" int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream) {
   using namespace sitk;
@@ -490,6 +863,7 @@ extern "C" int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_
   SITK_REQUIRE(d->N % 4 == 0 && d->K % 8 == 0, "gemm_wgrad: N %% 4 and K %% 8 required (N=%d K=%d)", d->N, d->K);
   SITK_REQUIRE(d->lddy % 4 == 0 && d->ldx % 8 == 0, "gemm_wgrad: leading dims must keep 16-byte alignment");
   SITK_REQUIRE(d->dY && d->X && d->dW, "gemm_wgrad: null operand");
+  if (wgrad_fast_ok(d, dtype)) return sitk_gemm_wgrad_group(d, 1, dtype, stream);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SITK_BF16) return dispatch_wgrad<bf16>(d, s);
   if (dtype == SITK_F32) return dispatch_wgrad<float>(d, s);

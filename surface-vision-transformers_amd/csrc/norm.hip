@@ -6,87 +6,110 @@
 
 namespace sitk {
 
-// One wave normalises one row at a time; a lane owns float4 groups c = lane, lane+64, ...
-// NV = ceil(D / 256) groups per lane live in registers.
-template <typename T, int NV>
+// Row layout: LPR lanes (16 / 32 / 64) share one row, so a wave normalises 64 / LPR rows at once;
+// lane j of a row group owns float4 groups c = j, j + LPR, ... (NV of them, in registers).
+// Row statistics are reduced with xor-shuffles inside the LPR-lane group.
+template <int LPR>
+SITK_DEV float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int LPR, int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             int64_t rows, int D) {
+  constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % LPR, sub = lane / LPR;
   const int nvec = D >> 2;
   f32x4 g[NV], b[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = lane + 64 * i;
+    const int c = j + LPR * i;
     if (c < nvec) { g[i] = load4(gamma + 4 * c); b[i] = load4(beta + 4 * c); }
   }
   const float invD = 1.0f / (float)D;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const float* xr = x + row * D;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + wave) * RPW; r0 < rows; r0 += (int64_t)gridDim.x * 4 * RPW) {
+    const int64_t row = r0 + sub;
+    const bool ok = row < rows;
+    const float* xr = x + (ok ? row : 0) * D;
     f32x4 v[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = lane + 64 * i;
-      v[i] = c < nvec ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const int c = j + LPR * i;
+      v[i] = (ok && c < nvec) ? load4(xr + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
       s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
-    const float mu = wave_sum(s) * invD;
+    const float mu = group_sum<LPR>(s) * invD;
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = lane + 64 * i;
+      const int c = j + LPR * i;
       if (c < nvec) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; ss += d * d; }
       }
     }
-    const float var = wave_sum(ss) * invD;
-    const float rs = rsqrtf(var + 1e-5f);
+    const float rs = rsqrtf(group_sum<LPR>(ss) * invD + 1e-5f);
+    if (ok) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        f32x4 o;
+      for (int i = 0; i < NV; ++i) {
+        const int c = j + LPR * i;
+        if (c < nvec) {
+          f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[i][e] + b[i][e];
-        store4(y + row * D + 4 * c, o);
+          for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mu) * rs * g[i][e] + b[i][e];
+          store4(y + row * D + 4 * c, o);
+        }
       }
+      if (j == 0) { mean[row] = mu; rstd[row] = rs; }
     }
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
   }
 }
 
 // dx = dres + rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
 // dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy   (per-lane partials -> LDS -> one atomic per
 // column per workgroup)
-template <typename T, int NV>
+template <typename T, int LPR, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* dres,
-                                                            float* dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int64_t rows, int D) {
-  __shared__ float red[2][4][NV * 64 * 4];
+                                                            float* dx, T* __restrict__ dx_c, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ partials,
+                                                            int64_t rows, int D, int rows_per_block) {
+  constexpr int RPW = 64 / LPR;
+  __shared__ float red[2][4 * RPW][NV * LPR * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % LPR, sub = lane / LPR;
   const int nvec = D >> 2;
   f32x4 g[NV], dg[NV], db[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int c = lane + 64 * i;
+    const int c = j + LPR * i;
     g[i] = c < nvec ? load4(gamma + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
     dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float invD = 1.0f / (float)D;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
+  const int64_t rbeg = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t rend = rbeg + rows_per_block < rows ? rbeg + rows_per_block : rows;
+  for (int64_t r0 = rbeg + wave * RPW; r0 < rend; r0 += 4 * RPW) {
+    const int64_t row = r0 + sub;
+    const bool ok = row < rend;
+    const int64_t rr = ok ? row : rbeg;
+    const float mu = mean[rr], rs = rstd[rr];
     f32x4 xh[NV], gy[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
+      const int c = j + LPR * i;
+      xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok && c < nvec) {
         const f32x4 xv = load4(x + row * D + 4 * c);
         const f32x4 dyv = load4(dy + row * D + 4 * c);
 #pragma unroll
@@ -100,37 +123,56 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
       }
     }
-    s1 = wave_sum(s1) * invD;
-    s2 = wave_sum(s2) * invD;
+    s1 = group_sum<LPR>(s1) * invD;
+    s2 = group_sum<LPR>(s2) * invD;
+    if (ok) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvec) {
-        f32x4 o;
+      for (int i = 0; i < NV; ++i) {
+        const int c = j + LPR * i;
+        if (c < nvec) {
+          f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
-        if (dres) o += load4(dres + row * D + 4 * c);
-        store4(dx + row * D + 4 * c, o);
+          for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - s1 - xh[i][e] * s2);
+          if (dres) o += load4(dres + row * D + 4 * c);
+          store4(dx + row * D + 4 * c, o);
+          if (dx_c) store4(dx_c + row * D + 4 * c, o);
+        }
       }
     }
   }
+  // slot (i, j, e) of row-group (wave, sub) holds column 4 * (j + LPR i) + e == (i * LPR + j) * 4 + e
 #pragma unroll
   for (int i = 0; i < NV; ++i)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      red[0][wave][(i * 64 + lane) * 4 + e] = dg[i][e];
-      red[1][wave][(i * 64 + lane) * 4 + e] = db[i][e];
+      red[0][wave * RPW + sub][(i * LPR + j) * 4 + e] = dg[i][e];
+      red[1][wave * RPW + sub][(i * LPR + j) * 4 + e] = db[i][e];
     }
   __syncthreads();
-  for (int c = threadIdx.x; c < NV * 256; c += 256) {
-    // column index of slot (i, lane, e): 4 * (lane + 64 i) + e  == c when laid out as above
-    if (c < D) {
-      const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-      const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4 * RPW; ++r) { a += red[0][r][c]; b += red[1][r][c]; }
+    if (partials) {  // plain stores; summed by ln_finalize_kernel (no contended atomics on 2 D addresses)
+      partials[(size_t)blockIdx.x * 2 * D + c] = a;
+      partials[(size_t)blockIdx.x * 2 * D + D + c] = b;
+    } else {
       unsafeAtomicAdd(dgamma + c, a);
       unsafeAtomicAdd(dbeta + c, b);
     }
   }
+}
+
+// dgamma[c] += sum_b partials[b][c], dbeta[c] += sum_b partials[b][D + c]; grid (cdiv(2D,256), chunks)
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partials, int nblocks, int D,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * D) return;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) s += partials[(size_t)b * 2 * D + c];
+  if (b1 > b0) unsafeAtomicAdd(c < D ? dgamma + c : dbeta + (c - D), s);
 }
 
 // out[c] += sum_r in[r][c], optional row flags (row counted iff fa[r] && (fb == null || fb[r])).
@@ -162,37 +204,74 @@ static int launch_colsum(const TI* in, int ld, const uint8_t* fa, const uint8_t*
   return check_launch("colsum");
 }
 
+// lanes per row: smallest of 16 / 32 / 64 that keeps <= 4 float4 groups per lane
+static bool ln_shape(int D, int& lpr, int& nv) {
+  const int nvec = D / 4;
+  for (int l = 16; l <= 64; l *= 2) {
+    const int n = cdiv(nvec, l);
+    if (n <= 4) { lpr = l; nv = n; return true; }
+  }
+  return false;
+}
+
+#define SITK_LN_CASES(KERNEL, ...)                                                            \
+  switch (lpr * 8 + nv) {                                                                     \
+    case 16 * 8 + 1: KERNEL(16, 1, __VA_ARGS__); break;                                       \
+    case 16 * 8 + 2: KERNEL(16, 2, __VA_ARGS__); break;                                       \
+    case 16 * 8 + 3: KERNEL(16, 3, __VA_ARGS__); break;                                       \
+    case 16 * 8 + 4: KERNEL(16, 4, __VA_ARGS__); break;                                       \
+    case 32 * 8 + 3: KERNEL(32, 3, __VA_ARGS__); break;                                       \
+    case 32 * 8 + 4: KERNEL(32, 4, __VA_ARGS__); break;                                       \
+    case 64 * 8 + 3: KERNEL(64, 3, __VA_ARGS__); break;                                       \
+    case 64 * 8 + 4: KERNEL(64, 4, __VA_ARGS__); break;                                       \
+    default: set_error("layernorm: D=%d unsupported (D <= 1024)", D); return SITK_ERR_INVALID; \
+  }
+
 template <typename T>
 static int dispatch_ln_fwd(const float* x, const float* g, const float* b, void* y, float* mean, float* rstd,
                            int64_t rows, int D, hipStream_t s) {
-  const int grid = (int)std::min<int64_t>(cdiv64(rows, 4), 4096);
-  const int nv = cdiv(D, 256);
+  int lpr = 0, nv = 0;
+  if (!ln_shape(D, lpr, nv)) { set_error("layernorm: D=%d > 1024 unsupported", D); return SITK_ERR_INVALID; }
+  const int rows_per_block = 4 * (64 / lpr);
+  const int grid = (int)std::min<int64_t>(cdiv64(rows, rows_per_block), 8192);
   T* yt = reinterpret_cast<T*>(y);
-  switch (nv) {
-    case 1: hipLaunchKernelGGL((layernorm_fwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, x, g, b, yt, mean, rstd, rows, D); break;
-    case 2: hipLaunchKernelGGL((layernorm_fwd_kernel<T, 2>), dim3(grid), dim3(256), 0, s, x, g, b, yt, mean, rstd, rows, D); break;
-    case 3: hipLaunchKernelGGL((layernorm_fwd_kernel<T, 3>), dim3(grid), dim3(256), 0, s, x, g, b, yt, mean, rstd, rows, D); break;
-    case 4: hipLaunchKernelGGL((layernorm_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, x, g, b, yt, mean, rstd, rows, D); break;
-    default: set_error("layernorm: D=%d > 1024 unsupported", D); return SITK_ERR_INVALID;
-  }
+#define SITK_LN_FWD(L, N, ...) \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<T, L, N>), dim3(grid), dim3(256), 0, s, x, g, b, yt, mean, rstd, rows, D)
+  SITK_LN_CASES(SITK_LN_FWD, 0)
+#undef SITK_LN_FWD
   return check_launch("layernorm_fwd");
+}
+
+// rows per workgroup / number of workgroups of the backward kernel (also sizes the partials scratch)
+static void ln_bwd_grid(int64_t rows, int D, int& rows_per_block, int& grid) {
+  int lpr = 16, nv = 1;
+  ln_shape(D, lpr, nv);
+  rows_per_block = 2 * 4 * (64 / lpr);  // 2 passes of the workgroup's 4 * RPW row slots
+  if (cdiv64(rows, rows_per_block) > 4096) rows_per_block = (int)cdiv64(rows, 4096);
+  grid = (int)cdiv64(rows, rows_per_block);
 }
 
 template <typename T>
 static int dispatch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* g,
-                           const float* dres, float* dx, float* dg, float* db, int64_t rows, int D, hipStream_t s) {
-  // ~64 rows per workgroup keeps the atomic traffic at D*8 bytes per 64 rows
-  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(rows, 64), 2048));
-  const int nv = cdiv(D, 256);
+                           const float* dres, float* dx, void* dx_c, float* dg, float* db, float* partials,
+                           int64_t rows, int D, hipStream_t s) {
+  int lpr = 0, nv = 0;
+  if (!ln_shape(D, lpr, nv)) { set_error("layernorm: D=%d > 1024 unsupported", D); return SITK_ERR_INVALID; }
+  int rows_per_block, grid;
+  ln_bwd_grid(rows, D, rows_per_block, grid);
   const T* dyt = reinterpret_cast<const T*>(dy);
-  switch (nv) {
-    case 1: hipLaunchKernelGGL((layernorm_bwd_kernel<T, 1>), dim3(grid), dim3(256), 0, s, dyt, x, mean, rstd, g, dres, dx, dg, db, rows, D); break;
-    case 2: hipLaunchKernelGGL((layernorm_bwd_kernel<T, 2>), dim3(grid), dim3(256), 0, s, dyt, x, mean, rstd, g, dres, dx, dg, db, rows, D); break;
-    case 3: hipLaunchKernelGGL((layernorm_bwd_kernel<T, 3>), dim3(grid), dim3(256), 0, s, dyt, x, mean, rstd, g, dres, dx, dg, db, rows, D); break;
-    case 4: hipLaunchKernelGGL((layernorm_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, s, dyt, x, mean, rstd, g, dres, dx, dg, db, rows, D); break;
-    default: set_error("layernorm: D=%d > 1024 unsupported", D); return SITK_ERR_INVALID;
+  T* dxc = reinterpret_cast<T*>(dx_c);
+#define SITK_LN_BWD(L, N, ...)                                                                                     \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, L, N>), dim3(grid), dim3(256), 0, s, dyt, x, mean, rstd, g, dres, dx, \
+                     dxc, dg, db, partials, rows, D, rows_per_block)
+  SITK_LN_CASES(SITK_LN_BWD, 0)
+#undef SITK_LN_BWD
+  SITK_LAUNCH_CHECK("layernorm_bwd");
+  if (partials) {
+    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * D, 256), std::min(grid, 32)), dim3(256), 0, s, partials, grid, D, dg, db);
+    SITK_LAUNCH_CHECK("layernorm_bwd_finalize");
   }
-  return check_launch("layernorm_bwd");
+  return SITK_OK;
 }
 
 }  // namespace sitk
@@ -209,15 +288,24 @@ extern "C" int sitk_layernorm_fwd(const float* x, const float* gamma, const floa
   return SITK_ERR_INVALID;
 }
 
+extern "C" size_t sitk_layernorm_bwd_partial_floats(int64_t rows, int D) {
+  if (rows <= 0 || D <= 0 || D > 1024) return 0;
+  int rpb, grid;
+  sitk::ln_bwd_grid(rows, D, rpb, grid);
+  return (size_t)grid * 2 * D;
+}
+
 extern "C" int sitk_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
-                                  const float* gamma, const float* dres, float* dx_out, float* dgamma, float* dbeta,
-                                  int64_t rows, int D, int dtype, sitk_stream_t stream) {
+                                  const float* gamma, const float* dres, float* dx_out, void* dx_out_c, float* dgamma,
+                                  float* dbeta, float* partials, int64_t rows, int D, int dtype, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(dy && x && mean && rstd && gamma && dx_out && dgamma && dbeta, "layernorm_bwd: null pointer");
   SITK_REQUIRE(rows > 0 && D > 0 && D % 4 == 0, "layernorm_bwd: rows=%lld D=%d", (long long)rows, D);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return dispatch_ln_bwd<bf16>(dy, x, mean, rstd, gamma, dres, dx_out, dgamma, dbeta, rows, D, s);
-  if (dtype == SITK_F32) return dispatch_ln_bwd<float>(dy, x, mean, rstd, gamma, dres, dx_out, dgamma, dbeta, rows, D, s);
+  if (dtype == SITK_BF16)
+    return dispatch_ln_bwd<bf16>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, dgamma, dbeta, partials, rows, D, s);
+  if (dtype == SITK_F32)
+    return dispatch_ln_bwd<float>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, dgamma, dbeta, partials, rows, D, s);
   set_error("layernorm_bwd: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }

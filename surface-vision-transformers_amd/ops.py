@@ -111,6 +111,20 @@ def gemm_wgrad(dY, X, dW, dtype, db=None, M=None, N=None, K=None, dymap=None, xm
     return dW
 
 
+def gemm_wgrad_group(problems, dtype):
+    """problems: list (<= 4) of dicts(dY, X, dW, db=None): all weight gradients in ONE launch."""
+    code = rt.dtype_code(dtype)
+    arr = (rt.WgradDesc * len(problems))()
+    for d, p in zip(arr, problems):
+        dY, X, dW, db = p["dY"], p["X"], p["dW"], p.get("db")
+        rt.require_cuda(dY, X, dW, db)
+        d.M, d.N, d.K = dY.shape[0], dW.shape[0], dW.shape[1]
+        d.dY, d.lddy, d.dy_is_f32, d.dymap = dY.data_ptr(), dY.stride(0), int(dY.dtype == torch.float32), _rowmap(None)
+        d.X, d.ldx, d.xmap = X.data_ptr(), X.stride(0), _rowmap(None)
+        d.dW, d.lddw, d.db = dW.data_ptr(), dW.stride(0), rt.ptr(db)
+    rt.check(rt.lib.sitk_gemm_wgrad_group(arr, len(problems), code, rt.stream_ptr()))
+
+
 # ---- LayerNorm -------------------------------------------------------------------------------------
 def layernorm_fwd(x, gamma, beta, dtype):
     rt.require_cuda(x, gamma, beta)
@@ -124,15 +138,21 @@ def layernorm_fwd(x, gamma, beta, dtype):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dtype, dx=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, dtype, dx=None, dx_c=None, partials=None):
     rows, D = x.shape
     code = rt.dtype_code(dtype)
     if dx is None:
         dx = torch.empty_like(x)
+    if partials is not None:
+        assert partials.numel() >= rt.lib.sitk_layernorm_bwd_partial_floats(rows, D)
     rt.check(rt.lib.sitk_layernorm_bwd(dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                                       rt.ptr(dres), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), rows, D, code,
-                                       rt.stream_ptr()))
+                                       rt.ptr(dres), dx.data_ptr(), rt.ptr(dx_c), dgamma.data_ptr(), dbeta.data_ptr(),
+                                       rt.ptr(partials), rows, D, code, rt.stream_ptr()))
     return dx
+
+
+def layernorm_bwd_partial_floats(rows, D):
+    return rt.lib.sitk_layernorm_bwd_partial_floats(rows, D)
 
 
 # ---- attention -------------------------------------------------------------------------------------

@@ -220,6 +220,31 @@ def test_layernorm_fwd_bwd(ops, dtype, D):
     buf = dres.clone()
     ops.layernorm_bwd(dyd, x, mean, rstd, g, buf, dgam, dbet, dtype, dx=buf)
     assert rel(buf, xr.grad + dres) < 2e-5
+    # second output in the compute dtype + partial-sum scratch (the encoder's configuration)
+    dgam2, dbet2 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dxc = torch.empty((rows, D), dtype=tdt(dtype), device=DEV)
+    part = torch.empty(ops.layernorm_bwd_partial_floats(rows, D), device=DEV)
+    dx2 = ops.layernorm_bwd(dyd, x, mean, rstd, g, dres, dgam2, dbet2, dtype, dx_c=dxc, partials=part)
+    assert rel(dx2, xr.grad + dres) < 2e-5 and torch.equal(dxc, dx2.to(tdt(dtype)))
+    assert rel(dgam2, gr.grad) < 2e-5 and rel(dbet2, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_group_matches_single_launches(ops, dtype):
+    td = tdt(dtype)
+    R, D, M = 321 * 5 + 7, 192, 768
+    probs, refs = [], []
+    for i, (n, k, bias) in enumerate([(D, M, True), (M, D, True), (D, D, True), (3 * D, D, False)]):
+        dY, X = ints(f"wgg/dY{i}", (R, n), -2, 3).to(td), ints(f"wgg/X{i}", (R, k), -2, 3).to(td)
+        dW = torch.zeros((n, k), device=DEV)
+        db = torch.zeros((n,), device=DEV) if bias else None
+        probs.append(dict(dY=dY, X=X, dW=dW, db=db))
+        refs.append((dY.float().t() @ X.float(), dY.float().sum(0)))
+    ops.gemm_wgrad_group(probs, dtype)
+    for p, (rw, rb) in zip(probs, refs):
+        assert torch.equal(p["dW"], rw)
+        if p["db"] is not None:
+            assert torch.equal(p["db"], rb)
 
 
 # ---------------------------------------------------------------------------------------------------
