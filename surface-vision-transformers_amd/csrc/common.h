@@ -47,6 +47,25 @@ int check_launch(const char* what);
     if (_e) return _e;                               \
   } while (0)
 
+// internal (cross-translation-unit) helpers of the LayerNorm backward used by the encoder
+namespace sitk {
+constexpr int LN_FINALIZE_MAX = 32;
+struct LnFinalizeEntry {
+  const float* partials;
+  float* dgamma;
+  float* dbeta;
+};
+struct LnFinalizeBatch {
+  LnFinalizeEntry e[LN_FINALIZE_MAX];
+};
+// row/parameter-gradient kernel only: per-workgroup dgamma/dbeta sums go to `partials`
+int layernorm_bwd_deferred(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* dres, float* dx_out, void* dx_out_c, float* partials, int64_t rows, int D, int dtype,
+                           hipStream_t s);
+// one launch reducing every deferred entry into its dgamma/dbeta
+int layernorm_finalize_multi(const LnFinalizeEntry* entries, int count, int64_t rows, int D, hipStream_t s);
+}  // namespace sitk
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -73,6 +73,7 @@ struct Scratch {
   float* dxB;
   char *dxAc, *dxBc;
   float* ln_partials;
+  size_t ln_partial_floats;
 };
 
 struct Layout {
@@ -118,7 +119,8 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
   L.scratch.dxB = (float*)stake(R * D * 4);
   L.scratch.dxAc = stake(R * D * es);
   L.scratch.dxBc = stake(R * D * es);
-  L.scratch.ln_partials = (float*)stake(sitk_layernorm_bwd_partial_floats((int64_t)R, (int)D) * 4);
+  L.scratch.ln_partial_floats = sitk_layernorm_bwd_partial_floats((int64_t)R, (int)D);
+  L.scratch.ln_partials = (float*)stake(L.scratch.ln_partial_floats * 4 * 2 * c.depth);   // one region per LayerNorm
   L.scratch_bytes = off;
   return L;
 }
@@ -252,6 +254,9 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   // each in the compute dtype (Ac, Bc) that feeds the GEMMs' operand loads: LN2' reads A and writes
   // B, LN1' reads B and writes A, so d(x_out) [A] and d(x_mid) [B] both survive until the layer's
   // four weight gradients run as ONE grouped launch.
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  std::vector<LnFinalizeEntry> ln_entries;
+  ln_entries.reserve(2 * (layer_end - layer_begin));
   SITK_TRY(sitk_cast_rows(dx, D, S.dxAc, D, R, D, dt, stream));
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const LayerActs& a = L.layers[l];
@@ -262,8 +267,9 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     SITK_TRY(sitk_gemm_nt(&d1, dt, stream));
     sitk_gemm_desc d2 = gemm_desc(R, D, M, S.du, M, 0, a.w1_t, SITK_EPI_STORE, S.dh, D, 0);
     SITK_TRY(sitk_gemm_nt(&d2, dt, stream));
-    SITK_TRY(sitk_layernorm_bwd(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, S.dxB, S.dxBc, G[l].ln2_w, G[l].ln2_b,
-                                S.ln_partials, R, D, dt, stream));
+    float* part2 = S.ln_partials + (size_t)(2 * l + 1) * S.ln_partial_floats;
+    SITK_TRY(layernorm_bwd_deferred(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, S.dxB, S.dxBc, part2, R, D, dt, hs));
+    ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b});
     // ---- attention branch: xmid = x + Wo attn(Wqkv LN1(x)) + bo ----
     sitk_gemm_desc d3 = gemm_desc(R, I, D, S.dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
     SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
@@ -278,8 +284,10 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     SITK_TRY(sitk_gemm_wgrad_group(wg, 4, dt, stream));
     sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, S.dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
     SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
-    SITK_TRY(sitk_layernorm_bwd(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, G[l].ln1_w, G[l].ln1_b,
-                                S.ln_partials, R, D, dt, stream));
+    float* part1 = S.ln_partials + (size_t)(2 * l) * S.ln_partial_floats;
+    SITK_TRY(layernorm_bwd_deferred(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, part1, R, D, dt, hs));
+    ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b});
   }
-  return SITK_OK;
+  // every LayerNorm parameter gradient of the slice in one reduction launch
+  return layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs);
 }

@@ -37,18 +37,32 @@ struct GeluParts {
   float cdf;  // 0.5 (1 + erf(x / sqrt2))
   float pdf;  // exp(-x^2/2) / sqrt(2 pi)
 };
-SITK_DEV GeluParts gelu_parts(float x) {
-  const float ax = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-  const float e = __expf(-ax * ax);
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float erf_abs = fmaf(-poly * t, e, 1.0f);
-  const float erfv = copysignf(erf_abs, x);
-  return GeluParts{0.5f * (1.0f + erfv), e * 0.39894228040143267794f};
+// Phi(x) = x >= 0 ? 1 - h : h with h = 0.5 * erfc(|x|/sqrt2) = 0.5 * poly(t) * exp(-x^2/2), t = 1/(1 + p|x|/sqrt2).
+//   ACCURATE (f32 mode): A&S 7.1.26, 5 terms, |erf err| <= 1.5e-7
+//   else     (bf16 mode): A&S 7.1.25, 3 terms, |erf err| <= 2.5e-5 (far below one bf16 ulp of the
+//                         output; the VALU epilogue of the fc1 / dfc2 GEMMs is their bottleneck)
+template <bool ACCURATE>
+SITK_DEV GeluParts gelu_parts_t(float x) {
+  const float ax = fabsf(x);
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-x^2 / 2)
+  float h;
+  if constexpr (ACCURATE) {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float poly = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    poly = fmaf(poly, t, 0.5f * 1.421413741f);
+    poly = fmaf(poly, t, 0.5f * -0.284496736f);
+    poly = fmaf(poly, t, 0.5f * 0.254829592f);
+    h = poly * t * e;
+  } else {
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.47047f * 0.70710678118654752440f, ax, 1.0f));
+    float poly = fmaf(0.5f * 0.7478556f, t, 0.5f * -0.0958798f);
+    poly = fmaf(poly, t, 0.5f * 0.3480242f);
+    h = poly * t * e;
+  }
+  return GeluParts{x >= 0.f ? 1.0f - h : h, e * 0.39894228040143267794f};
 }
+template <typename T>
+SITK_DEV GeluParts gelu_parts(float x) { return gelu_parts_t<sizeof(T) == 4>(x); }
 
 template <typename T, typename TO, int EPI>
 SITK_DEV void gemm_epilogue(const GemmParams& p, int m, int n, f32x4 v) {
@@ -63,16 +77,54 @@ SITK_DEV void gemm_epilogue(const GemmParams& p, int m, int n, f32x4 v) {
     store4(reinterpret_cast<T*>(p.out) + orow, v);
     f32x4 g;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = v[i] * gelu_parts(v[i]).cdf;
+    for (int i = 0; i < 4; ++i) g[i] = v[i] * gelu_parts<T>(v[i]).cdf;
     store4(reinterpret_cast<T*>(p.out2) + orow, g);
   } else if constexpr (EPI == SITK_EPI_DGELU) {
     const f32x4 u = load4(reinterpret_cast<const T*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const GeluParts gp = gelu_parts(u[i]);
+      const GeluParts gp = gelu_parts<T>(u[i]);
       v[i] *= fmaf(u[i], gp.pdf, gp.cdf);
     }
     store4(reinterpret_cast<T*>(p.out) + orow, v);
+  }
+}
+
+// Epilogue math only (no stores): v <- acc (+bias) (+residual | * gelu'(u)); v2 <- gelu(v) for BIAS_GELU.
+template <typename T, int EPI>
+SITK_DEV void epilogue_math(const GemmParams& p, int m, int n, f32x4& v, f32x4& v2) {
+  if (p.bias) v += load4(p.bias + n);
+  if constexpr (EPI == SITK_EPI_BIAS_RES) {
+    v += load4(reinterpret_cast<const float*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
+  } else if constexpr (EPI == SITK_EPI_BIAS_GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v2[i] = v[i] * gelu_parts<T>(v[i]).cdf;
+  } else if constexpr (EPI == SITK_EPI_DGELU) {
+    const f32x4 u = load4(reinterpret_cast<const T*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const GeluParts gp = gelu_parts<T>(u[i]);
+      v[i] *= fmaf(u[i], gp.pdf, gp.cdf);
+    }
+  }
+}
+
+// A 16-row x BN-column half tile held as v[i] = 4 features (16 i + 4*(lane>>4) ..) of row lane&15 goes
+// through a wave-private LDS region and out to global memory as whole rows, 16 bytes per lane.
+template <typename TS, int BN>
+SITK_DEV void staged_rows_store(char* slot, const f32x4 (&v)[BN / 16], TS* out, const GemmParams& p, int mrow, int n0, int lane) {
+  constexpr int PB = BN * (int)sizeof(TS) + 16;     // padded row pitch (bytes)
+  constexpr int CPRW = BN * (int)sizeof(TS) / 16;   // 16-byte chunks per row
+  constexpr int EPC = 16 / (int)sizeof(TS);
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < BN / 16; ++i) store4(reinterpret_cast<TS*>(slot + fr * PB) + 16 * i + 4 * fq, v[i]);
+#pragma unroll
+  for (int c0 = 0; c0 < 16 * CPRW; c0 += 64) {
+    const int c = c0 + lane, row = c / CPRW, cc = c % CPRW;
+    const u32x4 d = *reinterpret_cast<const u32x4*>(slot + row * PB + cc * 16);
+    const int m = mrow + row, n = n0 + cc * EPC;
+    if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)map_row(p.omap, m) * p.ldo + n) = d;
   }
 }
 
@@ -221,7 +273,8 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(GemmParams p, int gro
   using T = bf16;
   constexpr int NT = BN / 16;                 // MFMA column tiles per strip
   constexpr int WB = KT * BN * 128;           // weight panel bytes
-  constexpr int SB = KT * 32 * 128;           // one strip slot: 32 rows x KT panels of 128 B
+  constexpr int SB = KT * 32 * 128 > 8704 ? KT * 32 * 128 : 8704;  // strip slot (32 rows x KT panels of 128 B), also
+                                                                    // the staging area of the epilogue (<= 16 x 528 B)
   __shared__ __attribute__((aligned(256))) char smem[WB + 8 * SB];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -284,17 +337,25 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(GemmParams p, int gro
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mma(fw[i], fa[j], acc[i][j]);
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // slot fully read: refill it
-    if (strip + nunits < nstrips) issue(strip + nunits);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // slot fully read
+    // ---- epilogue: math in registers, then the 16-row half tiles go through this wave's own LDS
+    // slot so that every store instruction writes whole rows (16 lanes x 16 B = 256 contiguous
+    // bytes) instead of sixteen 32-byte fragments ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int m = strip * 32 + 16 * j + fr;
+      const int mrow = strip * 32 + 16 * j;
+      f32x4 v1[NT], v2[NT];
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        const int n = n0 + 16 * i + 4 * fq;
-        if (m < p.M && n < p.N) gemm_epilogue<T, TO, EPI>(p, m, n, acc[i][j]);
+        const int n = n0 + 16 * i + 4 * fq, m = mrow + fr;
+        v1[i] = acc[i][j];
+        v2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < p.M && n < p.N) epilogue_math<T, EPI>(p, m, n, v1[i], v2[i]);
       }
+      staged_rows_store<TO, BN>(slot, v1, reinterpret_cast<TO*>(p.out), p, mrow, n0, lane);
+      if constexpr (EPI == SITK_EPI_BIAS_GELU) staged_rows_store<T, BN>(slot, v2, reinterpret_cast<T*>(p.out2), p, mrow, n0, lane);
     }
+    if (strip + nunits < nstrips) issue(strip + nunits);            // slot free again: refill it
   }
 }
 
@@ -321,7 +382,8 @@ template <typename T, typename TA, typename TO, int EPI>
 static int launch_gemm_nt(const GemmParams& p, hipStream_t s) {
   if constexpr (std::is_same<T, bf16>::value && std::is_same<TA, bf16>::value) {
     // weight-resident streaming kernel: K up to 192, 16-byte aligned rows, enough tokens to stream
-    if (p.K <= 192 && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.M >= 1024)
+    if (p.K <= 192 && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.M >= 1024 && p.N % 8 == 0 &&
+        (sizeof(TO) == 4 || p.ldo % 8 == 0))
       return launch_gemm_nt_wres<TO, EPI>(p, s);
   }
   const bool wide = (p.N % 128 == 0) || p.N > 1024;

@@ -254,7 +254,7 @@ static void ln_bwd_grid(int64_t rows, int D, int& rows_per_block, int& grid) {
 template <typename T>
 static int dispatch_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* g,
                            const float* dres, float* dx, void* dx_c, float* dg, float* db, float* partials,
-                           int64_t rows, int D, hipStream_t s) {
+                           int64_t rows, int D, hipStream_t s, bool finalize = true) {
   int lpr = 0, nv = 0;
   if (!ln_shape(D, lpr, nv)) { set_error("layernorm: D=%d > 1024 unsupported", D); return SITK_ERR_INVALID; }
   int rows_per_block, grid;
@@ -267,11 +267,44 @@ static int dispatch_ln_bwd(const void* dy, const float* x, const float* mean, co
   SITK_LN_CASES(SITK_LN_BWD, 0)
 #undef SITK_LN_BWD
   SITK_LAUNCH_CHECK("layernorm_bwd");
-  if (partials) {
+  if (partials && finalize) {
     hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * D, 256), std::min(grid, 32)), dim3(256), 0, s, partials, grid, D, dg, db);
     SITK_LAUNCH_CHECK("layernorm_bwd_finalize");
   }
   return SITK_OK;
+}
+
+// All deferred LayerNorm parameter-gradient reductions of a backward slice in one launch.
+__global__ __launch_bounds__(256) void ln_finalize_multi_kernel(LnFinalizeBatch batch, int nblocks, int D) {
+  const LnFinalizeEntry e = batch.e[blockIdx.z];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * D) return;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  float s = 0.f;
+  for (int b = b0; b < b1; ++b) s += e.partials[(size_t)b * 2 * D + c];
+  if (b1 > b0) unsafeAtomicAdd(c < D ? e.dgamma + c : e.dbeta + (c - D), s);
+}
+
+int layernorm_finalize_multi(const LnFinalizeEntry* entries, int count, int64_t rows, int D, hipStream_t s) {
+  int rpb, grid;
+  ln_bwd_grid(rows, D, rpb, grid);
+  for (int i0 = 0; i0 < count; i0 += LN_FINALIZE_MAX) {
+    LnFinalizeBatch b;
+    const int n = std::min(LN_FINALIZE_MAX, count - i0);
+    for (int i = 0; i < n; ++i) b.e[i] = entries[i0 + i];
+    hipLaunchKernelGGL(ln_finalize_multi_kernel, dim3(cdiv(2 * D, 256), std::min(grid, 16), n), dim3(256), 0, s, b, grid, D);
+    SITK_LAUNCH_CHECK("layernorm_finalize_multi");
+  }
+  return SITK_OK;
+}
+
+int layernorm_bwd_deferred(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* dres, float* dx_out, void* dx_out_c, float* partials, int64_t rows, int D, int dtype,
+                           hipStream_t s) {
+  if (dtype == SITK_BF16)
+    return dispatch_ln_bwd<bf16>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, nullptr, nullptr, partials, rows, D, s, false);
+  return dispatch_ln_bwd<float>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, nullptr, nullptr, partials, rows, D, s, false);
 }
 
 }  // namespace sitk

@@ -104,3 +104,16 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f
+
+
+def test_reference_style_import_resolves_to_sitk(sitk_pkg):
+    """`from models.sit import SiT` (tools/train.py:38) with the package dir on sys.path."""
+    import subprocess
+    import sys
+    code = ("from models.sit import SiT; from models.mpp import masked_patch_pretraining; import sitk.models.sit as s; "
+            "assert SiT is s.SiT; m = SiT(dim=192, depth=1, heads=3, mlp_dim=768, num_patches=80, num_vertices=561); "
+            "print(len(m.state_dict()))")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "surface-vision-transformers_amd")]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp")
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == str(4 + 11 + 4)
