@@ -344,8 +344,238 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Sequence-resident variants (bf16, N <= 384: the 81- and 321-token configurations of the reference).
+// K and V of one (batch, head) are 2 * 384 * 128 B = 96 KB: the whole pair is brought into LDS ONCE
+// by LDS-DMA (one workgroup of 8 waves per (batch, head)), then every wave walks its 16-row query
+// (or key) tiles over all of it with no further barrier or staging.  Removes the 6x K/V re-reads, the
+// 12 barriers and the exposed global-load latency per tile of the tiled kernels above.
+// ------------------------------------------------------------------------------------------
+constexpr int RES_MAX_N = 384;
+__device__ u32x4 g_zero_page_attn[4];
+
+// rows [0, ntiles*64) x 64 bf16 columns of `src` (leading dim ld) -> LDS tiles [t][64][128 B]; rows >= nrows are zero
+SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, int nrows, int ntiles, int wave, int lane) {
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_attn);
+  for (int q = wave; q < ntiles * 8; q += 8) {      // one piece = 8 rows x 128 B
+    const int row = q * 8 + (lane >> 3), r64 = row & 63;
+    const int key = ((r64 >> 1) & 1) | (((r64 >> 3) & 1) << 1);
+    const int chunk = (lane & 7) ^ (key << 1);
+    const char* g = row < nrows ? reinterpret_cast<const char*>(src + (size_t)row * ld + chunk * 8) : zero;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                           float* __restrict__ lse, int N, int H, float scale) {
+  using T = bf16;
+  __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int h = blockIdx.x % H, b = blockIdx.x / H, I = H * 64, nkt = (N + 63) / 64;
+  const size_t ld = (size_t)3 * I;
+  const T* base = qkv + (size_t)b * N * ld;
+  char* sK = smem;
+  char* sV = smem + nkt * 8192;
+  dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane);
+  dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float c = scale * kLog2e;
+  for (int qt = wave; qt * 16 < N; qt += 8) {
+    const int q = qt * 16 + fr, qc = min(q, N - 1);
+    u32x4 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + ks * 32 + fq * 8);
+    float m = -1e30f, l = 0.f;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nkt; ++t) {
+      f32x4 s[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      row_mma<T>(s, sK + t * 8192, qf, lane);
+      const bool tail = (t + 1) * 64 > N;
+      float mx = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          if (tail && t * 64 + 16 * i + 4 * fq + jj >= N) s[i][jj] = -INFINITY;
+          mx = fmaxf(mx, s[i][jj]);
+        }
+      mx = xor_max4(mx) * c;                       // c > 0: max commutes with the scale
+      const float mn = fmaxf(m, mx);
+      const float alpha = fast_exp2(m - mn);
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float pv = fast_exp2(fmaf(s[i][jj], c, -mn));
+          s[i][jj] = pv;
+          ps += pv;
+        }
+      l = l * alpha + ps;
+      m = mn;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+      TrMma<T>::run(oacc, s, sV + t * 8192, lane);
+    }
+    const float lt = xor_sum4(l);
+    const float inv = 1.0f / lt;
+    if (q < N) {
+      T* orow = o + ((size_t)b * N + q) * I + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt + 4 * fq, oacc[dt] * inv);
+      if (fq == 0) lse[((size_t)b * H + h) * N + q] = (m + __log2f(lt)) * kLn2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                              const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
+                                                              int H, float scale) {
+  using T = bf16;
+  __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int h = blockIdx.x % H, b = blockIdx.x / H, I = H * 64, nkt = (N + 63) / 64;
+  const size_t ld = (size_t)3 * I;
+  const T* base = qkv + (size_t)b * N * ld;
+  char* sK = smem;
+  char* sV = smem + nkt * 8192;
+  dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane);
+  dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float c = scale * kLog2e;
+  for (int qt = wave; qt * 16 < N; qt += 8) {
+    const int q = qt * 16 + fr, qc = min(q, N - 1);
+    u32x4 qf[2], dof[2];
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int eo = ks * 32 + fq * 8;
+      qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
+      const T* dop = d_o + ((size_t)b * N + qc) * I + h * 64 + eo;
+      const T* op = o + ((size_t)b * N + qc) * I + h * 64 + eo;
+      dof[ks] = *reinterpret_cast<const u32x4*>(dop);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dpart += (float)dop[e] * (float)op[e];
+    }
+    const float dl = xor_sum4(dpart);
+    const size_t ridx = ((size_t)b * H + h) * N + qc;
+    if (q < N && fq == 0) delta[ridx] = dl;
+    const float Lq = lse[ridx] * kLog2e;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nkt; ++t) {
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      row_mma<T>(s, sK + t * 8192, qf, lane);
+      row_mma<T>(dp, sV + t * 8192, dof, lane);
+      const bool tail = (t + 1) * 64 > N;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          float pv = fast_exp2(fmaf(s[i][jj], c, -Lq));
+          if (tail && t * 64 + 16 * i + 4 * fq + jj >= N) pv = 0.f;
+          s[i][jj] = pv * (dp[i][jj] - dl) * scale;
+        }
+      TrMma<T>::run(dq, s, sK + t * 8192, lane);
+    }
+    if (q < N) {
+      T* row = dqkv + ((size_t)b * N + q) * ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt + 4 * fq, dq[dt]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               bf16* __restrict__ dqkv, int N, int H, float scale) {
+  using T = bf16;
+  __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192 + 2 * RES_MAX_N * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int h = blockIdx.x % H, b = blockIdx.x / H, I = H * 64, nqt = (N + 63) / 64;
+  const size_t ld = (size_t)3 * I;
+  const T* base = qkv + (size_t)b * N * ld;
+  char* sQ = smem;
+  char* sDO = smem + nqt * 8192;
+  float* sL = reinterpret_cast<float*>(smem + 2 * (RES_MAX_N / 64) * 8192);
+  float* sD = sL + RES_MAX_N;
+  dma_rows_bf16(sQ, base + h * 64, ld, N, nqt, wave, lane);
+  dma_rows_bf16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, nqt, wave, lane);
+  for (int r = tid; r < nqt * 64; r += 512) {
+    const size_t ridx = ((size_t)b * H + h) * N + min(r, N - 1);
+    sL[r] = r < N ? lse[ridx] * kLog2e : INFINITY;     // exp2(x - inf) = 0 for padded query rows
+    sD[r] = r < N ? delta[ridx] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float c = scale * kLog2e;
+  for (int kt = wave; kt * 16 < N; kt += 8) {
+    const int key = kt * 16 + fr, kc = min(key, N - 1);
+    u32x4 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int eo = ks * 32 + fq * 8;
+      kf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo);
+      vf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + eo);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int t = 0; t < nqt; ++t) {
+      f32x4 s[4], dp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      row_mma<T>(s, sQ + t * 8192, kf, lane);
+      row_mma<T>(dp, sDO + t * 8192, vf, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 Lr = *reinterpret_cast<const f32x4*>(sL + t * 64 + 16 * i + 4 * fq);
+        const f32x4 Dr = *reinterpret_cast<const f32x4*>(sD + t * 64 + 16 * i + 4 * fq);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float pv = fast_exp2(fmaf(s[i][jj], c, -Lr[jj]));
+          s[i][jj] = pv;
+          dp[i][jj] = pv * (dp[i][jj] - Dr[jj]) * scale;
+        }
+      }
+      TrMma<T>::run(dv, s, sDO + t * 8192, lane);
+      TrMma<T>::run(dk, dp, sQ + t * 8192, lane);
+    }
+    if (key < N) {
+      T* row = dqkv + ((size_t)b * N + key) * ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store4(row + I + 16 * dt + 4 * fq, dk[dt]);
+        store4(row + 2 * I + 16 * dt + 4 * fq, dv[dt]);
+      }
+    }
+  }
+}
+
 template <typename T>
 static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (N <= RES_MAX_N) {
+      hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
+                         reinterpret_cast<bf16*>(o), lse, N, H, scale);
+      return check_launch("attention_fwd_res");
+    }
+  }
   dim3 grid(cdiv(N, 64) * H * B);
   hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
                      reinterpret_cast<T*>(o), lse, N, H, scale);
@@ -355,6 +585,17 @@ static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, fl
 template <typename T>
 static int run_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
                    int B, int N, int H, float scale, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (N <= RES_MAX_N) {
+      hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
+                         reinterpret_cast<const bf16*>(o), reinterpret_cast<const bf16*>(d_o), lse, delta,
+                         reinterpret_cast<bf16*>(dqkv), N, H, scale);
+      SITK_LAUNCH_CHECK("attention_bwd_dq_res");
+      hipLaunchKernelGGL(attn_bwd_dkv_res_kernel, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
+                         reinterpret_cast<const bf16*>(d_o), lse, delta, reinterpret_cast<bf16*>(dqkv), N, H, scale);
+      return check_launch("attention_bwd_dkv_res");
+    }
+  }
   dim3 grid(cdiv(N, 64) * H * B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
                      reinterpret_cast<const T*>(o), reinterpret_cast<const T*>(d_o), lse, delta,

@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   constexpr int EPV = Mma<T>::EPV;
   constexpr int BKE = 128 / (int)sizeof(T);  // contraction elements per 128-byte tile row
   constexpr int ACH = BM * 8 / 256, WCH = BN * 8 / 256;
-  __shared__ __attribute__((aligned(256))) char smem[(BM + BN) * 128];
+  constexpr int STAGE = (BM + BN) * 128;    // one LDS stage: A tile then W tile
+  __shared__ __attribute__((aligned(256))) char smem[2 * STAGE];
   char* sA = smem;
   char* sW = smem + BM * 128;
 
@@ -162,7 +163,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   const TA* __restrict__ A = reinterpret_cast<const TA*>(p.A);
   const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
 
-  u32x4 ra[ACH], rw[WCH];
   const u32x4 zero = {0u, 0u, 0u, 0u};
   size_t a_base[ACH], w_base[WCH];
   bool a_ok[ACH], w_ok[WCH];
@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     w_ok[i] = n < p.N;
     w_base[i] = w_ok[i] ? (size_t)n * p.ldw + (c & 7) * EPV : 0;
   }
-  auto gload = [&](int kt) {
+  // Pipeline: global loads run TWO k-tiles ahead in two register stages; LDS is double buffered, so
+  // there is one barrier per k-tile and the write of tile k+1 overlaps other waves' MFMAs of tile k.
+  auto gload = [&](int kt, u32x4 (&ra)[ACH], u32x4 (&rw)[WCH]) {
     const int kb = kt * BKE;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
@@ -195,16 +197,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
         rw[i] = (k + EPV <= p.K) ? VecLoad<T, T>::load(W + w_base[i] + kb) : vec_load_partial<T, T>(W + w_base[i] + kb, p.K - k);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf, const u32x4 (&ra)[ACH], const u32x4 (&rw)[WCH]) {
+    char* bA = sA + buf * STAGE;
+    char* bW = sW + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < ACH; ++i) {
       const int c = tid + 256 * i;
-      *reinterpret_cast<u32x4*>(sA + lds_off(c >> 3, (c & 7) * 16)) = ra[i];
+      *reinterpret_cast<u32x4*>(bA + lds_off(c >> 3, (c & 7) * 16)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < WCH; ++i) {
       const int c = tid + 256 * i;
-      *reinterpret_cast<u32x4*>(sW + lds_off(c >> 3, (c & 7) * 16)) = rw[i];
+      *reinterpret_cast<u32x4*>(bW + lds_off(c >> 3, (c & 7) * 16)) = rw[i];
     }
   };
 
@@ -213,33 +217,42 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int KT = (p.K + BKE - 1) / BKE;
-  gload(0);
-  lstore();
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT) gload(kt + 1);
+  auto compute = [&](int buf) {
+    const char* bA = sA + buf * STAGE;
+    const char* bW = sW + buf * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       u32x4 fw[NT], fa[MT];
 #pragma unroll
       for (int i = 0; i < NT; ++i)
-        fw[i] = *reinterpret_cast<const u32x4*>(sW + lds_off(wn * (BN / WN) + 16 * i + fr, ks * 64 + fq * 16));
+        fw[i] = *reinterpret_cast<const u32x4*>(bW + lds_off(wn * (BN / WN) + 16 * i + fr, ks * 64 + fq * 16));
 #pragma unroll
       for (int j = 0; j < MT; ++j)
-        fa[j] = *reinterpret_cast<const u32x4*>(sA + lds_off(wm * (BM / WM) + 16 * j + fr, ks * 64 + fq * 16));
+        fa[j] = *reinterpret_cast<const u32x4*>(bA + lds_off(wm * (BM / WM) + 16 * j + fr, ks * 64 + fq * 16));
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = Mma<T>::mma(fw[i], fa[j], acc[i][j]);
     }
+  };
+
+  const int KT = (p.K + BKE - 1) / BKE;
+  u32x4 ra0[ACH], rw0[WCH], ra1[ACH], rw1[WCH];
+  gload(0, ra0, rw0);
+  if (KT > 1) gload(1, ra1, rw1);
+  lstore(0, ra0, rw0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; kt += 2) {
+    if (kt + 2 < KT) gload(kt + 2, ra0, rw0);
+    compute(0);
+    if (kt + 1 < KT) lstore(1, ra1, rw1);
     __syncthreads();
-    if (kt + 1 < KT) {
-      lstore();
-      __syncthreads();
-    }
+    if (kt + 1 >= KT) break;
+    if (kt + 3 < KT) gload(kt + 3, ra1, rw1);
+    compute(1);
+    if (kt + 2 < KT) lstore(0, ra0, rw0);
+    __syncthreads();
   }
 
 #pragma unroll
@@ -268,14 +281,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 // ------------------------------------------------------------------------------------------
 __device__ u32x4 g_zero_page_nt[4];
 
-template <typename TO, int EPI, int BN, int KT>
-__global__ __launch_bounds__(512) void gemm_nt_wres_kernel(GemmParams p, int groups) {
+template <typename TO, int BN>
+constexpr int wres_stage_bytes() { return (16 * (BN * (int)sizeof(TO) + 16) + 255) / 256 * 256; }
+template <typename TO, int BN, int KT, int MT>
+constexpr int wres_slot_bytes() {
+  return KT * MT * 16 * 128 > wres_stage_bytes<TO, BN>() ? KT * MT * 16 * 128 : wres_stage_bytes<TO, BN>();
+}
+
+// WAVES waves per workgroup, each streaming strips of 16*MT tokens (16 waves x 16 rows when the LDS
+// budget allows: 4 waves per SIMD hide the DMA / epilogue latencies of one another).
+template <typename TO, int EPI, int BN, int KT, int WAVES, int MT>
+__global__ __launch_bounds__(WAVES * 64) void gemm_nt_wres_kernel(GemmParams p, int groups) {
   using T = bf16;
   constexpr int NT = BN / 16;                 // MFMA column tiles per strip
+  constexpr int ROWS = 16 * MT;               // tokens per strip
+  constexpr int PPP = ROWS / 8;               // 8-row DMA pieces per 128-byte panel of a strip
   constexpr int WB = KT * BN * 128;           // weight panel bytes
-  constexpr int SB = KT * 32 * 128 > 8704 ? KT * 32 * 128 : 8704;  // strip slot (32 rows x KT panels of 128 B), also
-                                                                    // the staging area of the epilogue (<= 16 x 528 B)
-  __shared__ __attribute__((aligned(256))) char smem[WB + 8 * SB];
+  constexpr int SB = wres_slot_bytes<TO, BN, KT, MT>();  // strip slot, also the epilogue's staging area
+  __shared__ __attribute__((aligned(256))) char smem[WB + WAVES * SB];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
@@ -284,8 +307,8 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(GemmParams p, int gro
   const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
   const char* zero = reinterpret_cast<const char*>(g_zero_page_nt);
   const int r8 = lane >> 3;                                          // row within an 8-row DMA piece
-  // ---- weight panel: KT panels x BN rows, pieces of 8 rows; 8 waves share the pieces ----
-  for (int q = wave; q < KT * BN / 8; q += 8) {
+  // ---- weight panel: KT panels x BN rows, pieces of 8 rows shared by the waves ----
+  for (int q = wave; q < KT * BN / 8; q += WAVES) {
     const int kt = q / (BN / 8), row = (q % (BN / 8)) * 8 + r8;
     const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
     const int k = kt * 64 + ((lane & 7) ^ (key << 1)) * 8;
@@ -295,19 +318,19 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(GemmParams p, int gro
                                      (__attribute__((address_space(3))) void*)(smem + kt * BN * 128 + (q % (BN / 8)) * 1024), 16, 0, 0);
   }
   char* slot = smem + WB + wave * SB;
-  const int nstrips = (p.M + 31) / 32;
-  const int unit = g * 8 + wave, nunits = groups * 8;
+  const int nstrips = (p.M + ROWS - 1) / ROWS;
+  const int unit = g * WAVES + wave, nunits = groups * WAVES;
   auto issue = [&](int strip) {
 #pragma unroll
-    for (int q = 0; q < KT * 4; ++q) {
-      const int kt = q / 4, row = (q % 4) * 8 + r8;
+    for (int q = 0; q < KT * PPP; ++q) {
+      const int kt = q / PPP, row = (q % PPP) * 8 + r8;
       const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
       const int k = kt * 64 + ((lane & 7) ^ (key << 1)) * 8;
-      const int m = strip * 32 + row;
+      const int m = strip * ROWS + row;
       const bool ok = m < p.M && k < p.K;
       const T* src = ok ? A + (size_t)map_row(p.amap, ok ? m : 0) * p.lda + k : reinterpret_cast<const T*>(zero);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(slot + kt * 32 * 128 + (q % 4) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(slot + kt * ROWS * 128 + (q % PPP) * 1024), 16, 0, 0);
     }
   };
   int strip = unit;
@@ -318,32 +341,34 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(GemmParams p, int gro
   const int fr = lane & 15, fq = lane >> 4;
   for (; strip < nstrips; strip += nunits) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's strip has landed
-    f32x4 acc[NT][2];
+    f32x4 acc[NT][MT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        u32x4 fa[2], fw[NT];
+        u32x4 fa[MT], fw[NT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          fa[j] = *reinterpret_cast<const u32x4*>(slot + kt * 32 * 128 + lds_off(16 * j + fr, ks * 64 + fq * 16));
+        for (int j = 0; j < MT; ++j)
+          fa[j] = *reinterpret_cast<const u32x4*>(slot + kt * ROWS * 128 + lds_off(16 * j + fr, ks * 64 + fq * 16));
 #pragma unroll
         for (int i = 0; i < NT; ++i)
           fw[i] = *reinterpret_cast<const u32x4*>(smem + kt * BN * 128 + lds_off(16 * i + fr, ks * 64 + fq * 16));
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mma(fw[i], fa[j], acc[i][j]);
+          for (int j = 0; j < MT; ++j) acc[i][j] = Mma<T>::mma(fw[i], fa[j], acc[i][j]);
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // slot fully read
-    // ---- epilogue: math in registers, then the 16-row half tiles go through this wave's own LDS
-    // slot so that every store instruction writes whole rows (16 lanes x 16 B = 256 contiguous
-    // bytes) instead of sixteen 32-byte fragments ----
+    // ---- epilogue: math in registers, then the 16-row tiles go through this wave's own LDS slot so
+    // that every store instruction writes whole rows (16 lanes x 16 B = 256 contiguous bytes)
+    // instead of sixteen 32-byte fragments ----
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int mrow = strip * 32 + 16 * j;
+    for (int j = 0; j < MT; ++j) {
+      const int mrow = strip * ROWS + 16 * j;
       f32x4 v1[NT], v2[NT];
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
@@ -359,23 +384,161 @@ __global__ __launch_bounds__(512) void gemm_nt_wres_kernel(GemmParams p, int gro
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Large-K NT GEMM for feature counts that are multiples of 192 (net.3, and the input gradients
+// through net.0 / to_qkv; the patch embedding): tile 128 tokens x 192 features x 64 (k), 8 waves as
+// 4 (tokens) x 2 (features), each 32 x 96.  A and W k-tiles travel global -> LDS by LDS-DMA into two
+// stages (counted vmcnt + raw s_barrier, the next k-tile's DMA stays in flight under the MFMAs);
+// fragments are read by ds_read_b128 inside asm blocks so that the compiler does not drain that DMA.
+// 77 flop per staged byte (the 128 x 64 generic tile: 43), A is read once per 192 features.
+// ------------------------------------------------------------------------------------------
+#define SITK_N192_READS(KSBASE_A, KSBASE_W)                                                        \
+  asm volatile(                                                                                    \
+      "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:2048\n\t"                                 \
+      "ds_read_b128 %2, %9 offset:16384\n\tds_read_b128 %3, %9 offset:18432\n\t"                   \
+      "ds_read_b128 %4, %9 offset:20480\n\tds_read_b128 %5, %9 offset:22528\n\t"                   \
+      "ds_read_b128 %6, %9 offset:24576\n\tds_read_b128 %7, %9 offset:26624\n\t"                   \
+      "s_waitcnt lgkmcnt(0)"                                                                       \
+      : "=&v"(fa[0]), "=&v"(fa[1]), "=&v"(fw[0]), "=&v"(fw[1]), "=&v"(fw[2]), "=&v"(fw[3]), "=&v"(fw[4]), \
+        "=&v"(fw[5])                                                                               \
+      : "v"(KSBASE_A), "v"(KSBASE_W));                                                             \
+  __builtin_amdgcn_sched_barrier(0)
+
+template <typename TO, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_n192_kernel(GemmParams p) {
+  using T = bf16;
+  constexpr int STG = (128 + 192) * 128;   // 40 KB per stage: A rows 0..127 then W rows 0..191
+  constexpr int NSTG = 4;                  // 160 KB: the whole LDS of a CU
+  __shared__ __attribute__((aligned(256))) char smem[NSTG * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+  const int tiles_n = p.N / 192;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (L / tiles_n) * 128, n0 = (L % tiles_n) * 192;
+  const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_nt);
+
+  // LDS-DMA roles: 40 pieces of 8 rows per stage (16 of A, 24 of W), 5 per wave
+  const int r8 = lane >> 3;
+  const T* src_row[5];
+  int src_chunk[5];
+  bool src_ok[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int q = wave * 5 + i, row = (q < 16 ? q : q - 16) * 8 + r8;
+    const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    src_chunk[i] = ((lane & 7) ^ (key << 1)) * 8;
+    if (q < 16) {
+      const int m = m0 + row;
+      src_ok[i] = m < p.M;
+      src_row[i] = A + (size_t)map_row(p.amap, src_ok[i] ? m : 0) * p.lda;
+    } else {
+      const int n = n0 + row;
+      src_ok[i] = n < p.N;
+      src_row[i] = W + (size_t)(src_ok[i] ? n : 0) * p.ldw;
+    }
+  }
+  auto issue = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int k = kt * 64 + src_chunk[i];
+      const T* src = (src_ok[i] && k < p.K) ? src_row[i] + k : reinterpret_cast<const T*>(zero);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + buf * STG + (wave * 5 + i) * 1024), 16, 0, 0);
+    }
+  };
+  // per-lane fragment addresses (LDS byte addresses): row*128 + ((ks*64 + fq*16) ^ key<<5); key from lane&15 only
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
+  uint32_t aoff[2], woff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int byte = (ks * 64 + fq * 16) ^ (keyl << 5);
+    aoff[ks] = lbase + (wm * 32 + fr) * 128 + byte;
+    woff[ks] = lbase + (wn * 96 + fr) * 128 + byte;
+  }
+
+  f32x4 acc[6][2];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const int KT = (p.K + 63) / 64;
+  // NSTG-deep ring: k-tiles kt+1 .. kt+NSTG-2 are in flight while kt is multiplied; ONE barrier per
+  // k-tile (a wave passes barrier kt+1 only after its reads of stage kt, so refilling that stage
+  // right after the barrier is safe).
+#pragma unroll
+  for (int i = 0; i < NSTG - 1; ++i)
+    if (i < KT) issue(i, i);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int rem = min(NSTG - 2, KT - 1 - kt);
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + NSTG - 1 < KT) issue(kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
+    const uint32_t bo = (kt % NSTG) * STG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4 fa[2], fw[6];
+      const uint32_t ka = aoff[ks] + bo, kw = woff[ks] + bo;
+      SITK_N192_READS(ka, kw);
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mma(fw[i], fa[j], acc[i][j]);
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+  // epilogue through a wave-private staging area (the k-tile stages are free now)
+  char* slot = smem + wave * 6656;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int mrow = m0 + wm * 32 + 16 * j;
+    f32x4 v1[6], v2[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int n = n0 + wn * 96 + 16 * i + 4 * fq, m = mrow + fr;
+      v1[i] = acc[i][j];
+      v2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m < p.M && n < p.N) epilogue_math<T, EPI>(p, m, n, v1[i], v2[i]);
+    }
+    staged_rows_store<TO, 96>(slot, v1, reinterpret_cast<TO*>(p.out), p, mrow, n0 + wn * 96, lane);
+    if constexpr (EPI == SITK_EPI_BIAS_GELU) staged_rows_store<T, 96>(slot, v2, reinterpret_cast<T*>(p.out2), p, mrow, n0 + wn * 96, lane);
+  }
+}
+
+template <typename TO, int EPI>
+static int launch_gemm_nt_n192(const GemmParams& p, hipStream_t s) {
+  const int grid = cdiv(p.M, 128) * (p.N / 192);
+  hipLaunchKernelGGL((gemm_nt_n192_kernel<TO, EPI>), dim3(grid), dim3(512), 0, s, p);
+  return check_launch("gemm_nt_n192");
+}
+
+template <typename TO, int EPI, int BN, int KT>
+static int launch_gemm_nt_wres_cfg(const GemmParams& p, hipStream_t s) {
+  constexpr int lds16 = KT * BN * 128 + 16 * wres_slot_bytes<TO, BN, KT, 1>();
+  const int tiles_n = cdiv(p.N, BN);
+  if constexpr (lds16 <= 160 * 1024) {
+    const int groups = std::max(1, std::min(256 / tiles_n, cdiv(cdiv(p.M, 16), 16)));
+    hipLaunchKernelGGL((gemm_nt_wres_kernel<TO, EPI, BN, KT, 16, 1>), dim3(groups * tiles_n), dim3(1024), 0, s, p, groups);
+  } else {
+    const int groups = std::max(1, std::min(256 / tiles_n, cdiv(cdiv(p.M, 32), 8)));
+    hipLaunchKernelGGL((gemm_nt_wres_kernel<TO, EPI, BN, KT, 8, 2>), dim3(groups * tiles_n), dim3(512), 0, s, p, groups);
+  }
+  return check_launch("gemm_nt_wres");
+}
+
 template <typename TO, int EPI>
 static int launch_gemm_nt_wres(const GemmParams& p, hipStream_t s) {
   const int KT = cdiv(p.K, 64);
-  const bool wide = p.N % 128 == 0;
-  const int tiles_n = cdiv(p.N, wide ? 128 : 64);
-  const int nstrips = cdiv(p.M, 32);
-  int groups = std::max(1, 256 / tiles_n);
-  groups = std::min(groups, cdiv(nstrips, 8));
-  const dim3 grid(groups * tiles_n), block(512);
-#define SITK_WRES(BN_, KT_) hipLaunchKernelGGL((gemm_nt_wres_kernel<TO, EPI, BN_, KT_>), grid, block, 0, s, p, groups)
-  if (wide) {
-    if (KT == 1) SITK_WRES(128, 1); else if (KT == 2) SITK_WRES(128, 2); else SITK_WRES(128, 3);
-  } else {
-    if (KT == 1) SITK_WRES(64, 1); else if (KT == 2) SITK_WRES(64, 2); else SITK_WRES(64, 3);
+  if (p.N % 128 == 0) {
+    if (KT == 1) return launch_gemm_nt_wres_cfg<TO, EPI, 128, 1>(p, s);
+    if (KT == 2) return launch_gemm_nt_wres_cfg<TO, EPI, 128, 2>(p, s);
+    return launch_gemm_nt_wres_cfg<TO, EPI, 128, 3>(p, s);
   }
-#undef SITK_WRES
-  return check_launch("gemm_nt_wres");
+  if (KT == 1) return launch_gemm_nt_wres_cfg<TO, EPI, 64, 1>(p, s);
+  if (KT == 2) return launch_gemm_nt_wres_cfg<TO, EPI, 64, 2>(p, s);
+  return launch_gemm_nt_wres_cfg<TO, EPI, 64, 3>(p, s);
 }
 
 template <typename T, typename TA, typename TO, int EPI>
@@ -385,6 +548,9 @@ static int launch_gemm_nt(const GemmParams& p, hipStream_t s) {
     if (p.K <= 192 && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.M >= 1024 && p.N % 8 == 0 &&
         (sizeof(TO) == 4 || p.ldo % 8 == 0))
       return launch_gemm_nt_wres<TO, EPI>(p, s);
+    if (p.K > 192 && p.N % 192 == 0 && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.M >= 1024 &&
+        (sizeof(TO) == 4 || p.ldo % 8 == 0))
+      return launch_gemm_nt_n192<TO, EPI>(p, s);
   }
   const bool wide = (p.N % 128 == 0) || p.N > 1024;
   if (wide) {
