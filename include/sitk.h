@@ -127,6 +127,13 @@ typedef struct {
 int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_t stream);
 /* Up to 4 independent weight gradients (the four Linears of one encoder layer) in ONE launch. */
 int sitk_gemm_wgrad_group(const sitk_wgrad_desc* d, int count, int dtype, sitk_stream_t stream);
+/* Same, with a caller-provided workspace: when every problem is bf16 with a dimension that is a multiple
+ * of 192 the large-tile kernel (128 x 192 tiles, partial tiles reduced through the workspace instead of
+ * float atomics) runs; otherwise, or if `ws` is NULL / too small, this is sitk_gemm_wgrad_group.
+ * sitk_gemm_wgrad_group_ws_bytes returns the workspace size that selects the large-tile path (0 = n/a). */
+size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int count, int dtype);
+int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int dtype, void* ws, size_t ws_bytes,
+                             sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps 1e-5, biased variance, affine): the PreNorm norms of the

@@ -74,6 +74,8 @@ struct Scratch {
   char *dxAc, *dxBc;
   float* ln_partials;
   size_t ln_partial_floats;
+  char* wgrad_ws;
+  size_t wgrad_ws_bytes;
 };
 
 struct Layout {
@@ -119,6 +121,15 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
   L.scratch.dxB = (float*)stake(R * D * 4);
   L.scratch.dxAc = stake(R * D * es);
   L.scratch.dxBc = stake(R * D * es);
+  {  // slab of the large-tile weight-gradient path (0 bytes when the shapes are not eligible)
+    sitk_wgrad_desc wg[4] = {};
+    const int dims[4][2] = {{(int)D, (int)M}, {(int)M, (int)D}, {(int)D, (int)I}, {3 * (int)I, (int)D}};
+    for (int i = 0; i < 4; ++i) {
+      wg[i].M = (int)R; wg[i].N = dims[i][0]; wg[i].K = dims[i][1]; wg[i].lddy = dims[i][0]; wg[i].ldx = dims[i][1];
+    }
+    L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg, 4, c.dtype);
+    L.scratch.wgrad_ws = stake(L.scratch.wgrad_ws_bytes);
+  }
   L.scratch.ln_partial_floats = sitk_layernorm_bwd_partial_floats((int64_t)R, (int)D);
   L.scratch.ln_partials = (float*)stake(L.scratch.ln_partial_floats * 4 * 2 * c.depth);   // one region per LayerNorm
   L.scratch_bytes = off;
@@ -281,7 +292,7 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
         wgrad_desc(R, D, I, S.dxBc, 0, a.o, G[l].wo, G[l].bo),
         wgrad_desc(R, 3 * I, D, S.dqkv, 0, a.h1, G[l].wqkv, nullptr),
     };
-    SITK_TRY(sitk_gemm_wgrad_group(wg, 4, dt, stream));
+    SITK_TRY(sitk_gemm_wgrad_group_ws(wg, 4, dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
     sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, S.dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
     SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
     float* part1 = S.ln_partials + (size_t)(2 * l) * S.ln_partial_floats;

@@ -1,0 +1,307 @@
+// sitk weight gradients, large-tile variant with a slab reduction (bf16, dims that are multiples of 192).
+//
+//   dW[n][k] += sum_m dY[m][n] X[m][k]        (and db[n] += sum_m dY[m][n])
+//
+// The 64x64-tile kernel of gemm.hip stages 32 flop per byte and is bound by L2 -> LDS traffic
+// (profiles/r01_pmc_wgrad_group.txt).  Here a workgroup owns a 128 x 192 output tile (77 flop/B):
+//   * the 128-column side ("P") and the 192-column side ("Q") are the two operands, whichever of
+//     dY / X has the dimension that is a multiple of 192 goes on the Q side (the tile is written
+//     back transposed when that is dY);
+//   * 4 waves = 2 token halves x 2 halves of the 128 side; a wave holds a 64 x 192 fp32 accumulator
+//     (48 MFMA tiles, 192 registers: one wave per SIMD owns the register file);
+//   * 64-token stages (2 + 3 panels of 64 rows x 128 B = 40 KB) move global -> LDS by LDS-DMA through
+//     a 4-deep ring (all 160 KB of the CU), three stages in flight, one raw barrier per stage;
+//     transposed fragments are read inside asm blocks (a compiler-visible LDS read would make hipcc
+//     drain the DMA ring with s_waitcnt vmcnt(0));
+//   * token-split partial tiles are written to a slab with plain stores and summed into dW by a
+//     second kernel: bitwise reproducible, and none of the 24 MB of partials goes through float
+//     atomics (1.3 TB/s chip-wide, MI355X_MICROARCH.md).
+#include <algorithm>
+
+#include "common.h"
+
+namespace sitk {
+
+constexpr int WB_MAX_PROBLEMS = 4;
+constexpr int WB_TILE_ELEMS = 128 * 192;
+struct WbProblem {
+  const bf16* P;   // 128-column side operand (M, ldp)
+  const bf16* Q;   // 192-column side operand (M, ldq)
+  int ldp, ldq, cp, cq;  // leading dims and total columns of each side
+  float* dW;
+  int lddw;
+  int swapped;     // 0: P = dY (rows n), Q = X (cols k); 1: P = X (cols k), Q = dY (rows n)
+  float* db;       // bias gradient of the dY side or null
+  int M, tiles_q, tiles, block_begin, splits, chunk;
+};
+struct WbGroup {
+  WbProblem p[WB_MAX_PROBLEMS];
+  int count;
+};
+
+__device__ u32x4 g_zero_page_wb[4];
+
+#define SITK_WB_TR2(dlo, dhi, areg, off, offhi) \
+  "ds_read_b64_tr_b16 " dlo ", " areg " offset:" #off "\n\tds_read_b64_tr_b16 " dhi ", " areg " offset:" #offhi "\n\t"
+
+__global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __restrict__ slab) {
+  constexpr int STG = 5 * 8192;  // panels: P0 P1 Q0 Q1 Q2, each 64 rows x 128 B
+  constexpr int NSTG = 4;
+  __shared__ __attribute__((aligned(256))) char smem[NSTG * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wave & 1, wh = wave >> 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < WB_MAX_PROBLEMS; ++i)
+    if (i < grp.count && bid >= grp.p[i].block_begin) pi = i;
+  const WbProblem P = grp.p[pi];
+  const int local = bid - P.block_begin;
+  const int split = local / P.tiles, tile = local % P.tiles;
+  const int p0 = (tile / P.tiles_q) * 128, q0 = (tile % P.tiles_q) * 192;
+  const int mbeg = split * P.chunk, mend = min(P.M, mbeg + P.chunk);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_wb);
+
+  // LDS-DMA: 40 pieces (8 rows x 128 B) per stage; wave w moves P pieces 4w..4w+3 and Q pieces 6w..6w+5
+  const int r8 = lane >> 3;
+  auto issue = [&](int mt, int stage) {
+    char* sb = smem + stage * STG;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const bool isP = i < 4;
+      const int q = isP ? wave * 4 + i : wave * 6 + (i - 4);
+      const int panel = q >> 3, row = (q & 7) * 8 + r8;
+      const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+      const int col = (isP ? p0 : q0) + panel * 64 + ((lane & 7) ^ (key << 1)) * 8;
+      const int m = mt + row;
+      const bool ok = m < mend && col < (isP ? P.cp : P.cq);
+      const bf16* src = ok ? (isP ? P.P + (size_t)m * P.ldp : P.Q + (size_t)m * P.ldq) + col : reinterpret_cast<const bf16*>(zero);
+      char* dst = sb + (isP ? 0 : 2 * 8192) + q * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  // transposed-read addresses: rows wt*32 + 8g + q (+4), column block i of a panel at 32*(i ^ key) + 8*(lane&3)
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int rowl = wt * 32 + 8 * (lane >> 4) + ((lane >> 2) & 3);
+  const int keyl = ((rowl >> 1) & 1) | (((rowl >> 3) & 1) << 1);
+  uint32_t toff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) toff[i] = lbase + rowl * 128 + 32 * (i ^ keyl) + 8 * (lane & 3);
+
+  f32x4 acc[4][12], accb[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 12; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias: sum of the dY-side columns, via one extra MFMA per dY block against a ones fragment
+  const bool biasP = P.db != nullptr && !P.swapped && q0 == 0;           // dY on the P side (4 blocks of this wave)
+  const bool biasQ = P.db != nullptr && P.swapped && p0 == 0 && wh == 0;  // dY on the Q side (12 blocks)
+  u32x4 ones;
+  {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)1.0f;
+    ones = __builtin_bit_cast(u32x4, o);
+  }
+
+  const int nstage = (mend - mbeg + 63) / 64;
+#pragma unroll
+  for (int i = 0; i < NSTG - 1; ++i)
+    if (i < nstage) issue(mbeg + i * 64, i);
+  for (int s = 0; s < nstage; ++s) {
+    const int rem = min(NSTG - 2, nstage - 1 - s);
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s + NSTG - 1 < nstage) issue(mbeg + (s + NSTG - 1) * 64, (s + NSTG - 1) % NSTG);
+    const uint32_t so = (s % NSTG) * STG;
+    const uint32_t b0 = toff[0] + so, b1 = toff[1] + so, b2 = toff[2] + so, b3 = toff[3] + so;
+    const uint32_t a0 = b0 + wh * 8192, a1 = b1 + wh * 8192, a2 = b2 + wh * 8192, a3 = b3 + wh * 8192;
+    u32x2 pl[4], ph[4], ql[12], qh[12];
+    asm volatile(
+        SITK_WB_TR2("%0", "%1", "%16", 0, 512) SITK_WB_TR2("%2", "%3", "%17", 0, 512)
+        SITK_WB_TR2("%4", "%5", "%18", 0, 512) SITK_WB_TR2("%6", "%7", "%19", 0, 512)
+        SITK_WB_TR2("%8", "%9", "%20", 16384, 16896) SITK_WB_TR2("%10", "%11", "%21", 16384, 16896)
+        SITK_WB_TR2("%12", "%13", "%22", 16384, 16896) SITK_WB_TR2("%14", "%15", "%23", 16384, 16896)
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(pl[0]), "=&v"(ph[0]), "=&v"(pl[1]), "=&v"(ph[1]), "=&v"(pl[2]), "=&v"(ph[2]), "=&v"(pl[3]), "=&v"(ph[3]),
+          "=&v"(ql[0]), "=&v"(qh[0]), "=&v"(ql[1]), "=&v"(qh[1]), "=&v"(ql[2]), "=&v"(qh[2]), "=&v"(ql[3]), "=&v"(qh[3])
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    asm volatile(
+        SITK_WB_TR2("%0", "%1", "%16", 24576, 25088) SITK_WB_TR2("%2", "%3", "%17", 24576, 25088)
+        SITK_WB_TR2("%4", "%5", "%18", 24576, 25088) SITK_WB_TR2("%6", "%7", "%19", 24576, 25088)
+        SITK_WB_TR2("%8", "%9", "%16", 32768, 33280) SITK_WB_TR2("%10", "%11", "%17", 32768, 33280)
+        SITK_WB_TR2("%12", "%13", "%18", 32768, 33280) SITK_WB_TR2("%14", "%15", "%19", 32768, 33280)
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(ql[4]), "=&v"(qh[4]), "=&v"(ql[5]), "=&v"(qh[5]), "=&v"(ql[6]), "=&v"(qh[6]), "=&v"(ql[7]), "=&v"(qh[7]),
+          "=&v"(ql[8]), "=&v"(qh[8]), "=&v"(ql[9]), "=&v"(qh[9]), "=&v"(ql[10]), "=&v"(qh[10]), "=&v"(ql[11]), "=&v"(qh[11])
+        : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 fp[4], fqv[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fp[i] = u32x4{pl[i][0], pl[i][1], ph[i][0], ph[i][1]};
+#pragma unroll
+    for (int j = 0; j < 12; ++j) fqv[j] = u32x4{ql[j][0], ql[j][1], qh[j][0], qh[j][1]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 12; ++j) acc[i][j] = Mma<bf16>::mma(fp[i], fqv[j], acc[i][j]);
+    if (biasP) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) accb[i] = Mma<bf16>::mma(fp[i], ones, accb[i]);
+    }
+    if (biasQ) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) accb[j] = Mma<bf16>::mma(ones, fqv[j], accb[j]);
+    }
+  }
+  __builtin_amdgcn_s_barrier();   // every wave is done with the ring: reuse it for the token-half reduction
+
+  // acc[i][j][jj] <-> P column (row of the tile) wh*64 + 16i + 4fq + jj, Q column 16j + fr
+  const int fr = lane & 15, fq = lane >> 4;
+  float* red = reinterpret_cast<float*>(smem) + wh * (64 * 192);
+  if (wt == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 12; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) red[(16 * i + 4 * fq + jj) * 192 + 16 * j + fr] = acc[i][j][jj];
+  }
+  __syncthreads();
+  if (wt == 0) {
+    float* out = slab + (size_t)bid * WB_TILE_ELEMS + wh * (64 * 192);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 12; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int e = (16 * i + 4 * fq + jj) * 192 + 16 * j + fr;
+          out[e] = acc[i][j][jj] + red[e];
+        }
+  }
+  if (biasP && fr == 0) {   // column sums of dY blocks on the P side: accb[i][jj] <-> n = p0 + wh*64 + 16i + 4fq + jj
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int n = p0 + wh * 64 + 16 * i + 4 * fq + jj;
+        if (n < P.cp) unsafeAtomicAdd(P.db + n, accb[i][jj]);
+      }
+  }
+  if (biasQ && fq == 0) {   // dY on the Q side: every row of the ones product holds the sums; row 0 = (fq 0, jj 0)
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int n = q0 + 16 * j + fr;
+      if (n < P.cq) unsafeAtomicAdd(P.db + n, accb[j][0]);
+    }
+  }
+}
+
+// dW (+)= sum over the splits of a tile's slabs, honouring the orientation; one thread per 4 Q columns
+__global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, const float* __restrict__ slab, int total_tiles) {
+  const int gt = blockIdx.y;  // global tile index over all problems
+  int pi = 0, tbase = 0;
+  bool found = false;
+#pragma unroll
+  for (int i = 0; i < WB_MAX_PROBLEMS; ++i) {
+    if (!found && i < grp.count) {
+      if (gt < tbase + grp.p[i].tiles) { pi = i; found = true; }
+      else tbase += grp.p[i].tiles;
+    }
+  }
+  const WbProblem P = grp.p[pi];
+  const int tile = gt - tbase;
+  const int p0 = (tile / P.tiles_q) * 128, q0 = (tile % P.tiles_q) * 192;
+  const int e4 = (blockIdx.x * 256 + threadIdx.x) * 4;   // element index within the 128 x 192 tile
+  if (e4 >= WB_TILE_ELEMS) return;
+  const int r = e4 / 192, c = e4 % 192;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sp = 0; sp < P.splits; ++sp)
+    s += *reinterpret_cast<const f32x4*>(slab + (size_t)(P.block_begin + sp * P.tiles + tile) * WB_TILE_ELEMS + e4);
+  const int pc = p0 + r;
+  if (pc >= P.cp) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int qc = q0 + c + e;
+    if (qc < P.cq) {
+      float* dst = P.swapped ? P.dW + (size_t)qc * P.lddw + pc : P.dW + (size_t)pc * P.lddw + qc;
+      *dst += s[e];
+    }
+  }
+}
+
+static bool wb_eligible(const sitk_wgrad_desc& d) {
+  const bool align = d.N % 8 == 0 && d.K % 8 == 0 && d.lddy % 8 == 0 && d.ldx % 8 == 0;
+  const bool plain = d.dymap.group == 0 && d.xmap.group == 0 && !d.dy_is_f32;
+  return align && plain && d.M >= 2048 && (d.K % 192 == 0 || d.N % 192 == 0);
+}
+
+static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks, int& tiles_total) {
+  tiles_total = 0;
+  for (int i = 0; i < count; ++i) {
+    WbProblem& p = g.p[i];
+    const bool normal = d[i].K % 192 == 0;   // Q side = X columns (k)
+    p.swapped = normal ? 0 : 1;
+    p.P = reinterpret_cast<const bf16*>(normal ? d[i].dY : d[i].X);
+    p.Q = reinterpret_cast<const bf16*>(normal ? d[i].X : d[i].dY);
+    p.ldp = normal ? d[i].lddy : d[i].ldx;
+    p.ldq = normal ? d[i].ldx : d[i].lddy;
+    p.cp = normal ? d[i].N : d[i].K;
+    p.cq = normal ? d[i].K : d[i].N;
+    p.dW = d[i].dW; p.lddw = d[i].lddw; p.db = d[i].db; p.M = d[i].M;
+    p.tiles_q = p.cq / 192;
+    p.tiles = cdiv(p.cp, 128) * p.tiles_q;
+    tiles_total += p.tiles;
+  }
+  g.count = count;
+  blocks = 0;
+  for (int i = 0; i < count; ++i) {
+    WbProblem& p = g.p[i];
+    int splits = std::max(1, 256 / tiles_total);
+    splits = std::min(splits, std::max(1, p.M / 256));
+    p.chunk = cdiv(cdiv(p.M, splits), 64) * 64;
+    p.splits = cdiv(p.M, p.chunk);
+    p.block_begin = blocks;
+    blocks += p.tiles * p.splits;
+  }
+  return SITK_OK;
+}
+
+}  // namespace sitk
+
+using namespace sitk;
+
+extern "C" size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int count, int dtype) {
+  if (!d || count < 1 || count > WB_MAX_PROBLEMS || dtype != SITK_BF16) return 0;
+  for (int i = 0; i < count; ++i)
+    if (!wb_eligible(d[i])) return 0;
+  WbGroup g;
+  int blocks, tiles;
+  wb_plan(d, count, g, blocks, tiles);
+  return (size_t)blocks * WB_TILE_ELEMS * sizeof(float);
+}
+
+extern "C" int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int dtype, void* ws, size_t ws_bytes,
+                                        sitk_stream_t stream) {
+  SITK_REQUIRE(d != nullptr && count >= 1 && count <= WB_MAX_PROBLEMS, "gemm_wgrad_group_ws: 1..%d problems", WB_MAX_PROBLEMS);
+  const size_t need = sitk_gemm_wgrad_group_ws_bytes(d, count, dtype);
+  if (need == 0 || ws == nullptr || ws_bytes < need) return sitk_gemm_wgrad_group(d, count, dtype, stream);  // generic tiles
+  for (int i = 0; i < count; ++i)
+    SITK_REQUIRE(d[i].dY && d[i].X && d[i].dW, "gemm_wgrad_group_ws: null operand in problem %d", i);
+  WbGroup g;
+  int blocks, tiles;
+  wb_plan(d, count, g, blocks, tiles);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(wgrad_big_kernel, dim3(blocks), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
+  SITK_LAUNCH_CHECK("wgrad_big");
+  hipLaunchKernelGGL(wgrad_big_reduce_kernel, dim3(WB_TILE_ELEMS / 4 / 256, tiles), dim3(256), 0, s, g,
+                     reinterpret_cast<const float*>(ws), tiles);
+  return check_launch("wgrad_big_reduce");
+}

@@ -111,8 +111,10 @@ def gemm_wgrad(dY, X, dW, dtype, db=None, M=None, N=None, K=None, dymap=None, xm
     return dW
 
 
-def gemm_wgrad_group(problems, dtype):
-    """problems: list (<= 4) of dicts(dY, X, dW, db=None): all weight gradients in ONE launch."""
+def gemm_wgrad_group(problems, dtype, workspace=None):
+    """problems: list (<= 4) of dicts(dY, X, dW, db=None): all weight gradients in ONE launch.
+    workspace: None (64x64 tiles + atomics), a uint8 tensor, or "auto" (allocate what the large-tile
+    slab path asks for)."""
     code = rt.dtype_code(dtype)
     arr = (rt.WgradDesc * len(problems))()
     for d, p in zip(arr, problems):
@@ -122,7 +124,14 @@ def gemm_wgrad_group(problems, dtype):
         d.dY, d.lddy, d.dy_is_f32, d.dymap = dY.data_ptr(), dY.stride(0), int(dY.dtype == torch.float32), _rowmap(None)
         d.X, d.ldx, d.xmap = X.data_ptr(), X.stride(0), _rowmap(None)
         d.dW, d.lddw, d.db = dW.data_ptr(), dW.stride(0), rt.ptr(db)
-    rt.check(rt.lib.sitk_gemm_wgrad_group(arr, len(problems), code, rt.stream_ptr()))
+    if workspace == "auto":
+        nbytes = rt.lib.sitk_gemm_wgrad_group_ws_bytes(arr, len(problems), code)
+        workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=problems[0]["dW"].device)
+    if workspace is None:
+        rt.check(rt.lib.sitk_gemm_wgrad_group(arr, len(problems), code, rt.stream_ptr()))
+    else:
+        rt.check(rt.lib.sitk_gemm_wgrad_group_ws(arr, len(problems), code, workspace.data_ptr(), workspace.numel(),
+                                                 rt.stream_ptr()))
 
 
 # ---- LayerNorm -------------------------------------------------------------------------------------

@@ -65,6 +65,8 @@ _SIGS = {
     "sitk_gemm_nt": (C.c_int, [C.POINTER(GemmDesc), _I, _P]),
     "sitk_gemm_wgrad": (C.c_int, [C.POINTER(WgradDesc), _I, _P]),
     "sitk_gemm_wgrad_group": (C.c_int, [C.POINTER(WgradDesc), _I, _I, _P]),
+    "sitk_gemm_wgrad_group_ws_bytes": (_Z, [C.POINTER(WgradDesc), _I, _I]),
+    "sitk_gemm_wgrad_group_ws": (C.c_int, [C.POINTER(WgradDesc), _I, _I, _P, _Z, _P]),
     "sitk_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "sitk_layernorm_bwd_partial_floats": (_Z, [_L, _I]),
     "sitk_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),

@@ -229,6 +229,27 @@ def test_layernorm_fwd_bwd(ops, dtype, D):
     assert rel(dgam2, gr.grad) < 2e-5 and rel(dbet2, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("D,M,H", [(192, 768, 3), (384, 1536, 6)])
+def test_wgrad_large_tile_slab_path_integer_exact(ops, D, M, H):
+    """bf16 128x192-tile kernel + slab reduction (sitk_gemm_wgrad_group_ws): both orientations, partial
+    tiles (192 = 128 + 64), bias on either side, accumulate semantics, token tail (R % 64 != 0)."""
+    R, I = 321 * 8 + 5, H * 64
+    probs, refs = [], []
+    for i, (n, k, bias) in enumerate([(D, M, True), (M, D, True), (D, I, True), (3 * I, D, False)]):
+        dY, X = ints(f"wgb/dY{i}", (R, n), -2, 3).to(torch.bfloat16), ints(f"wgb/X{i}", (R, k), -2, 3).to(torch.bfloat16)
+        X[:, 0] += 1.0
+        dW = torch.ones((n, k), device=DEV)                  # pre-existing gradient: must be accumulated into
+        db = torch.zeros((n,), device=DEV) if bias else None
+        probs.append(dict(dY=dY, X=X, dW=dW, db=db))
+        refs.append((dY.float().t() @ X.float() + 1.0, dY.float().sum(0)))
+    from sitk import runtime as rt
+    ops.gemm_wgrad_group(probs, "bf16", workspace="auto")
+    for p, (rw, rb) in zip(probs, refs):
+        assert torch.equal(p["dW"], rw)
+        if p["db"] is not None:
+            assert torch.equal(p["db"], rb)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_group_matches_single_launches(ops, dtype):
     td = tdt(dtype)
