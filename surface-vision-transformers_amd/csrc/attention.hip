@@ -9,6 +9,8 @@
 // the accumulator is reused in registers as the next product's B operand, the LDS tile supplies the
 // A operand through ds_read_b64_tr_b16 (bf16) or ds_read_b32 (f32), so the query (forward, dQ) or
 // key (dK/dV) index stays on lane&15 through the whole kernel and per-row softmax state is per-lane.
+#include <type_traits>
+
 #include "common.h"
 
 namespace sitk {
@@ -354,6 +356,53 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
 constexpr int RES_MAX_N = 384;
 __device__ u32x4 g_zero_page_attn[4];
 
+// Per-lane byte offsets into a 64-row bf16 tile, computed ONCE per kernel: with them every fragment
+// read is `tile + lane offset + compile-time immediate` (the XOR swizzle of lds_off() depends only on
+// lane bits here; recomputing it per read cost more VALU than the softmax itself).
+struct LaneOffs {
+  int row[2];  // row-read (ds_read_b128) offset of k-step ks for row (lane&15):  + t * 2048 per 16-row block
+  int tr[4];   // transposed-read offset of column block dt for row 4*(lane>>4) + ((lane>>2)&3): + s2*4096, + 2048 (second half)
+};
+SITK_DEV LaneOffs lane_offs_bf16(int lane) {
+  LaneOffs o;
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) o.row[ks] = lds_off(fr, ks * 64 + fq * 16);
+  const int r = 4 * fq + ((lane >> 2) & 3);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o.tr[dt] = lds_off(r, (16 * dt + 4 * (lane & 3)) * 2);
+  return o;
+}
+SITK_DEV void row_mma_o(f32x4 (&s)[4], const char* tile, const u32x4 (&frag)[2], const LaneOffs& o) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      s[t] = Mma<bf16>::mma(*reinterpret_cast<const u32x4*>(tile + o.row[ks] + t * 2048), frag[ks], s[t]);
+}
+SITK_DEV void tr_mma_o(f32x4 (&acc)[4], const f32x4 (&p)[4], const char* tile, const LaneOffs& o) {
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    bf16x8 pb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pb[e] = (bf16)p[2 * s2][e]; pb[e + 4] = (bf16)p[2 * s2 + 1][e]; }
+    const u32x4 pf = __builtin_bit_cast(u32x4, pb);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(tile + o.tr[dt] + s2 * 4096));
+      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(tile + o.tr[dt] + s2 * 4096 + 2048));
+      u32x4 vf;
+      vf[0] = __builtin_bit_cast(u32x2, lo)[0];
+      vf[1] = __builtin_bit_cast(u32x2, lo)[1];
+      vf[2] = __builtin_bit_cast(u32x2, hi)[0];
+      vf[3] = __builtin_bit_cast(u32x2, hi)[1];
+      acc[dt] = Mma<bf16>::mma(vf, pf, acc[dt]);
+    }
+  }
+}
+
 // rows [0, ntiles*64) x 64 bf16 columns of `src` (leading dim ld) -> LDS tiles [t][64][128 B]; rows >= nrows are zero
 SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, int nrows, int ntiles, int wave, int lane) {
   const char* zero = reinterpret_cast<const char*>(g_zero_page_attn);
@@ -383,6 +432,7 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const bf16* __restric
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
+  const LaneOffs lo = lane_offs_bf16(lane);
   for (int qt = wave; qt * 16 < N; qt += 8) {
     const int q = qt * 16 + fr, qc = min(q, N - 1);
     u32x4 qf[2];
@@ -393,18 +443,20 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const bf16* __restric
     f32x4 oacc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nkt; ++t) {
+    const int nfull = N >> 6;   // key tiles without padding: no masking instructions in their body
+    auto kv_tile = [&](int t, auto masked) {
       f32x4 s[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      row_mma<T>(s, sK + t * 8192, qf, lane);
-      const bool tail = (t + 1) * 64 > N;
+      row_mma_o(s, sK + t * 8192, qf, lo);
       float mx = -1e30f;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          if (tail && t * 64 + 16 * i + 4 * fq + jj >= N) s[i][jj] = -INFINITY;
+          if constexpr (decltype(masked)::value) {
+            if (t * 64 + 16 * i + 4 * fq + jj >= N) s[i][jj] = -INFINITY;
+          }
           mx = fmaxf(mx, s[i][jj]);
         }
       mx = xor_max4(mx) * c;                       // c > 0: max commutes with the scale
@@ -423,8 +475,10 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const bf16* __restric
       m = mn;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
-      TrMma<T>::run(oacc, s, sV + t * 8192, lane);
-    }
+      tr_mma_o(oacc, s, sV + t * 8192, lo);
+    };
+    for (int t = 0; t < nfull; ++t) kv_tile(t, std::false_type{});
+    if (nfull < nkt) kv_tile(nfull, std::true_type{});
     const float lt = xor_sum4(l);
     const float inv = 1.0f / lt;
     if (q < N) {
@@ -454,6 +508,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const bf16* __rest
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
+  const LaneOffs lo = lane_offs_bf16(lane);
   for (int qt = wave; qt * 16 < N; qt += 8) {
     const int q = qt * 16 + fr, qc = min(q, N - 1);
     u32x4 qf[2], dof[2];
@@ -475,23 +530,27 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const bf16* __rest
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nkt; ++t) {
+    const int nfull = N >> 6;
+    auto kv_tile = [&](int t, auto masked) {
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      row_mma<T>(s, sK + t * 8192, qf, lane);
-      row_mma<T>(dp, sV + t * 8192, dof, lane);
-      const bool tail = (t + 1) * 64 > N;
+      row_mma_o(s, sK + t * 8192, qf, lo);
+      row_mma_o(dp, sV + t * 8192, dof, lo);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           float pv = fast_exp2(fmaf(s[i][jj], c, -Lq));
-          if (tail && t * 64 + 16 * i + 4 * fq + jj >= N) pv = 0.f;
+          if constexpr (decltype(masked)::value) {
+            if (t * 64 + 16 * i + 4 * fq + jj >= N) pv = 0.f;
+          }
           s[i][jj] = pv * (dp[i][jj] - dl) * scale;
         }
-      TrMma<T>::run(dq, s, sK + t * 8192, lane);
-    }
+      tr_mma_o(dq, s, sK + t * 8192, lo);
+    };
+    for (int t = 0; t < nfull; ++t) kv_tile(t, std::false_type{});
+    if (nfull < nkt) kv_tile(nfull, std::true_type{});
     if (q < N) {
       T* row = dqkv + ((size_t)b * N + q) * ld + h * 64;
 #pragma unroll
@@ -524,6 +583,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const bf16* __res
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
+  const LaneOffs lo = lane_offs_bf16(lane);
   for (int kt = wave; kt * 16 < N; kt += 8) {
     const int key = kt * 16 + fr, kc = min(key, N - 1);
     u32x4 kf[2], vf[2];
@@ -540,8 +600,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const bf16* __res
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      row_mma<T>(s, sQ + t * 8192, kf, lane);
-      row_mma<T>(dp, sDO + t * 8192, vf, lane);
+      row_mma_o(s, sQ + t * 8192, kf, lo);
+      row_mma_o(dp, sDO + t * 8192, vf, lo);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f32x4 Lr = *reinterpret_cast<const f32x4*>(sL + t * 64 + 16 * i + 4 * fq);
@@ -553,8 +613,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const bf16* __res
           dp[i][jj] = pv * (dp[i][jj] - Dr[jj]) * scale;
         }
       }
-      TrMma<T>::run(dv, s, sDO + t * 8192, lane);
-      TrMma<T>::run(dk, dp, sQ + t * 8192, lane);
+      tr_mma_o(dv, s, sDO + t * 8192, lo);
+      tr_mma_o(dk, dp, sQ + t * 8192, lo);
     }
     if (key < N) {
       T* row = dqkv + ((size_t)b * N + key) * ld + h * 64;

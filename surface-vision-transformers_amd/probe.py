@@ -1,11 +1,12 @@
 """Per-kernel timing of the hot path at the live workload's shapes (bench.py's `roofline` object).
 
-Every kernel family of one encoder layer is launched `reps` times back to back on torch's current
-stream between two HIP events (the same stream the engine launches on), on buffers of exactly the
-shapes the engine uses.  The family with the largest (average duration x launches per step) is the
-dominant kernel; its achieved rate = algorithmic FLOPs (or bytes) per launch / average duration.
-The rocprofv3 --kernel-trace --stats summary of the same bench command (profiles/) lists the same
-kernels by name; their average durations must agree with these.
+Every kernel family of one encoder layer is launched exactly as csrc/encoder.hip launches it (same
+entry point, operand dtypes, epilogue, workspace) `reps` times inside a hipGraph, and the replay is
+timed between two HIP events on the replay stream: no host launch gap is included.  The family with
+the largest (average duration x launches per step) is the dominant kernel; its achieved rate =
+algorithmic FLOPs (or bytes) per launch / average duration.  The rocprofv3 --kernel-trace --stats
+summary of the same bench command (profiles/) lists the same kernels by name; an entry that covers two
+kernels (e.g. the weight-gradient kernel and its slab reduction) must equal the sum of their averages.
 """
 import torch
 
@@ -33,7 +34,7 @@ def _time(fn, reps):
 
 
 def layer_kernels(eng):
-    """[(name, fn, flops, algorithmic bytes, launches per step)] for one encoder layer."""
+    """[(name, rocprof kernel names, fn, flops, algorithmic bytes, launches per step)] for one layer."""
     B, N, D, dt = eng.B, eng.N, eng.D, eng.dtype
     tr = eng.sit.transformer
     H, M = tr.heads, tr.mlp_dim
@@ -45,53 +46,68 @@ def layer_kernels(eng):
     rn = lambda *s, dtype=td: (torch.randn(*s, device=dev, generator=g) * 0.5).to(dtype)  # noqa: E731
     f32 = torch.float32
     h, qkv, o, u, gg = rn(R, D), rn(R, 3 * I), rn(R, I), rn(R, M), rn(R, M)
-    x32, dx32 = rn(R, D, dtype=f32), rn(R, D, dtype=f32)
+    x32, dx32, dxc = rn(R, D, dtype=f32), rn(R, D, dtype=f32), rn(R, D)
     wqkv, wqkv_t = rn(3 * I, D), rn(D, 3 * I)
     wo, wo_t = rn(D, I), rn(I, D)
     w1, w1_t, w2, w2_t = rn(M, D), rn(D, M), rn(D, M), rn(M, D)
     bD, bM = rn(D, dtype=f32), rn(M, dtype=f32)
     gam = rn(D, dtype=f32)
     out_qkv, out_o = torch.empty_like(qkv), torch.empty_like(o)
-    out_x = torch.empty_like(x32)
+    out_x, out_xc = torch.empty_like(x32), torch.empty_like(h)
     out_u, out_g, out_h = torch.empty_like(u), torch.empty_like(u), torch.empty_like(h)
     dW = {k: torch.zeros(s, dtype=f32, device=dev) for k, s in
           dict(qkv=(3 * I, D), o=(D, I), w1=(M, D), w2=(D, M)).items()}
-    dbD, dbM = torch.zeros(D, device=dev), torch.zeros(M, device=dev)
+    dbD, dbD2, dbM = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(M, device=dev)
     o_att, lse = ops.attention_fwd(qkv, B, N, H, 0.125, dt)
     mean, rstd = torch.zeros(R, device=dev), torch.ones(R, device=dev)
+    part = torch.empty(ops.layernorm_bwd_partial_floats(R, D), device=dev)
+    probs = [dict(dY=dxc, X=gg, dW=dW["w2"], db=dbD), dict(dY=u, X=h, dW=dW["w1"], db=dbM),
+             dict(dY=dxc, X=o, dW=dW["o"], db=dbD2), dict(dY=qkv, X=h, dW=dW["qkv"])]
+    nbytes = ops.rt.lib.sitk_gemm_wgrad_group_ws_bytes(*_desc_array(probs), ops.rt.dtype_code(dt))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     att = 4.0 * B * H * N * N * 64
-    ks = [
-        ("layernorm_fwd", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), 2 * L),
-        ("gemm_nt qkv (STORE)", lambda: ops.gemm_nt(h, wqkv, out_qkv, dt), 2.0 * R * 3 * I * D, R * (D + 3 * I) * es, L),
-        ("attn_fwd_kernel", lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt), att, R * 4 * I * es, L),
-        ("gemm_nt proj (BIAS_RES)", lambda: ops.gemm_nt(o, wo, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32),
-         2.0 * R * D * I, R * (I * es + 8 * D), L),
-        ("gemm_nt fc1 (BIAS_GELU)", lambda: ops.gemm_nt(h, w1, out_u, dt, epilogue=ops.EPI_BIAS_GELU, bias=bM, out2=out_g),
-         2.0 * R * M * D, R * (D + 2 * M) * es, L),
-        ("gemm_nt fc2 (BIAS_RES)", lambda: ops.gemm_nt(gg, w2, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32),
-         2.0 * R * D * M, R * (M * es + 8 * D), L),
-        ("wgrad w2", lambda: ops.gemm_wgrad(dx32, gg, dW["w2"], dt, db=dbD), 2.0 * R * D * M, R * (4 * D + M * es), L),
-        ("gemm_nt dfc2 (DGELU)", lambda: ops.gemm_nt(dx32, w2_t, out_u, dt, epilogue=ops.EPI_DGELU, aux=u),
-         2.0 * R * D * M, R * (4 * D + 2 * M * es), L),
-        ("wgrad w1", lambda: ops.gemm_wgrad(u, h, dW["w1"], dt, db=dbM), 2.0 * R * D * M, R * (M + D) * es, L),
-        ("gemm_nt dfc1 (STORE)", lambda: ops.gemm_nt(u, w1_t, out_h, dt), 2.0 * R * D * M, R * (M + D) * es, L),
-        ("layernorm_bwd", lambda: ops.layernorm_bwd(h, x32, mean, rstd, gam, dx32, dbD, dbD, dt, dx=out_x), 0,
-         R * D * (es + 12), 2 * L),
-        ("wgrad wo", lambda: ops.gemm_wgrad(dx32, o, dW["o"], dt, db=dbD), 2.0 * R * D * I, R * (4 * D + I * es), L),
-        ("gemm_nt dproj (STORE)", lambda: ops.gemm_nt(dx32, wo_t, out_o, dt), 2.0 * R * D * I, R * (4 * D + I * es), L),
-        ("attention_bwd (dq + dkv kernels)", lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt),
-         2.5 * att, R * 8 * I * es, L),
-        ("wgrad wqkv", lambda: ops.gemm_wgrad(qkv, h, dW["qkv"], dt), 2.0 * R * 3 * I * D, R * (3 * I + D) * es, L),
-        ("gemm_nt dqkv (STORE)", lambda: ops.gemm_nt(qkv, wqkv_t, out_h, dt), 2.0 * R * 3 * I * D, R * (3 * I + D) * es, L),
+    wg_flops = 2.0 * R * (D * M * 2 + D * I + 3 * I * D)
+    return [
+        ("layernorm_fwd", "layernorm_fwd_kernel", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), 2 * L),
+        ("to_qkv", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(h, wqkv, out_qkv, dt), 2.0 * R * 3 * I * D, R * (D + 3 * I) * es, L),
+        ("attention forward", "attn_fwd_res_kernel", lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt), att, R * 4 * I * es, L),
+        ("to_out + residual", "gemm_nt_wres_kernel",
+         lambda: ops.gemm_nt(o, wo, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * I, R * (I * es + 8 * D), L),
+        ("net.0 + GELU", "gemm_nt_wres_kernel",
+         lambda: ops.gemm_nt(h, w1, out_u, dt, epilogue=ops.EPI_BIAS_GELU, bias=bM, out2=out_g), 2.0 * R * M * D, R * (D + 2 * M) * es, L),
+        ("net.3 + residual", "gemm_nt_n192_kernel",
+         lambda: ops.gemm_nt(gg, w2, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * M, R * (M * es + 8 * D), L),
+        ("d net.3 (x GELU')", "gemm_nt_wres_kernel",
+         lambda: ops.gemm_nt(dxc, w2_t, out_u, dt, epilogue=ops.EPI_DGELU, aux=u), 2.0 * R * D * M, R * (D + 2 * M) * es, L),
+        ("d net.0", "gemm_nt_n192_kernel", lambda: ops.gemm_nt(u, w1_t, out_h, dt), 2.0 * R * D * M, R * (M + D) * es, L),
+        ("layernorm_bwd", "layernorm_bwd_kernel",
+         lambda: ops.layernorm_bwd(h, x32, mean, rstd, gam, dx32, dbD, dbD2, dt, dx=out_x, dx_c=out_xc, partials=part),
+         0, R * D * (2 * es + 12), 2 * L),
+        ("d to_out", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(dxc, wo_t, out_o, dt), 2.0 * R * D * I, R * (D + I) * es, L),
+        ("attention backward", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
+         lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt), 2.5 * att, R * 8 * I * es, L),
+        ("weight gradients of the layer", "wgrad_big_kernel + wgrad_big_reduce_kernel",
+         lambda: ops.gemm_wgrad_group(probs, dt, workspace=ws), wg_flops, R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L),
+        ("d to_qkv", "gemm_nt_n192_kernel", lambda: ops.gemm_nt(qkv, wqkv_t, out_h, dt), 2.0 * R * 3 * I * D, R * (3 * I + D) * es, L),
     ]
-    return ks
+
+
+def _desc_array(problems):
+    from . import runtime as rt
+    arr = (rt.WgradDesc * len(problems))()
+    for d, p in zip(arr, problems):
+        dY, X, dW = p["dY"], p["X"], p["dW"]
+        d.M, d.N, d.K = dY.shape[0], dW.shape[0], dW.shape[1]
+        d.lddy, d.ldx, d.lddw = dY.stride(0), X.stride(0), dW.stride(0)
+        d.dy_is_f32 = int(dY.dtype == torch.float32)
+    return arr, len(problems)
 
 
 def dominant_kernel_roofline(eng, peak_tflops, peak_gbs, reps=20):
     rows = []
-    for name, fn, flops, nbytes, launches in layer_kernels(eng):
+    for name, kernels, fn, flops, nbytes, launches in layer_kernels(eng):
         t = _time(fn, reps)
-        rows.append(dict(kernel=name, us=round(t * 1e6, 2), launches_per_step=launches,
+        rows.append(dict(op=name, kernels=kernels, us=round(t * 1e6, 2), launches_per_step=launches,
                          tflops=round(flops / t / 1e12, 1), gbs=round(nbytes / t / 1e9, 1),
                          step_share_us=round(t * 1e6 * launches, 1)))
     dom = max(rows, key=lambda r: r["step_share_us"])
@@ -99,7 +115,7 @@ def dominant_kernel_roofline(eng, peak_tflops, peak_gbs, reps=20):
     mfma_bound = dom["tflops"] > 0
     ach = dom["tflops"] if mfma_bound else dom["gbs"]
     peak = peak_tflops if mfma_bound else peak_gbs
-    return {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "achieved": ach, "peak": peak,
-            "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
+    return {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernels"], "op": dom["op"], "achieved": ach,
+            "peak": peak, "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
             "avg_us": dom["us"], "launches_per_step": dom["launches_per_step"],
             "encoder_kernel_sum_us": round(total, 1), "kernels": rows}
