@@ -56,6 +56,14 @@ int sitk_dtype_size(int dtype);
 int sitk_gather_tokens(const float* x_bvc, const uint16_t* table_pv, void* tokens, int B, int n_vertices,
                        int C, int P, int V, int ld, int dtype, sitk_stream_t stream);
 
+/* Same with the reference's per-channel normalisation fused in front of the gather
+ * (tools/preprocessing.py:72: (data - means) / stds; mean, stdv: (C) fp32 device arrays, a true fp32
+ * division) -- the device-resident input pipeline of SURVEY 8(f).2: raw surfaces stay in HBM and only
+ * the table indexes them every step.                                                             */
+int sitk_gather_tokens_norm(const float* x_bvc, const uint16_t* table_pv, const float* mean, const float* stdv,
+                            void* tokens, int B, int n_vertices, int C, int P, int V, int ld, int dtype,
+                            sitk_stream_t stream);
+
 /* Drop-in layout of the reference: x_bcpv (B, C, P, V) fp32 (models/sit.py:47-49) -> tokens as above. */
 int sitk_patchify(const float* x_bcpv, void* tokens, int B, int C, int P, int V, int ld, int dtype,
                   sitk_stream_t stream);

@@ -106,13 +106,33 @@ struct TrMma<float> {
 };
 
 SITK_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-SITK_DEV float xor_max4(float v) {  // reduce over the 4 lanes sharing lane&15
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
+// Reductions over the 4 lanes that share lane&15 (lanes l, l^16, l^32, l^48) with the gfx950 half/row
+// swaps instead of ds_bpermute: v_permlane16_swap(v, v) leaves {row0,row0,row2,row2} / {row1,row1,row3,row3},
+// v_permlane32_swap(v, v) leaves {lo,lo} / {hi,hi}; combining the two results pairs every lane with its
+// xor-16 / xor-32 partner.  Pure VALU: no LDS round trip on the softmax critical path.
+// Written as inline asm: with hipcc 7.2 the __builtin_amdgcn_permlane{16,32}_swap forms were folded
+// incorrectly once both inputs carry the same value (checked on hardware: 200/256 lanes wrong in a
+// 4-iteration loop, while the asm form below is exact).  The instruction modifies BOTH registers in
+// place; s_nop 1 covers the VALU-write -> permlane-read hazard on either side.
+SITK_DEV void permlane16_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+SITK_DEV void permlane32_swap(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+SITK_DEV float xor_max4(float v) {
+  float a = v, b = v;
+  permlane16_swap(a, b);
+  a = b = fmaxf(a, b);
+  permlane32_swap(a, b);
+  return fmaxf(a, b);
 }
 SITK_DEV float xor_sum4(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
+  float a = v, b = v;
+  permlane16_swap(a, b);
+  a = b = a + b;
+  permlane32_swap(a, b);
+  return a + b;
 }
 
 // 1-D grid, XCD-aware: the ceil(N/64) blocks of one (batch, head) are consecutive logical ids, so

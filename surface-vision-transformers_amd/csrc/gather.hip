@@ -14,8 +14,14 @@ namespace sitk {
 // is 655 KB, so the 1.2x re-reads of shared edge/corner vertices are served by L2.
 template <typename T>
 __global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restrict__ x, const uint16_t* __restrict__ table,
-                                                            T* __restrict__ tokens, int64_t rows, int n_vertices, int P, int V, int ld) {
+                                                            T* __restrict__ tokens, int64_t rows, int n_vertices, int P, int V, int ld,
+                                                            const float* __restrict__ mean, const float* __restrict__ stdv) {
   const int slots = ld >> 2;  // 4-element slots per token row, the first V carry data, the rest zero pad
+  // optional per-channel normalisation (x - mean[c]) / std[c]  (tools/preprocessing.py:72); a true division
+  // so that the result is bit-identical to the reference's numpy expression evaluated in fp32
+  const bool norm = mean != nullptr;
+  const f32x4 mu = norm ? load4(mean) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 sd = norm ? load4(stdv) : f32x4{1.f, 1.f, 1.f, 1.f};
   for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {  // row = b * P + p
     const int p = (int)(row % P);
     const int64_t b = row / P;
@@ -24,6 +30,10 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restr
       if (v < V) {
         const int vid = table[(size_t)p * V + v];
         val = *reinterpret_cast<const f32x4*>(x + ((size_t)b * n_vertices + vid) * 4);
+        if (norm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] = (val[e] - mu[e]) / sd[e];
+        }
       }
       store4(tokens + (size_t)row * ld + 4 * v, val);
     }
@@ -91,10 +101,12 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 }
 
 template <typename T>
-static int run_gather(const float* x, const uint16_t* table, void* tokens, int B, int nv, int P, int V, int ld, hipStream_t s) {
+static int run_gather(const float* x, const uint16_t* table, void* tokens, int B, int nv, int P, int V, int ld,
+                      const float* mean, const float* stdv, hipStream_t s) {
   const int64_t rows = (int64_t)B * P;
   dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
-  hipLaunchKernelGGL((gather_tokens_kernel<T>), grid, dim3(256), 0, s, x, table, reinterpret_cast<T*>(tokens), rows, nv, P, V, ld);
+  hipLaunchKernelGGL((gather_tokens_kernel<T>), grid, dim3(256), 0, s, x, table, reinterpret_cast<T*>(tokens), rows, nv, P, V, ld,
+                     mean, stdv);
   return check_launch("gather_tokens");
 }
 
@@ -136,14 +148,21 @@ static int run_stage_weight(const float* w, int rows, int cols, void* wc, int ld
 
 extern "C" int sitk_gather_tokens(const float* x_bvc, const uint16_t* table_pv, void* tokens, int B, int n_vertices,
                                   int C, int P, int V, int ld, int dtype, sitk_stream_t stream) {
+  return sitk_gather_tokens_norm(x_bvc, table_pv, nullptr, nullptr, tokens, B, n_vertices, C, P, V, ld, dtype, stream);
+}
+
+extern "C" int sitk_gather_tokens_norm(const float* x_bvc, const uint16_t* table_pv, const float* mean, const float* stdv,
+                                       void* tokens, int B, int n_vertices, int C, int P, int V, int ld, int dtype,
+                                       sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(x_bvc && table_pv && tokens, "gather_tokens: null pointer");
+  SITK_REQUIRE((mean == nullptr) == (stdv == nullptr), "gather_tokens_norm: mean and std go together");
   SITK_REQUIRE(C == 4, "gather_tokens: channels-last gather is specialised for num_channels == 4 (got %d); use patchify", C);
   SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "gather_tokens: bad shape");
   SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "gather_tokens: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return run_gather<bf16>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, s);
-  if (dtype == SITK_F32) return run_gather<float>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, s);
+  if (dtype == SITK_BF16) return run_gather<bf16>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
+  if (dtype == SITK_F32) return run_gather<float>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
   set_error("gather_tokens: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }

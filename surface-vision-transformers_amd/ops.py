@@ -21,8 +21,19 @@ def _rowmap(rm):
 
 
 # ---- gather / layout -------------------------------------------------------------------------------
-def gather_tokens(x_bvc, table_pv, dtype, ld=None):
-    """(B, 40962, 4) fp32 + (P, V) uint16 table -> (B*P, ld) tokens of `dtype` (zero padded)."""
+def gather_tokens(x_bvc, table_pv, dtype, ld=None, mean=None, std=None):
+    """(B, 40962, 4) fp32 + (P, V) uint16 table -> (B*P, ld) tokens of `dtype` (zero padded).
+    mean/std: optional (C,) fp32 device tensors -> (x - mean) / std fused in front of the gather."""
+    if mean is not None:
+        rt.require_cuda(x_bvc, table_pv, mean, std)
+        B, nv, Cc = x_bvc.shape
+        P, V = table_pv.shape
+        code = rt.dtype_code(dtype)
+        ld = ld or pad64(V * Cc)
+        out = torch.empty((B * P, ld), dtype=rt.torch_dtype(code), device=x_bvc.device)
+        rt.check(rt.lib.sitk_gather_tokens_norm(x_bvc.data_ptr(), table_pv.data_ptr(), mean.data_ptr(), std.data_ptr(),
+                                                out.data_ptr(), B, nv, Cc, P, V, ld, code, rt.stream_ptr()))
+        return out
     rt.require_cuda(x_bvc, table_pv)
     B, nv, Cc = x_bvc.shape
     P, V = table_pv.shape

@@ -59,6 +59,7 @@ _SIGS = {
     "sitk_last_error": (C.c_char_p, []),
     "sitk_dtype_size": (C.c_int, [_I]),
     "sitk_gather_tokens": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sitk_gather_tokens_norm": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_patchify": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_cast_rows": (C.c_int, [_P, _I, _P, _I, _L, _I, _I, _P]),
     "sitk_stage_weight": (C.c_int, [_P, _I, _I, _P, _I, _P, _I, _I, _P]),

@@ -65,6 +65,20 @@ def test_gather_tokens_bit_exact(ops, dtype, k):
     assert float(out[:, K:].float().abs().max()) == 0.0     # zero padding
 
 
+def test_gather_with_fused_normalisation_bit_exact(ops):
+    """(x - means) / stds of tools/preprocessing.py:72 fused in front of the gather: bit-identical to the
+    numpy expression evaluated in fp32 followed by the reference gather."""
+    from sitk import tables
+    t = tables.load_table(320, 153)
+    x = detgen.normal("gn/x", (2, 40962, 4), mean=3.0, std=2.0, seed=1)
+    mean = np.array([2.9, -0.1, 3.4, 0.05], np.float32)       # per-channel statistics like labels/dHCP/*/means.npy
+    std = np.array([1.9, 0.7, 2.2, 0.11], np.float32)
+    ref = sit_oracle.gather_tokens(((x - mean) / std).astype(np.float32), t)
+    out = ops.gather_tokens(torch.from_numpy(x).to(DEV), tables.table_tensor(t, DEV), "f32",
+                            mean=torch.from_numpy(mean).to(DEV), std=torch.from_numpy(std).to(DEV))
+    assert torch.equal(out[:, :612].reshape(2, 320, 612), torch.from_numpy(ref).to(DEV))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C", [1, 3, 4])
 def test_patchify_bit_exact(ops, dtype, C):
