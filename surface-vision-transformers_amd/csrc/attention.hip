@@ -424,9 +424,9 @@ SITK_DEV void tr_mma_o(f32x4 (&acc)[4], const f32x4 (&p)[4], const char* tile, c
 }
 
 // rows [0, ntiles*64) x 64 bf16 columns of `src` (leading dim ld) -> LDS tiles [t][64][128 B]; rows >= nrows are zero
-SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, int nrows, int ntiles, int wave, int lane) {
+SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, int nrows, int ntiles, int wave, int lane, int nwaves) {
   const char* zero = reinterpret_cast<const char*>(g_zero_page_attn);
-  for (int q = wave; q < ntiles * 8; q += 8) {      // one piece = 8 rows x 128 B
+  for (int q = wave; q < ntiles * 8; q += nwaves) {      // one piece = 8 rows x 128 B
     const int row = q * 8 + (lane >> 3), r64 = row & 63;
     const int key = ((r64 >> 1) & 1) | (((r64 >> 3) & 1) << 1);
     const int chunk = (lane & 7) ^ (key << 1);
@@ -436,7 +436,8 @@ SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, 
   }
 }
 
-__global__ __launch_bounds__(512) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                            float* __restrict__ lse, int N, int H, float scale) {
   using T = bf16;
   __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192];
@@ -447,13 +448,13 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const bf16* __restric
   const T* base = qkv + (size_t)b * N * ld;
   char* sK = smem;
   char* sV = smem + nkt * 8192;
-  dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane);
-  dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane);
+  dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
+  dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_bf16(lane);
-  for (int qt = wave; qt * 16 < N; qt += 8) {
+  for (int qt = wave; qt * 16 < N; qt += WAVES) {
     const int q = qt * 16 + fr, qc = min(q, N - 1);
     u32x4 qf[2];
 #pragma unroll
@@ -510,7 +511,8 @@ __global__ __launch_bounds__(512) void attn_fwd_res_kernel(const bf16* __restric
   }
 }
 
-__global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                               const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                               float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
                                                               int H, float scale) {
@@ -523,13 +525,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const bf16* __rest
   const T* base = qkv + (size_t)b * N * ld;
   char* sK = smem;
   char* sV = smem + nkt * 8192;
-  dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane);
-  dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane);
+  dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
+  dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_bf16(lane);
-  for (int qt = wave; qt * 16 < N; qt += 8) {
+  for (int qt = wave; qt * 16 < N; qt += WAVES) {
     const int q = qt * 16 + fr, qc = min(q, N - 1);
     u32x4 qf[2], dof[2];
     float dpart = 0.f;
@@ -579,7 +581,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_res_kernel(const bf16* __rest
   }
 }
 
-__global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16* __restrict__ dqkv, int N, int H, float scale) {
   using T = bf16;
@@ -593,9 +596,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const bf16* __res
   char* sDO = smem + nqt * 8192;
   float* sL = reinterpret_cast<float*>(smem + 2 * (RES_MAX_N / 64) * 8192);
   float* sD = sL + RES_MAX_N;
-  dma_rows_bf16(sQ, base + h * 64, ld, N, nqt, wave, lane);
-  dma_rows_bf16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, nqt, wave, lane);
-  for (int r = tid; r < nqt * 64; r += 512) {
+  dma_rows_bf16(sQ, base + h * 64, ld, N, nqt, wave, lane, WAVES);
+  dma_rows_bf16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, nqt, wave, lane, WAVES);
+  for (int r = tid; r < nqt * 64; r += WAVES * 64) {
     const size_t ridx = ((size_t)b * H + h) * N + min(r, N - 1);
     sL[r] = r < N ? lse[ridx] * kLog2e : INFINITY;     // exp2(x - inf) = 0 for padded query rows
     sD[r] = r < N ? delta[ridx] : 0.f;
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_res_kernel(const bf16* __res
   __syncthreads();
   const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_bf16(lane);
-  for (int kt = wave; kt * 16 < N; kt += 8) {
+  for (int kt = wave; kt * 16 < N; kt += WAVES) {
     const int key = kt * 16 + fr, kc = min(key, N - 1);
     u32x4 kf[2], vf[2];
 #pragma unroll
@@ -651,7 +654,7 @@ template <typename T>
 static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (N <= RES_MAX_N) {
-      hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
+      hipLaunchKernelGGL(attn_fwd_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
                          reinterpret_cast<bf16*>(o), lse, N, H, scale);
       return check_launch("attention_fwd_res");
     }
@@ -667,11 +670,11 @@ static int run_bwd(const void* qkv, const void* o, const void* d_o, const float*
                    int B, int N, int H, float scale, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (N <= RES_MAX_N) {
-      hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
+      hipLaunchKernelGGL(attn_bwd_dq_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
                          reinterpret_cast<const bf16*>(o), reinterpret_cast<const bf16*>(d_o), lse, delta,
                          reinterpret_cast<bf16*>(dqkv), N, H, scale);
       SITK_LAUNCH_CHECK("attention_bwd_dq_res");
-      hipLaunchKernelGGL(attn_bwd_dkv_res_kernel, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
+      hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
                          reinterpret_cast<const bf16*>(d_o), lse, delta, reinterpret_cast<bf16*>(dqkv), N, H, scale);
       return check_launch("attention_bwd_dkv_res");
     }
