@@ -404,32 +404,38 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_wres_kernel(GemmParams p, 
       : "v"(KSBASE_A), "v"(KSBASE_W));                                                             \
   __builtin_amdgcn_sched_barrier(0)
 
-template <typename TO, int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_n192_kernel(GemmParams p) {
+// WM = waves along the token dimension (4: 128-token tiles, 3: 96-token tiles for grids that would
+// otherwise leave a third of the CUs idle); 2 waves along the 192 features.
+template <typename TO, int EPI, int WM>
+__global__ __launch_bounds__(WM * 128) void gemm_nt_n192_kernel(GemmParams p) {
   using T = bf16;
-  constexpr int STG = (128 + 192) * 128;   // 40 KB per stage: A rows 0..127 then W rows 0..191
+  constexpr int BM = WM * 32;
+  constexpr int APC = BM / 8;              // 8-row DMA pieces of the A tile
+  constexpr int PIECES = (APC + 24) / (2 * WM);  // per wave and stage: 5 (WM 4) / 6 (WM 3)
+  static_assert(PIECES * 2 * WM == APC + 24, "pieces must divide evenly");
+  constexpr int STG = (BM + 192) * 128;    // A rows then W rows 0..191
   constexpr int NSTG = 4;                  // 160 KB: the whole LDS of a CU
   __shared__ __attribute__((aligned(256))) char smem[NSTG * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
   const int tiles_n = p.N / 192;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (L / tiles_n) * 128, n0 = (L % tiles_n) * 192;
+  const int m0 = (L / tiles_n) * BM, n0 = (L % tiles_n) * 192;
   const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
   const T* __restrict__ W = reinterpret_cast<const T*>(p.W);
   const char* zero = reinterpret_cast<const char*>(g_zero_page_nt);
 
-  // LDS-DMA roles: 40 pieces of 8 rows per stage (16 of A, 24 of W), 5 per wave
+  // LDS-DMA roles: APC + 24 pieces of 8 rows per stage (A then W), PIECES per wave
   const int r8 = lane >> 3;
-  const T* src_row[5];
-  int src_chunk[5];
-  bool src_ok[5];
+  const T* src_row[PIECES];
+  int src_chunk[PIECES];
+  bool src_ok[PIECES];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int q = wave * 5 + i, row = (q < 16 ? q : q - 16) * 8 + r8;
+  for (int i = 0; i < PIECES; ++i) {
+    const int q = wave * PIECES + i, row = (q < APC ? q : q - APC) * 8 + r8;
     const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
     src_chunk[i] = ((lane & 7) ^ (key << 1)) * 8;
-    if (q < 16) {
+    if (q < APC) {
       const int m = m0 + row;
       src_ok[i] = m < p.M;
       src_row[i] = A + (size_t)map_row(p.amap, src_ok[i] ? m : 0) * p.lda;
@@ -441,11 +447,11 @@ __global__ __launch_bounds__(512) void gemm_nt_n192_kernel(GemmParams p) {
   }
   auto issue = [&](int kt, int buf) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < PIECES; ++i) {
       const int k = kt * 64 + src_chunk[i];
       const T* src = (src_ok[i] && k < p.K) ? src_row[i] + k : reinterpret_cast<const T*>(zero);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(smem + buf * STG + (wave * 5 + i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(smem + buf * STG + (wave * PIECES + i) * 1024), 16, 0, 0);
     }
   };
   // per-lane fragment addresses (LDS byte addresses): row*128 + ((ks*64 + fq*16) ^ key<<5); key from lane&15 only
@@ -456,7 +462,7 @@ __global__ __launch_bounds__(512) void gemm_nt_n192_kernel(GemmParams p) {
   for (int ks = 0; ks < 2; ++ks) {
     const int byte = (ks * 64 + fq * 16) ^ (keyl << 5);
     aoff[ks] = lbase + (wm * 32 + fr) * 128 + byte;
-    woff[ks] = lbase + (wn * 96 + fr) * 128 + byte;
+    woff[ks] = lbase + (BM - 128) * 128 + (wn * 96 + fr) * 128 + byte;   // the read macro adds 16384 = 128 rows
   }
 
   f32x4 acc[6][2];
@@ -471,8 +477,8 @@ __global__ __launch_bounds__(512) void gemm_nt_n192_kernel(GemmParams p) {
     if (i < KT) issue(i, i);
   for (int kt = 0; kt < KT; ++kt) {
     const int rem = min(NSTG - 2, KT - 1 - kt);
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (kt + NSTG - 1 < KT) issue(kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
@@ -509,8 +515,15 @@ __global__ __launch_bounds__(512) void gemm_nt_n192_kernel(GemmParams p) {
 
 template <typename TO, int EPI>
 static int launch_gemm_nt_n192(const GemmParams& p, hipStream_t s) {
-  const int grid = cdiv(p.M, 128) * (p.N / 192);
-  hipLaunchKernelGGL((gemm_nt_n192_kernel<TO, EPI>), dim3(grid), dim3(512), 0, s, p);
+  const int tiles_n = p.N / 192;
+  const int g128 = cdiv(p.M, 128) * tiles_n, g96 = cdiv(p.M, 96) * tiles_n;
+  // one workgroup per CU (the 4-stage ring takes the whole LDS): prefer the tile height that fills more
+  // of the 256 CUs in a single round
+  if (g128 < 205 && g96 <= 256) {
+    hipLaunchKernelGGL((gemm_nt_n192_kernel<TO, EPI, 3>), dim3(g96), dim3(384), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_n192_kernel<TO, EPI, 4>), dim3(g128), dim3(512), 0, s, p);
+  }
   return check_launch("gemm_nt_n192");
 }
 
