@@ -36,7 +36,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 1
+#define SITK_ABI_VERSION 2
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -158,6 +158,31 @@ size_t sitk_layernorm_bwd_partial_floats(int64_t rows, int D);
 int sitk_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
                        const float* gamma, const float* dres, float* dx_out, void* dx_out_c, float* dgamma,
                        float* dbeta, float* partials, int64_t rows, int D, int dtype, sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused MLP half of an encoder block, PreNorm(LayerNorm, FeedForward) + residual
+ * (state-dict keys transformer.layers.i.1.{norm, fn.net.0, fn.net.3}, utils/utils.py:21-33;
+ * FeedForward = Linear, GELU(erf), Dropout(0), Linear, Dropout(0)), in ONE launch per direction.
+ * Specialised: dtype bf16, D == 192, M % 64 == 0, M <= 1024 (sitk_mlp_fused_supported); other
+ * shapes use sitk_layernorm_* + sitk_gemm_nt.
+ *   forward : out = x + gelu(LN(x) W1^T + b1) W2^T + b2
+ *     x (rows, D) fp32; w1_c (M, D), w2_c (D, M) `dtype` copies; out (rows, D) fp32 (may not alias x)
+ *     saved for backward (each may be NULL): h = LN(x) (rows, D) `dtype`, mean/rstd (rows) fp32,
+ *     u (rows, M) `dtype` pre-activation; g = gelu(u) (rows, M) `dtype` only when asked for.
+ *   backward: dx = dy + LN'(dh), dh = du W1, du = (dy W2) * gelu'(u)
+ *     dy fp32 + dy_c its `dtype` copy; x/mean/rstd/u as saved; w2t_c = W2^T (M, D), w1t_c = W1^T (D, M);
+ *     writes du and g = gelu(u) (rows, M) `dtype` (operands of the two weight gradients), dx fp32 and
+ *     dx_c its `dtype` copy, and per-workgroup LayerNorm dgamma/dbeta sums to `partials`
+ *     (sitk_mlp_bwd_partial_floats(rows) floats, layout [workgroup][2][D], workgroup = 128 rows).   */
+int sitk_mlp_fused_supported(int D, int M, int dtype);
+int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b, const void* w1_c, const float* b1,
+                 const void* w2_c, const float* b2, void* h, float* mean, float* rstd, void* u, void* g,
+                 float* out, int64_t rows, int D, int M, int dtype, sitk_stream_t stream);
+size_t sitk_mlp_bwd_partial_floats(int64_t rows);
+int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
+                 const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,
+                 float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
+                 sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head self-attention core of vit_pytorch.vit.Attention (dim_head = 64):

@@ -54,6 +54,7 @@ struct LnFinalizeEntry {
   const float* partials;
   float* dgamma;
   float* dbeta;
+  int nblocks;  // workgroups that wrote `partials` (0: the LayerNorm backward kernel's own grid)
 };
 struct LnFinalizeBatch {
   LnFinalizeEntry e[LN_FINALIZE_MAX];

@@ -68,6 +68,7 @@ struct LayerActs {
 };
 struct Scratch {
   char *du, *dh, *d_o, *dqkv;
+  char* g;  // gelu(u) of the layer in flight, recomputed by the fused MLP backward for the weight gradient
   float *delta, *ping, *pong;
   // backward: residual-gradient ping-pong (fp32 dxB besides the caller's dx) and compute-dtype copies
   float* dxB;
@@ -83,6 +84,9 @@ struct Layout {
   Scratch scratch;
   size_t acts_bytes = 0, scratch_bytes = 0;
 };
+
+// the fused LayerNorm + MLP kernels (mlp_fused.hip) cover the bf16 tiny shape
+static bool mlp_fused(const sitk_encoder_cfg& c) { return sitk_mlp_fused_supported(c.dim, c.mlp_dim, c.dtype) != 0; }
 
 static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) {
   Layout L;
@@ -106,12 +110,14 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
     a.lse = (float*)take((size_t)c.B * c.heads * c.N * 4);
     a.xmid = (float*)take(R * D * 4);
     a.h1 = take(R * D * es); a.qkv = take(R * 3 * I * es); a.o = take(R * I * es);
-    a.h2 = take(R * D * es); a.u = take(R * M * es); a.g = take(R * M * es);
+    a.h2 = take(R * D * es); a.u = take(R * M * es);
+    a.g = mlp_fused(c) ? nullptr : take(R * M * es);   // the fused MLP recomputes gelu(u) in backward
   }
   L.acts_bytes = off;
   off = 0;
   auto stake = [&](size_t bytes) { char* p = scratch ? scratch + off : nullptr; off += align_up(bytes, 256); return p; };
   L.scratch.du = stake(R * M * es);
+  L.scratch.g = mlp_fused(c) ? stake(R * M * es) : nullptr;
   L.scratch.dh = stake(R * D * es);
   L.scratch.d_o = stake(R * I * es);
   L.scratch.dqkv = stake(R * 3 * I * es);
@@ -234,6 +240,12 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     sitk_gemm_desc g2 = gemm_desc(R, D, I, a.o, I, 0, wo, SITK_EPI_BIAS_RES, a.xmid, D, 1);
     g2.bias = P[l].bo; g2.aux = x; g2.ldaux = D;
     SITK_TRY(sitk_gemm_nt(&g2, dt, stream));
+    if (mlp_fused(c)) {
+      SITK_TRY(sitk_mlp_fwd(a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2, a.mean2, a.rstd2, a.u, nullptr,
+                            xnext, R, D, M, dt, stream));
+      x = xnext;
+      continue;
+    }
     SITK_TRY(sitk_layernorm_fwd(a.xmid, P[l].ln2_w, P[l].ln2_b, a.h2, a.mean2, a.rstd2, R, D, dt, stream));
     sitk_gemm_desc g3 = gemm_desc(R, M, D, a.h2, D, 0, w1, SITK_EPI_BIAS_GELU, a.u, M, 0);
     g3.bias = P[l].b1; g3.out2 = a.g;
@@ -273,21 +285,29 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     const LayerActs& a = L.layers[l];
     const float* xl = l == 0 ? x_in : a.x_in;
     // ---- MLP branch: x_out = xmid + W2 gelu(W1 LN2(xmid) + b1) + b2 ----
-    sitk_gemm_desc d1 = gemm_desc(R, M, D, S.dxAc, D, 0, a.w2_t, SITK_EPI_DGELU, S.du, M, 0);
-    d1.aux = a.u; d1.ldaux = M;
-    SITK_TRY(sitk_gemm_nt(&d1, dt, stream));
-    sitk_gemm_desc d2 = gemm_desc(R, D, M, S.du, M, 0, a.w1_t, SITK_EPI_STORE, S.dh, D, 0);
-    SITK_TRY(sitk_gemm_nt(&d2, dt, stream));
     float* part2 = S.ln_partials + (size_t)(2 * l + 1) * S.ln_partial_floats;
-    SITK_TRY(layernorm_bwd_deferred(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, S.dxB, S.dxBc, part2, R, D, dt, hs));
-    ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b});
+    const void* gact = a.g;
+    if (mlp_fused(c)) {
+      SITK_TRY(sitk_mlp_bwd(dx, S.dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, S.du, S.g, S.dxB, S.dxBc,
+                            part2, R, D, M, dt, stream));
+      ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, cdiv(R, 128)});
+      gact = S.g;
+    } else {
+      sitk_gemm_desc d1 = gemm_desc(R, M, D, S.dxAc, D, 0, a.w2_t, SITK_EPI_DGELU, S.du, M, 0);
+      d1.aux = a.u; d1.ldaux = M;
+      SITK_TRY(sitk_gemm_nt(&d1, dt, stream));
+      sitk_gemm_desc d2 = gemm_desc(R, D, M, S.du, M, 0, a.w1_t, SITK_EPI_STORE, S.dh, D, 0);
+      SITK_TRY(sitk_gemm_nt(&d2, dt, stream));
+      SITK_TRY(layernorm_bwd_deferred(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, S.dxB, S.dxBc, part2, R, D, dt, hs));
+      ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, 0});
+    }
     // ---- attention branch: xmid = x + Wo attn(Wqkv LN1(x)) + bo ----
     sitk_gemm_desc d3 = gemm_desc(R, I, D, S.dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
     SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
     SITK_TRY(sitk_attention_bwd(a.qkv, a.o, S.d_o, a.lse, S.delta, S.dqkv, c.B, c.N, c.heads, scale, dt, stream));
     // ---- the four weight (+ bias) gradients of the layer, one launch ----
     sitk_wgrad_desc wg[4] = {
-        wgrad_desc(R, D, M, S.dxAc, 0, a.g, G[l].w2, G[l].b2),
+        wgrad_desc(R, D, M, S.dxAc, 0, gact, G[l].w2, G[l].b2),
         wgrad_desc(R, M, D, S.du, 0, a.h2, G[l].w1, G[l].b1),
         wgrad_desc(R, D, I, S.dxBc, 0, a.o, G[l].wo, G[l].bo),
         wgrad_desc(R, 3 * I, D, S.dqkv, 0, a.h1, G[l].wqkv, nullptr),
@@ -297,7 +317,7 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
     float* part1 = S.ln_partials + (size_t)(2 * l) * S.ln_partial_floats;
     SITK_TRY(layernorm_bwd_deferred(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, part1, R, D, dt, hs));
-    ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b});
+    ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, 0});
   }
   // every LayerNorm parameter gradient of the slice in one reduction launch
   return layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs);

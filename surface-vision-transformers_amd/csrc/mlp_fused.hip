@@ -1,0 +1,643 @@
+// sitk fused MLP half of an encoder block (bf16 compute mode, dim = 192), forward and backward.
+//
+//   forward   h   = LayerNorm(x)                          layers.i.1.norm
+//             u   = h W1^T + b1 ;  g = gelu_erf(u)        layers.i.1.fn.net.0 / GELU
+//             out = g W2^T + b2 + x                       layers.i.1.fn.net.3 + residual
+//
+//   backward  du  = (dy W2) * gelu'(u) ;  g = gelu(u)     (g is recomputed, never stored by forward)
+//             dh  = du W1
+//             dx  = dy + LayerNorm'(dh)                   + per-workgroup dgamma / dbeta partials
+//
+// Both directions are the same two chained GEMMs, so they share one kernel body.  As separate
+// launches each direction costs a LayerNorm pass and two GEMMs whose (tokens x mlp_dim) operand makes
+// an extra HBM round trip; here it never leaves the registers between the two products.
+//
+// A workgroup (8 waves, 2 per SIMD) owns 128 tokens.  Wave w = (tg, hh): token group tg = w >> 1 (32
+// tokens = 2 MFMA column tiles) and half hh = w & 1 of every 64-unit chunk of the hidden dimension.
+// The wave keeps the 32 x 192 operand of the first product (h, or dy) in registers for the whole
+// kernel (12 fragments) and walks the hidden dimension in chunks of 64 units:
+//     uacc (32 hidden x 32 tokens) = Wa[chunk half] . operand      6 k-steps x 4 MFMAs
+//     elementwise (bias + GELU, or GELU' with the saved u) in registers; u / du / g go to HBM once
+//     yacc (192 x 32 tokens)      += Wb[:, chunk half] . uacc      12 x 2 MFMAs; the accumulator pair of
+//                                     the first product IS the B operand of the second
+// Wa / Wb chunks (24 KB each) stream global -> LDS by LDS-DMA, double buffered, one raw barrier per
+// chunk.  The rows of the Wa chunk are stored permuted (slot 16 i + r <-> hidden 8 (r >> 2) + 4 i +
+// (r & 3)) so that a lane's 2 x 4 accumulator values are 8 CONSECUTIVE hidden units: they form the
+// natural-order B fragment of the second product and one 16-byte global store of u.  Fragment reads
+// sit in asm blocks (a compiler-visible LDS read would drain the DMA queue).  At the end the two
+// halves of a wave pair exchange partial sums through LDS and each finishes 96 of the 192 features.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace sitk {
+
+struct MlpParams {
+  // forward                              backward
+  const float* x;      // (R,192) residual stream in      | x_mid saved by forward
+  const float* gamma;  // LayerNorm weight
+  const float* beta;   // LayerNorm bias                   | unused
+  const bf16* wa;      // W1 (M,192)                       | W2^T (M,192)
+  const bf16* wb;      // W2 (192,M)                       | W1^T (192,M)
+  const float* b1;     // (M)                              | unused
+  const float* b2;     // (192)                            | unused
+  bf16* h;             // (R,192) LN output, saved         | unused
+  float* mean;         // (R) written                      | read
+  float* rstd;
+  bf16* u;             // (R,M) pre-activation written     | read
+  bf16* g;             // (R,M) gelu(u) written (or null)  | written (scratch for the weight gradient)
+  float* out;          // (R,192) fp32                     | dx (R,192) fp32
+  // backward only
+  const bf16* dyc;     // (R,192) compute-dtype copy of dy
+  const float* dy;     // (R,192) fp32 dy (residual gradient)
+  bf16* du;            // (R,M)
+  bf16* outc;          // (R,192) compute-dtype copy of dx
+  float* partials;     // (gridDim.x, 2, 192) dgamma / dbeta partial sums
+  int R, M;
+};
+
+__device__ u32x4 g_zero_page_mlp[4];
+__device__ unsigned long long g_mlp_stamps[8 * 8];   // diagnostic build (SITK_MLP_VAR=6): [wave][phase] cycle sums of workgroup 0
+
+// GELU without transcendentals in the loop.  v_exp_f32 / v_rcp_f32 run at a quarter of the VALU rate (16
+// cycles per wave instruction), and with one exp + one rcp per element the elementwise phase, not the
+// MFMAs, bounded the kernel.  Instead every workgroup tabulates Phi(x) = 0.5 (1 + erf(x / sqrt2)) -- and,
+// for backward, the density exp(-x^2/2)/sqrt(2 pi) -- once in LDS on the grid x_i = (i - 384) / 64,
+// i = 0..767 (exact erff / expf), and the loop interpolates linearly: 7 full-rate VALU operations and one
+// ds_read per element.  Interpolation error <= h^2/8 max|f''| = 7.4e-6 (Phi), 1.2e-5 (density); outside
+// [-6, 6) the end entries apply (Phi(-6) = 1e-9).  The result is closer to the reference's exact-erf GELU
+// than the polynomial erfc of the unfused bf16 epilogues (2.5e-5, gemm.hip).
+constexpr int MLP_TAB_N = 768;
+constexpr float MLP_TAB_SCALE = 64.0f, MLP_TAB_ZERO = 384.0f, MLP_TAB_TMAX = 767.99f;
+SITK_DEV float phi_cdf(float x) { return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+SITK_DEV float phi_pdf(float x) { return 0.39894228040143267794f * expf(-0.5f * x * x); }
+// table position of x: t in [0, 768), entry = floor(t), weight of the next entry = fract(t)
+SITK_DEV float tab_pos(float x) { return __builtin_amdgcn_fmed3f(fmaf(x, MLP_TAB_SCALE, MLP_TAB_ZERO), 0.0f, MLP_TAB_TMAX); }
+
+// two floats -> one dword of two bf16 (v_cvt_pk_bf16_f32)
+SITK_DEV uint32_t pack_bf16(float a, float b) {
+  bf16x2 v;
+  v[0] = (bf16)a; v[1] = (bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+SITK_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// Fragment reads are software pipelined: every block first drains the reads issued by the PREVIOUS block
+// (whose destination registers it carries as "+v" operands, so that no consumer can be scheduled above the
+// wait) and then issues the reads of the NEXT batch into the other register set.  The MFMAs of the
+// current batch run while those reads are in flight.
+#define SITK_MLP_WAIT_ISSUE4(c0, c1, c2, c3, n0, n1, n2, n3, aA, aB, oA0, oA1, oB0, oB1)                    \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+               "ds_read_b128 %4, %8 offset:" #oA0 "\n\tds_read_b128 %5, %8 offset:" #oA1 "\n\t"            \
+               "ds_read_b128 %6, %9 offset:" #oB0 "\n\tds_read_b128 %7, %9 offset:" #oB1                   \
+               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)        \
+               : "v"(aA), "v"(aB)                                                                          \
+               : "memory")
+#define SITK_MLP_ISSUE4(n0, n1, n2, n3, aA, aB, oA0, oA1, oB0, oB1)                                         \
+  asm volatile("ds_read_b128 %0, %4 offset:" #oA0 "\n\tds_read_b128 %1, %4 offset:" #oA1 "\n\t"            \
+               "ds_read_b128 %2, %5 offset:" #oB0 "\n\tds_read_b128 %3, %5 offset:" #oB1                   \
+               : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)                                                \
+               : "v"(aA), "v"(aB)                                                                          \
+               : "memory")
+#define SITK_MLP_WAIT4(c0, c1, c2, c3)                                                                      \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory")
+
+constexpr int MLP_D = 192;
+constexpr int MLP_W1B = 3 * 64 * 128;          // Wa chunk: 3 k-panels x 64 slot rows x 128 B = 24 KB
+constexpr int MLP_W2B = MLP_D * 128;           // Wb chunk: 192 rows x 64 hidden (128 B)     = 24 KB
+constexpr int MLP_OFF_H = 2 * (MLP_W1B + MLP_W2B);   // operand strip: 3 k-panels x 128 rows x 128 B = 48 KB
+constexpr int MLP_OFF_B1 = MLP_OFF_H + 3 * 128 * 128;
+constexpr int MLP_MAX_M = 1024;
+constexpr int MLP_OFF_TAB_F = MLP_OFF_B1 + MLP_MAX_M * 4;        // forward: {Phi, dPhi} x 768 = 6 KB after the bias
+constexpr int MLP_OFF_TAB_B = MLP_OFF_B1;                        // backward (no bias): {Phi, dPhi, pdf, dpdf} x 768 = 12 KB
+constexpr int MLP_SMEM = MLP_OFF_B1 + 12288;
+
+template <bool BWD, int VAR = 0>
+__global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
+  constexpr int D = MLP_D;
+  constexpr int W1B = MLP_W1B, W2B = MLP_W2B;
+  __shared__ __attribute__((aligned(256))) char smem[MLP_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tg = wave >> 1, hh = wave & 1;
+  const int blk0 = blockIdx.x * 128;
+  const int nchunks = p.M / 64;
+  const int M = p.M;
+
+  // ---- W chunk DMA: 48 pieces of 8 rows x 128 B; waves 0-3 carry Wa (24 pieces), waves 4-7 Wb ----
+  const int r8 = lane >> 3;
+  const bool isA = wave < 4;
+  const bf16* wsrc = isA ? p.wa : p.wb;
+  const int cstep = isA ? 64 * D : 64;                         // element step per chunk
+  int soff[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int qq = (wave & 3) * 6 + i;                         // piece within its matrix, 0..23
+    if (isA) {
+      const int kt = qq >> 3, s = (qq & 7) * 8 + r8;           // slot row in the 64-row panel
+      const int r = s & 15, it = (s >> 4) & 1, hs = s >> 5;
+      const int hidden = 32 * hs + 8 * (r >> 2) + 4 * it + (r & 3);
+      const int key = ((s >> 1) & 1) | (((s >> 3) & 1) << 1);
+      soff[i] = hidden * D + kt * 64 + (((lane & 7) ^ (key << 1)) * 8);
+    } else {
+      const int row = qq * 8 + r8;
+      const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+      soff[i] = row * M + (((lane & 7) ^ (key << 1)) * 8);
+    }
+  }
+  auto issue = [&](int c, int buf) {
+    char* base = smem + buf * (W1B + W2B) + (isA ? 0 : W1B) + (wave & 3) * 6 * 1024;
+    const bf16* src = wsrc + (size_t)c * cstep;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+  };
+  issue(0, 0);
+
+  // ---- GELU tables (see above); visible to everybody after the first barrier of the loop ----
+  for (int i = tid; i < MLP_TAB_N; i += 512) {
+    const float x0 = (float)(i - 384) * (1.0f / MLP_TAB_SCALE), x1 = (float)(i - 383) * (1.0f / MLP_TAB_SCALE);
+    const float c0 = phi_cdf(x0), c1 = phi_cdf(x1);
+    if constexpr (!BWD) {
+      *reinterpret_cast<f32x2*>(smem + MLP_OFF_TAB_F + i * 8) = f32x2{c0, c1 - c0};
+    } else {
+      const float d0 = phi_pdf(x0), d1 = phi_pdf(x1);
+      *reinterpret_cast<f32x4*>(smem + MLP_OFF_TAB_B + i * 16) = f32x4{c0, c1 - c0, d0, d1 - d0};
+    }
+  }
+
+  // Row-indexed global traffic goes through buffer descriptors of THIS workgroup's rows (base = its first
+  // row, num_records = its valid rows): rows past R fall outside num_records, so their loads return 0 and
+  // their stores are dropped without any per-lane branch, every wave issues the same number of memory
+  // operations (the vmcnt bookkeeping below relies on it), and the chunk offset rides in the scalar offset
+  // (no VALU address arithmetic).  The hardware range-checks the VGPR offset only -- never the scalar
+  // offset -- which is why the descriptor is per workgroup and the scalar offset stays inside a row.
+  const size_t nrows = (size_t)(p.R - blk0 < 128 ? p.R - blk0 : 128);
+  const size_t RD = nrows * D, RM = nrows * M, oD = (size_t)blk0 * D, oM = (size_t)blk0 * M;
+  const __amdgpu_buffer_rsrc_t r_u = make_rsrc(p.u + oM, p.u ? RM * 2 : 0);
+  const __amdgpu_buffer_rsrc_t r_g = make_rsrc(p.g + oM, p.g ? RM * 2 : 0);
+  const __amdgpu_buffer_rsrc_t r_du = make_rsrc(p.du + oM, BWD ? RM * 2 : 0);
+
+  // ---- operand strip: forward = LayerNorm of the block's rows (wave: 16 rows; 16 lanes per row, 4 rows
+  //      per pass, all 12 loads in flight together); backward = the compute-dtype copy of dy ----
+  char* sH = smem + MLP_OFF_H;
+  u32x4 hf[2][6];
+  if constexpr (!BWD) {
+    for (int i = tid; i < M; i += 512) reinterpret_cast<float*>(smem + MLP_OFF_B1)[i] = p.b1[i];
+    const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.x + oD, RD * 4);
+    const __amdgpu_buffer_rsrc_t r_h = make_rsrc(p.h + oD, p.h ? RD * 2 : 0);
+    const int j = lane & 15, sub = lane >> 4;
+    f32x4 gm[3], bt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gm[i] = load4(p.gamma + 4 * (j + 16 * i)); bt[i] = load4(p.beta + 4 * (j + 16 * i)); }
+    f32x4 v[4][3];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        v[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = wave * 16 + pass * 4 + sub, row = blk0 + r;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) s += v[pass][i][0] + v[pass][i][1] + v[pass][i][2] + v[pass][i][3];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mu = s * (1.0f / D);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[pass][i][e] - mu; ss += d * d; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float rs = rsqrtf(ss * (1.0f / D) + 1e-5f);
+      const bool ok = row < p.R;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c4 = j + 16 * i;                       // float4 index in the row: columns 4*c4 ..
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ok ? (v[pass][i][e] - mu) * rs * gm[i][e] + bt[i][e] : 0.f;
+        const int byte = c4 * 8;                         // bf16 byte offset in the 384-byte row
+        bf16x4 ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ob[e] = (bf16)o[e];
+        *reinterpret_cast<bf16x4*>(sH + (byte >> 7) * (128 * 128) + lds_off(r, byte & 127)) = ob;
+        if (p.h) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), r_h, (r * D + 4 * c4) * 2, 0, 0);
+      }
+      if (ok && j == 0 && p.mean) { p.mean[row] = mu; p.rstd[row] = rs; }
+    }
+    __syncthreads();
+    // this wave's operand fragments: token tile t, k-step k <-> 16 B of row 32 tg + 16 t + fr
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        hf[t][k] = *reinterpret_cast<const u32x4*>(sH + (k >> 1) * (128 * 128) +
+                                                   lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
+  } else {
+    const __amdgpu_buffer_rsrc_t r_dyc = make_rsrc(p.dyc + oD, RD * 2);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        hf[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_dyc, ((32 * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
+  }
+
+  // ---- per-lane LDS byte addresses ----
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
+  uint32_t aw1[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    aw1[ks] = lbase + (32 * hh + fr) * 128 + ((ks * 64 + fq * 16) ^ (keyl << 5));   // + kt*8192 + i*2048 (+ buffer)
+  const uint32_t aw2 = lbase + W1B + fr * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));  // + dt*2048 (+ buffer)
+  const uint32_t ab1 = lbase + MLP_OFF_B1 + (32 * hh + 8 * fq) * 4;                   // + c*256
+  const uint32_t ltabf = lbase + MLP_OFF_TAB_F, ltabb = lbase + MLP_OFF_TAB_B;
+
+  f32x4 yacc[12][2];
+#pragma unroll
+  for (int dt = 0; dt < 12; ++dt) { yacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; yacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  // (rows x M) operands: lane's 16 bytes of token tile t sit at vo[t] + (block, chunk) scalar offset
+  const int trow0 = blk0 + 32 * tg + fr, trow1 = trow0 + 16;
+  const int vo[2] = {((32 * tg + fr) * M + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * M + 32 * hh + 8 * fq) * 2};
+  const int so0 = 0;                                           // scalar offset: chunk only (c * 128 bytes)
+  // backward: the saved pre-activations of chunk c travel one chunk ahead of their use
+  u32x4 un[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+  if constexpr (BWD) {
+    un[0] = __builtin_amdgcn_raw_buffer_load_b128(r_u, vo[0], so0, 0);
+    un[1] = __builtin_amdgcn_raw_buffer_load_b128(r_u, vo[1], so0, 0);
+  }
+
+  // Waves w and w + 4 share a SIMD and the per-chunk barrier keeps them in lock step, so left alone they
+  // would fight for the MFMA pipe in the product phases and for VALU issue in the elementwise phase without
+  // ever overlapping the two.  A static priority lets one wave of each pair win the matrix pipe: it reaches
+  // its elementwise phase while the other is still in its MFMAs, and the phases interleave from there.
+  if (VAR != 5 && wave < 4) __builtin_amdgcn_s_setprio(2);
+  // global stores each wave issues per chunk after the next chunk's DMA
+  const int nstores = BWD ? 4 : (p.u ? 2 : 0) + (p.g ? 2 : 0);
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define SITK_STAMP(i)                                                                    \
+  if constexpr (VAR == 6) {                                                              \
+    const unsigned long long tn = __builtin_amdgcn_s_memtime();                          \
+    st[i] += tn - tprev;                                                                 \
+    tprev = tn;                                                                          \
+  }
+  if constexpr (VAR == 6) tprev = __builtin_amdgcn_s_memtime();
+  for (int c = 0; c < (VAR == 4 ? 0 : nchunks); ++c) {
+    const int buf = c & 1;
+    SITK_STAMP(7)
+    // chunk c's DMA (and, backward, its u loads) were issued before the previous iteration's stores
+    // (pinned there by the "memory" clobbers of the fragment-read blocks), so only those stores may stay in flight
+    if (c == 0 || nstores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nstores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    SITK_STAMP(0)
+    if (VAR != 3 || c == 0) __builtin_amdgcn_s_barrier();      // everybody's pieces landed; buffer buf^1 is free
+    SITK_STAMP(1)
+    const uint32_t bo = buf * (W1B + W2B);
+    const uint32_t a0 = aw1[0] + bo, a1 = aw1[1] + bo, a2 = aw2 + bo;
+    // batches of 4 fragments alternate between register sets X and Y.  First product, panel kt:
+    // {tile 0, tile 1} x {k-step 2 kt, 2 kt + 1}; second product, group j: feature tiles 4 j .. 4 j + 3.
+    u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
+    SITK_MLP_ISSUE4(x0, x1, x2, x3, a0, a1, 0, 2048, 0, 2048);
+    u32x4 uc[2];
+    if constexpr (BWD) {
+      uc[0] = un[0]; uc[1] = un[1];
+      if (c + 1 < nchunks) {
+        un[0] = __builtin_amdgcn_raw_buffer_load_b128(r_u, vo[0], so0 + (c + 1) * 128, 0);
+        un[1] = __builtin_amdgcn_raw_buffer_load_b128(r_u, vo[1], so0 + (c + 1) * 128, 0);
+      }
+    }
+    if (VAR != 3 && c + 1 < nchunks) issue(c + 1, buf ^ 1);
+
+    // ---- first product: uacc[i][t], hidden tile i (slot rows 32 hh + 16 i ..), token tile t; forward
+    //      starts the accumulators at the bias ----
+    f32x4 uacc[2][2];
+    if constexpr (!BWD) {
+      u32x4 t0, t1;
+      const uint32_t ab = ab1 + c * 256;
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(t0), "=&v"(t1) : "v"(ab) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : : "memory");
+      uacc[0][0] = uacc[0][1] = __builtin_bit_cast(f32x4, t0);
+      uacc[1][0] = uacc[1][1] = __builtin_bit_cast(f32x4, t1);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { uacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; uacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+#define SITK_MLP_FC1_MMAS(KT, f0, f1, f2, f3)                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    uacc[0][0] = Mma<bf16>::mma(f0, hf[0][2 * KT], uacc[0][0]);                                             \
+    uacc[0][1] = Mma<bf16>::mma(f0, hf[1][2 * KT], uacc[0][1]);                                             \
+    uacc[1][0] = Mma<bf16>::mma(f1, hf[0][2 * KT], uacc[1][0]);                                             \
+    uacc[1][1] = Mma<bf16>::mma(f1, hf[1][2 * KT], uacc[1][1]);                                             \
+    uacc[0][0] = Mma<bf16>::mma(f2, hf[0][2 * KT + 1], uacc[0][0]);                                         \
+    uacc[0][1] = Mma<bf16>::mma(f2, hf[1][2 * KT + 1], uacc[0][1]);                                         \
+    uacc[1][0] = Mma<bf16>::mma(f3, hf[0][2 * KT + 1], uacc[1][0]);                                         \
+    uacc[1][1] = Mma<bf16>::mma(f3, hf[1][2 * KT + 1], uacc[1][1]);                                         \
+    __builtin_amdgcn_sched_barrier(0);
+    SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a0, a1, 8192, 10240, 8192, 10240);
+    SITK_MLP_FC1_MMAS(0, x0, x1, x2, x3)
+    SITK_MLP_WAIT_ISSUE4(y0, y1, y2, y3, x0, x1, x2, x3, a0, a1, 16384, 18432, 16384, 18432);
+    SITK_MLP_FC1_MMAS(1, y0, y1, y2, y3)
+    SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a2, a2, 0, 2048, 4096, 6144);   // second product, group 0
+    SITK_MLP_FC1_MMAS(2, x0, x1, x2, x3)
+#undef SITK_MLP_FC1_MMAS
+    SITK_STAMP(2)
+
+    // ---- elementwise; lane holds hidden c*64 + 32 hh + 8 fq + 4 i + e of token 32 tg + 16 t + fr ----
+    u32x4 pf[2];                                               // B fragments of the second product
+    u32x4 sd[2];                                               // the other stored vector (u forward, g backward)
+    const int so = so0 + c * 128;
+    if constexpr (!BWD) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 v0 = uacc[0][t], v1 = uacc[1][t];
+        float xs[8], fw[8];
+        uint32_t ad[8];
+        u32x2 te[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xs[e] = e < 4 ? v0[e] : v1[e - 4];
+          const float tp = tab_pos(xs[e]);
+          fw[e] = __builtin_amdgcn_fractf(tp);
+          ad[e] = ltabf + ((uint32_t)tp << 3);
+        }
+        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
+                     "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(te[0]), "=&v"(te[1]), "=&v"(te[2]), "=&v"(te[3]), "=&v"(te[4]), "=&v"(te[5]), "=&v"(te[6]), "=&v"(te[7])
+                     : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+                     : "memory");
+        float gv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const f32x2 en = __builtin_bit_cast(f32x2, te[e]);
+          gv[e] = xs[e] * (VAR == 1 ? 0.5f : fmaf(fw[e], en[1], en[0]));
+        }
+        pf[t] = u32x4{pack_bf16(gv[0], gv[1]), pack_bf16(gv[2], gv[3]), pack_bf16(gv[4], gv[5]), pack_bf16(gv[6], gv[7])};
+        if (VAR != 2) {
+          sd[t] = u32x4{pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+          if (p.u) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_u, vo[t], so, 0);
+          if (p.g) __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_g, vo[t], so, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float dv[8], gv[8];
+#pragma unroll
+        for (int hf4 = 0; hf4 < 2; ++hf4) {                     // 4 elements at a time (register budget)
+          float us[4], fw[4];
+          uint32_t ad[4];
+          u32x4 te[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // bf16 -> f32 is a 16-bit shift of the packed dword
+            const uint32_t w = uc[t][2 * hf4 + (e >> 1)];
+            us[e] = __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+            const float tp = tab_pos(us[e]);
+            fw[e] = __builtin_amdgcn_fractf(tp);
+            ad[e] = ltabb + ((uint32_t)tp << 4);
+          }
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(te[0]), "=&v"(te[1]), "=&v"(te[2]), "=&v"(te[3])
+                       : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+                       : "memory");
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 en = __builtin_bit_cast(f32x4, te[e]);
+            const float cdf = fmaf(fw[e], en[1], en[0]), pdf = fmaf(fw[e], en[3], en[2]);
+            dv[4 * hf4 + e] = uacc[hf4][t][e] * fmaf(us[e], pdf, cdf);
+            gv[4 * hf4 + e] = us[e] * cdf;
+          }
+        }
+        pf[t] = u32x4{pack_bf16(dv[0], dv[1]), pack_bf16(dv[2], dv[3]), pack_bf16(dv[4], dv[5]), pack_bf16(dv[6], dv[7])};
+        sd[t] = u32x4{pack_bf16(gv[0], gv[1]), pack_bf16(gv[2], gv[3]), pack_bf16(gv[4], gv[5]), pack_bf16(gv[6], gv[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_du, vo[t], so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_g, vo[t], so, 0);
+      }
+    }
+
+    SITK_STAMP(3)
+    // ---- second product: yacc[dt][t] += Wb[16 dt .., chunk half] . pf[t] ----
+#define SITK_MLP_FC2_MMAS(J, f0, f1, f2, f3)                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    yacc[4 * J + 0][0] = Mma<bf16>::mma(f0, pf[0], yacc[4 * J + 0][0]);                                     \
+    yacc[4 * J + 0][1] = Mma<bf16>::mma(f0, pf[1], yacc[4 * J + 0][1]);                                     \
+    yacc[4 * J + 1][0] = Mma<bf16>::mma(f1, pf[0], yacc[4 * J + 1][0]);                                     \
+    yacc[4 * J + 1][1] = Mma<bf16>::mma(f1, pf[1], yacc[4 * J + 1][1]);                                     \
+    yacc[4 * J + 2][0] = Mma<bf16>::mma(f2, pf[0], yacc[4 * J + 2][0]);                                     \
+    yacc[4 * J + 2][1] = Mma<bf16>::mma(f2, pf[1], yacc[4 * J + 2][1]);                                     \
+    yacc[4 * J + 3][0] = Mma<bf16>::mma(f3, pf[0], yacc[4 * J + 3][0]);                                     \
+    yacc[4 * J + 3][1] = Mma<bf16>::mma(f3, pf[1], yacc[4 * J + 3][1]);                                     \
+    __builtin_amdgcn_sched_barrier(0);
+    SITK_MLP_WAIT_ISSUE4(y0, y1, y2, y3, x0, x1, x2, x3, a2, a2, 8192, 10240, 12288, 14336);
+    SITK_MLP_FC2_MMAS(0, y0, y1, y2, y3)
+    // Keep-alive: the vector memory pipeline reads the data registers of a 16-byte store well after the store
+    // issues when stores queue back to back (observed on gfx950: a VALU result written three instructions
+    // after the second store of a pair reached memory).  Holding the stored vectors live across the first
+    // MFMA group keeps the allocator from recycling their registers while the stores may still be reading.
+    if (VAR != 2) asm volatile("" : : "v"(sd[0]), "v"(sd[1]), "v"(pf[0]), "v"(pf[1]));
+    SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a2, a2, 16384, 18432, 20480, 22528);
+    SITK_MLP_FC2_MMAS(1, x0, x1, x2, x3)
+    SITK_MLP_WAIT4(y0, y1, y2, y3);
+    SITK_MLP_FC2_MMAS(2, y0, y1, y2, y3)
+#undef SITK_MLP_FC2_MMAS
+    SITK_STAMP(4)
+  }
+  if constexpr (VAR == 6) {
+    if (blockIdx.x == 0 && lane == 0)
+      for (int i = 0; i < 8; ++i) g_mlp_stamps[wave * 8 + i] = st[i];
+  }
+
+  // ---- pair exchange: wave hh finishes features [96 hh, 96 hh + 96); the other half's partial sums
+  //      cross through LDS (12 tiles x 1 KB per wave, in the W buffers that nobody reads any more) ----
+  __syncthreads();
+  {
+    char* mine = smem + wave * 12288;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)   // the half this wave does NOT finish (register indices stay compile-time constants)
+        *reinterpret_cast<f32x4*>(mine + ((i * 2 + t) * 64 + lane) * 16) = hh ? yacc[i][t] : yacc[6 + i][t];
+  }
+  __syncthreads();
+  f32x4 v[6][2];
+  {
+    const char* theirs = smem + (wave ^ 1) * 12288;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + ((i * 2 + t) * 64 + lane) * 16);
+        // yacc index must be a compile-time constant: select by hh without dynamic indexing
+        v[i][t] = (hh ? yacc[6 + i][t] : yacc[i][t]) + o;
+      }
+  }
+  const int n0 = 96 * hh + 4 * fq;                             // + 16 i : this lane's 4 features of tile i
+
+  if constexpr (!BWD) {
+    // out = v + b2 + x
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t ? trow1 : trow0;
+      if (row < p.R) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int n = n0 + 16 * i;
+          store4(p.out + (size_t)row * D + n, v[i][t] + load4(p.b2 + n) + load4(p.x + (size_t)row * D + n));
+        }
+      }
+    }
+  } else {
+    // LayerNorm backward on dh = v:  dx = dy + rstd (dh gamma - mean(dh gamma) - xhat mean(dh gamma xhat))
+    float* red = reinterpret_cast<float*>(smem + MLP_OFF_B1);  // [wave][t][16 tokens][2] row sums (2 KB)
+    f32x4 gmv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gmv[i] = load4(p.gamma + n0 + 16 * i);
+    f32x4 xh[6][2];
+    float mu[2], rs[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t ? trow1 : trow0;
+      const bool ok = row < p.R;
+      mu[t] = ok ? p.mean[row] : 0.f;
+      rs[t] = ok ? p.rstd[row] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const f32x4 xv = ok ? load4(p.x + (size_t)row * D + n0 + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][t][e] = (xv[e] - mu[t]) * rs[t];
+          const float gy = v[i][t][e] * gmv[i][e];
+          s1 += gy;
+          s2 += gy * xh[i][t][e];
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (fq == 0) { red[((wave * 2 + t) * 16 + fr) * 2] = s1; red[((wave * 2 + t) * 16 + fr) * 2 + 1] = s2; }
+    }
+    __syncthreads();
+    f32x4 dgs[6], dbs[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { dgs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = t ? trow1 : trow0;
+      const bool ok = row < p.R;
+      const float o1 = red[(((wave ^ 1) * 2 + t) * 16 + fr) * 2], o2 = red[(((wave ^ 1) * 2 + t) * 16 + fr) * 2 + 1];
+      const float m1 = (red[((wave * 2 + t) * 16 + fr) * 2] + o1) * (1.0f / D);
+      const float m2 = (red[((wave * 2 + t) * 16 + fr) * 2 + 1] + o2) * (1.0f / D);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int n = n0 + 16 * i;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o[e] = rs[t] * (v[i][t][e] * gmv[i][e] - m1 - xh[i][t][e] * m2);
+          dgs[i][e] += v[i][t][e] * xh[i][t][e];               // rows past R carry v = 0 (zero operand rows)
+          dbs[i][e] += v[i][t][e];
+        }
+        if (ok) {
+          o += load4(p.dy + (size_t)row * D + n);
+          store4(p.out + (size_t)row * D + n, o);
+          store4(p.outc + (size_t)row * D + n, o);
+        }
+      }
+    }
+    // column sums: every lane parks its 2 x 24 per-token-pair values in LDS (row = tg * 16 + fr, pitch 388
+    // floats: conflict-free 16-byte stores), then 384 threads each add up one column over the 64 rows
+    constexpr int CP = 2 * D + 4;
+    float* cs = reinterpret_cast<float*>(smem);                // 64 x 388 floats = 97 KB (W buffers + strip head)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      *reinterpret_cast<f32x4*>(cs + (tg * 16 + fr) * CP + n0 + 16 * i) = dgs[i];
+      *reinterpret_cast<f32x4*>(cs + (tg * 16 + fr) * CP + D + n0 + 16 * i) = dbs[i];
+    }
+    __syncthreads();
+    if (tid < 2 * D) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) s += cs[r * CP + tid];
+      p.partials[(size_t)blockIdx.x * 2 * D + tid] = s;
+    }
+  }
+}
+
+static int mlp_check(const char* what, int64_t rows, int D, int M, int dtype) {
+  SITK_REQUIRE(dtype == SITK_BF16 && D == MLP_D && M % 64 == 0 && M >= 64 && M <= MLP_MAX_M && rows > 0 && rows < (1ll << 31),
+               "%s: the fused path is specialised for bf16, dim 192, mlp_dim %% 64 == 0 and <= %d (got dtype %d dim %d mlp_dim %d)",
+               what, MLP_MAX_M, dtype, D, M);
+  return SITK_OK;
+}
+
+}  // namespace sitk
+
+using namespace sitk;
+
+extern "C" int sitk_mlp_fused_supported(int D, int M, int dtype) {
+  return dtype == SITK_BF16 && D == MLP_D && M % 64 == 0 && M >= 64 && M <= MLP_MAX_M;
+}
+
+extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b, const void* w1_c, const float* b1,
+                            const void* w2_c, const float* b2, void* h, float* mean, float* rstd, void* u, void* g,
+                            float* out, int64_t rows, int D, int M, int dtype, sitk_stream_t stream) {
+  SITK_REQUIRE(x && ln_w && ln_b && w1_c && b1 && w2_c && b2 && out, "mlp_fwd: null pointer");
+  SITK_REQUIRE((mean == nullptr) == (rstd == nullptr), "mlp_fwd: mean and rstd go together");
+  SITK_TRY(mlp_check("mlp_fwd", rows, D, M, dtype));
+  MlpParams p = {};
+  p.x = x; p.gamma = ln_w; p.beta = ln_b;
+  p.wa = reinterpret_cast<const bf16*>(w1_c); p.b1 = b1; p.wb = reinterpret_cast<const bf16*>(w2_c); p.b2 = b2;
+  p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd;
+  p.u = reinterpret_cast<bf16*>(u); p.g = reinterpret_cast<bf16*>(g); p.out = out;
+  p.R = (int)rows; p.M = M;
+  static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;
+  const dim3 grid(cdiv((int)rows, 128));
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  if (var == 1) hipLaunchKernelGGL((mlp_kernel<false, 1>), grid, dim3(512), 0, hs, p);
+  else if (var == 2) hipLaunchKernelGGL((mlp_kernel<false, 2>), grid, dim3(512), 0, hs, p);
+  else if (var == 3) hipLaunchKernelGGL((mlp_kernel<false, 3>), grid, dim3(512), 0, hs, p);
+  else if (var == 4) hipLaunchKernelGGL((mlp_kernel<false, 4>), grid, dim3(512), 0, hs, p);
+  else if (var == 5) hipLaunchKernelGGL((mlp_kernel<false, 5>), grid, dim3(512), 0, hs, p);
+  else if (var == 6) hipLaunchKernelGGL((mlp_kernel<false, 6>), grid, dim3(512), 0, hs, p);
+  else
+  hipLaunchKernelGGL((mlp_kernel<false, 0>), dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("mlp_fwd");
+}
+
+// diagnostic: per-phase cycle sums of workgroup 0 written by the SITK_MLP_VAR=6 build (not part of the ABI header)
+extern "C" int sitk_mlp_debug_stamps(unsigned long long* out64) {
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+
+extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) { return rows > 0 ? (size_t)cdiv64(rows, 128) * 2 * MLP_D : 0; }
+
+extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
+                            const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,
+                            float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
+                            sitk_stream_t stream) {
+  SITK_REQUIRE(dy && dy_c && x && mean && rstd && ln_w && w2t_c && w1t_c && u && du && g && dx && dx_c && partials,
+               "mlp_bwd: null pointer");
+  SITK_TRY(mlp_check("mlp_bwd", rows, D, M, dtype));
+  MlpParams p = {};
+  p.x = x; p.gamma = ln_w; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
+  p.wa = reinterpret_cast<const bf16*>(w2t_c); p.wb = reinterpret_cast<const bf16*>(w1t_c);
+  p.u = const_cast<bf16*>(reinterpret_cast<const bf16*>(u)); p.g = reinterpret_cast<bf16*>(g);
+  p.du = reinterpret_cast<bf16*>(du); p.dy = dy; p.dyc = reinterpret_cast<const bf16*>(dy_c);
+  p.out = dx; p.outc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
+  p.R = (int)rows; p.M = M;
+  hipLaunchKernelGGL((mlp_kernel<true, 0>), dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("mlp_bwd");
+}

@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void ln_finalize_multi_kernel(LnFinalizeBatch 
   const LnFinalizeEntry e = batch.e[blockIdx.z];
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= 2 * D) return;
+  if (e.nblocks > 0) nblocks = e.nblocks;
   const int per = (nblocks + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
   float s = 0.f;

@@ -175,6 +175,48 @@ def layernorm_bwd_partial_floats(rows, D):
     return rt.lib.sitk_layernorm_bwd_partial_floats(rows, D)
 
 
+# ---- fused LayerNorm + MLP (+ residual) ------------------------------------------------------------
+def mlp_fused_supported(D, M, dtype):
+    return bool(rt.lib.sitk_mlp_fused_supported(D, M, rt.dtype_code(dtype)))
+
+
+def mlp_fwd(x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
+    """out = x + gelu(LN(x) W1^T + b1) W2^T + b2; returns (out, h, mean, rstd, u, g) (saved tensors or None)."""
+    rt.require_cuda(x, ln_w, ln_b, w1_c, b1, w2_c, b2)
+    rows, D = x.shape
+    M = w1_c.shape[0]
+    code = rt.dtype_code(dtype)
+    td = rt.torch_dtype(code)
+    out = torch.empty_like(x)
+    h = torch.empty((rows, D), dtype=td, device=x.device) if save else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    u = torch.empty((rows, M), dtype=td, device=x.device) if save else None
+    g = torch.empty((rows, M), dtype=td, device=x.device) if want_g else None
+    rt.check(rt.lib.sitk_mlp_fwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w1_c.data_ptr(), b1.data_ptr(),
+                                 w2_c.data_ptr(), b2.data_ptr(), rt.ptr(h), rt.ptr(mean), rt.ptr(rstd), rt.ptr(u), rt.ptr(g),
+                                 out.data_ptr(), rows, D, M, code, rt.stream_ptr()))
+    return out, h, mean, rstd, u, g
+
+
+def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, dtype):
+    """returns (dx, dx_c, du, g, partials (workgroups, 2, D))"""
+    rows, D = x.shape
+    M = u.shape[1]
+    code = rt.dtype_code(dtype)
+    du = torch.empty_like(u)
+    g = torch.empty_like(u)
+    dx = torch.empty_like(x)
+    dx_c = torch.empty((rows, D), dtype=u.dtype, device=x.device)
+    nfl = rt.lib.sitk_mlp_bwd_partial_floats(rows)
+    partials = torch.empty(nfl, dtype=torch.float32, device=x.device)
+    rt.check(rt.lib.sitk_mlp_bwd(dy.data_ptr(), dy_c.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                 ln_w.data_ptr(), w2t_c.data_ptr(), w1t_c.data_ptr(), u.data_ptr(), du.data_ptr(),
+                                 g.data_ptr(), dx.data_ptr(), dx_c.data_ptr(), partials.data_ptr(), rows, D, M, code,
+                                 rt.stream_ptr()))
+    return dx, dx_c, du, g, partials.view(-1, 2, D)
+
+
 # ---- attention -------------------------------------------------------------------------------------
 def attention_fwd(qkv, B, N, H, scale, dtype):
     code = rt.dtype_code(dtype)

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsitk.so")
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SitkError(RuntimeError):
@@ -71,6 +71,10 @@ _SIGS = {
     "sitk_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "sitk_layernorm_bwd_partial_floats": (_Z, [_L, _I]),
     "sitk_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    "sitk_mlp_fused_supported": (C.c_int, [_I, _I, _I]),
+    "sitk_mlp_fwd": (C.c_int, [_P] * 13 + [_L, _I, _I, _I, _P]),
+    "sitk_mlp_bwd_partial_floats": (_Z, [_L]),
+    "sitk_mlp_bwd": (C.c_int, [_P] * 14 + [_L, _I, _I, _I, _P]),
     "sitk_attention_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "sitk_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "sitk_encoder_acts_bytes": (_Z, [C.POINTER(EncoderCfg)]),

@@ -1,0 +1,186 @@
+"""GPU parity tests of the fused LayerNorm + MLP (+ residual) kernels (csrc/mlp_fused.hip; the
+PreNorm(LayerNorm, FeedForward) half of a vit_pytorch block, state-dict keys layers.i.1.*) against a
+float64 torch statement whose GEMM operands are rounded to bf16 exactly where the kernels round.
+
+Tolerances are relative L2 errors; one bf16 rounding is 2^-9 = 2e-3 per stored value.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import detgen  # noqa: E402
+
+DEV = "cuda:0"
+D = 192
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sitk  # noqa: F401
+    from sitk import ops as _ops
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(name, shape, scale=1.0, seed=0):
+    return torch.from_numpy(detgen.normal(name, shape, std=scale, seed=seed)).to(DEV)
+
+
+def ints(name, shape, lo=-3, hi=4):
+    return torch.from_numpy(detgen.randint(name, shape, lo, hi).astype(np.float32)).to(DEV)
+
+
+def r16(t):
+    return t.to(torch.bfloat16).double()
+
+
+def params(tag, M):
+    ln_w, ln_b = rnd(tag + "/lw", (D,), 0.3) + 1.0, rnd(tag + "/lb", (D,), 0.2)
+    w1, b1 = rnd(tag + "/w1", (M, D), D ** -0.5), rnd(tag + "/b1", (M,), 0.1)
+    w2, b2 = rnd(tag + "/w2", (D, M), M ** -0.5), rnd(tag + "/b2", (D,), 0.1)
+    return ln_w, ln_b, w1, b1, w2, b2
+
+
+SHAPES = [(128, 64), (321 * 3, 768), (1000, 256), (20544, 768)]
+
+
+def test_supported_shapes(ops):
+    assert ops.mlp_fused_supported(192, 768, "bf16")
+    assert not ops.mlp_fused_supported(384, 1536, "bf16")      # small / base use the unfused kernels
+    assert not ops.mlp_fused_supported(192, 768, "f32")        # the exact-f32 verification mode too
+    assert not ops.mlp_fused_supported(192, 2048, "bf16")
+    from sitk import runtime as rt
+    x = torch.zeros((8, 384), device=DEV)
+    with pytest.raises(rt.SitkError):
+        ops.mlp_fwd(x, x[0], x[0], torch.zeros((64, 384), device=DEV).bfloat16(), x[0, :64],
+                    torch.zeros((384, 64), device=DEV).bfloat16(), x[0], "bf16")
+
+
+@pytest.mark.parametrize("rows,M", SHAPES)
+def test_mlp_fused_fwd(ops, rows, M):
+    """rows not a multiple of the 128-row workgroup; one / several / twelve hidden chunks; the BASELINE
+    config-2 shape (20544 x 768)."""
+    x = rnd("mlpf/x", (rows, D), 1.5)
+    ln_w, ln_b, w1, b1, w2, b2 = params("mlpf", M)
+    out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16", want_g=True)
+    torch.cuda.synchronize()
+    xd = x.double()
+    h_r = torch.nn.functional.layer_norm(xd, (D,), ln_w.double(), ln_b.double(), 1e-5)
+    assert rel(h, h_r) < 4e-3
+    assert rel(mean, xd.mean(1)) < 1e-5
+    assert rel(rstd, (xd.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
+    u_r = h.double() @ r16(w1).T + b1.double()                 # from the kernel's own (bf16) h: isolates the product
+    assert rel(u, u_r) < 4e-3
+    g_r = torch.nn.functional.gelu(u_r)
+    assert rel(g, g_r) < 6e-3
+    br_r = r16(g_r) @ r16(w2).T + b2.double()
+    assert rel(out - x, br_r) < 6e-3                           # the branch alone (the residual would mask errors)
+    assert rel(out, xd + br_r) < 2e-3
+    # inference form (nothing saved) gives the same output bits
+    out2 = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16", save=False)[0]
+    assert torch.equal(out, out2)
+
+
+def test_mlp_fused_fwd_integer_exact(ops):
+    """Small-integer weights: given the kernel's own bf16 h and g, both products are exact in fp32 --
+    any fragment-layout or hidden-permutation mistake shows as an O(1) error."""
+    M, rows = 128, 200
+    x = rnd("mlpi/x", (rows, D), 1.0)
+    ln_w, ln_b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    w1, w2 = ints("mlpi/w1", (M, D), -2, 3), ints("mlpi/w2", (D, M), -2, 3)
+    b1, b2 = ints("mlpi/b1", (M,)), ints("mlpi/b2", (D,))
+    out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16", want_g=True)
+    torch.cuda.synchronize()
+    u_r = h.double() @ w1.double().T + b1.double()
+    assert rel(u, u_r) < 3e-3                                  # one bf16 rounding of the stored u
+    out_r = x.double() + g.double() @ w2.double().T + b2.double()
+    assert rel(out, out_r) < 3e-6                              # fp32 accumulation of exactly representable products
+
+
+@pytest.mark.parametrize("rows,M", SHAPES)
+def test_mlp_fused_bwd(ops, rows, M):
+    x = rnd("mlpb/x", (rows, D), 1.5)
+    ln_w, ln_b, w1, b1, w2, b2 = params("mlpb", M)
+    dy = rnd("mlpb/dy", (rows, D), 1.0)
+    out, h, mean, rstd, u, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16")
+    w2t = w2.bfloat16().T.contiguous()                         # (M, D)
+    w1t = w1.bfloat16().T.contiguous()                         # (D, M)
+    dx, dx_c, du, g, partials = ops.mlp_bwd(dy, dy.bfloat16(), x, mean, rstd, ln_w, w2t, w1t, u, "bf16")
+    torch.cuda.synchronize()
+    ud = u.double()                                            # the saved (bf16) pre-activation is what backward sees
+    cdf = 0.5 * (1 + torch.erf(ud / math.sqrt(2)))
+    pdf = torch.exp(-0.5 * ud * ud) / math.sqrt(2 * math.pi)
+    du_r = (r16(dy) @ r16(w2)) * (cdf + ud * pdf)
+    assert rel(du, du_r) < 5e-3
+    assert rel(g, ud * cdf) < 5e-3
+    # LayerNorm backward from the kernel's own du (bf16): autograd in float64
+    xd = x.double().requires_grad_(True)
+    lw = ln_w.double().requires_grad_(True)
+    lb = ln_b.double().requires_grad_(True)
+    hd = torch.nn.functional.layer_norm(xd, (D,), lw, lb, 1e-5)
+    hd.backward(du.double() @ r16(w1))
+    dx_r = dy.double() + xd.grad
+    assert rel(dx - dy, xd.grad) < 2e-3
+    assert rel(dx, dx_r) < 1e-3
+    assert rel(dx_c, dx_r) < 4e-3
+    assert partials.shape == ((rows + 127) // 128, 2, D)
+    assert rel(partials[:, 0].sum(0), lw.grad) < 2e-3
+    assert rel(partials[:, 1].sum(0), lb.grad) < 2e-3
+
+
+def test_mlp_fused_bwd_zero_gradient_rows(ops):
+    """dy = 0 on some rows (the cls-only gradient of pool='cls' is zero almost everywhere at the top
+    layer): those rows must produce exactly dx = 0 and contribute nothing to dgamma / dbeta."""
+    rows, M = 300, 768
+    x = rnd("mlpz/x", (rows, D), 1.5)
+    ln_w, ln_b, w1, b1, w2, b2 = params("mlpz", M)
+    dy = rnd("mlpz/dy", (rows, D), 1.0)
+    dy[::3] = 0
+    out, h, mean, rstd, u, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16")
+    dx, dx_c, du, g, partials = ops.mlp_bwd(dy, dy.bfloat16(), x, mean, rstd, ln_w, w2.bfloat16().T.contiguous(),
+                                            w1.bfloat16().T.contiguous(), u, "bf16")
+    assert float(dx[::3].abs().max()) == 0.0 and float(du[::3].float().abs().max()) == 0.0
+    assert bool(torch.isfinite(dx).all()) and bool(torch.isfinite(partials).all())
+
+
+def test_mlp_fused_repeatable_and_in_bounds(ops):
+    """The kernels keep asynchronous LDS reads and stores in flight behind hand-placed waits: repeated
+    launches at the full BASELINE shape must give identical bits (a missing wait shows as lane-pattern
+    noise), and rows past R in the ragged last workgroup must not be written (sentinel rows stay intact)."""
+    from sitk import runtime as rt
+    rows, M, pad = 20544 - 37, 768, 128
+    x = rnd("mlpr/x", (rows, D), 1.5)
+    ln_w, ln_b, w1, b1, w2, b2 = params("mlpr", M)
+    dy = rnd("mlpr/dy", (rows, D), 1.0)
+    w1c, w2c = w1.bfloat16(), w2.bfloat16()
+    w1t, w2t = w1c.T.contiguous(), w2c.T.contiguous()
+    ref = None
+    for _ in range(4):
+        out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1c, b1, w2c, b2, "bf16", want_g=True)
+        got = (out, h, u, g) + ops.mlp_bwd(dy, dy.bfloat16(), x, mean, rstd, ln_w, w2t, w1t, u, "bf16")
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = [t.clone() for t in got]
+        else:
+            for a, b in zip(ref, got):
+                assert torch.equal(a, b)
+    # sentinel rows behind every row-indexed output of the forward kernel
+    big = lambda cols, dt: torch.full((rows + pad, cols), 7.0, dtype=dt, device=DEV)  # noqa: E731
+    out_b, h_b, u_b, g_b = big(D, torch.float32), big(D, torch.bfloat16), big(M, torch.bfloat16), big(M, torch.bfloat16)
+    mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+    rt.check(rt.lib.sitk_mlp_fwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w1c.data_ptr(), b1.data_ptr(), w2c.data_ptr(),
+                                 b2.data_ptr(), h_b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), u_b.data_ptr(), g_b.data_ptr(),
+                                 out_b.data_ptr(), rows, D, M, rt.BF16, rt.stream_ptr()))
+    torch.cuda.synchronize()
+    for t, r in ((out_b, ref[0]), (h_b, ref[1]), (u_b, ref[2]), (g_b, ref[3])):
+        assert torch.equal(t[:rows], r)
+        assert bool((t[rows:].float() == 7.0).all())

@@ -1,7 +1,7 @@
 """Micro-benchmark of single hot-path kernels at the headline shapes (for rocprofv3 --pmc runs).
 
     python tools/kbench.py <kernel> [--reps 20] [--batch 64]
-kernels: wgrad_w1 wgrad_w2 wgrad_qkv wgrad_layer gemm_qkv gemm_fc1 gemm_fc2 gemm_dfc2 gemm_dfc1 attn_fwd attn_bwd ln_fwd ln_bwd
+kernels: wgrad_w1 wgrad_w2 wgrad_qkv wgrad_layer gemm_qkv gemm_fc1 gemm_fc2 gemm_dfc2 gemm_dfc1 attn_fwd attn_bwd ln_fwd ln_bwd mlp_fwd mlp_fwd_nosave mlp_bwd
 """
 import argparse
 import os
@@ -55,6 +55,9 @@ def main():
         "gemm_dfc1": lambda: ops.gemm_nt(u, w["w1_t"], out_h, dt),
         "attn_fwd": lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt),
         "attn_bwd": lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt),
+        "mlp_fwd": lambda: ops.mlp_fwd(x32, bD, bD, w["w1"], bM, w["w2"], bD, dt),
+        "mlp_fwd_nosave": lambda: ops.mlp_fwd(x32, bD, bD, w["w1"], bM, w["w2"], bD, dt, save=False),
+        "mlp_bwd": lambda: ops.mlp_bwd(x32, dxT, x32, mean, rstd, bD, w["w2_t"], w["w1_t"], u, dt),
         "ln_fwd": lambda: ops.layernorm_fwd(x32, bD, bD, dt),
         "ln_bwd": lambda: ops.layernorm_bwd(h, x32, mean, rstd, bD, x32, bD.clone(), bD.clone(), dt, dx=out_x),
     }
@@ -64,13 +67,23 @@ def main():
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    # GPU-paced timing: the launches are replayed from one hipGraph (host launch cost of the python wrappers
+    # would otherwise dominate kernels shorter than ~20 us)
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            for _ in range(a.reps):
+                fn()
+    graph.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(a.reps):
-        fn()
+    for _ in range(5):
+        graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    print(f"{a.kernel}: {e0.elapsed_time(e1) / a.reps * 1e3:.1f} us/call (host-paced)")
+    print(f"{a.kernel}: {e0.elapsed_time(e1) / (5 * a.reps) * 1e3:.1f} us/call (graph replay of {a.reps} launches)")
 
 
 if __name__ == "__main__":

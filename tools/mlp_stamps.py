@@ -1,0 +1,30 @@
+"""Per-phase cycle breakdown of the fused MLP forward kernel (diagnostic build, SITK_MLP_VAR=6)."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+os.environ["SITK_MLP_VAR"] = "6"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sitk  # noqa: E402,F401
+from sitk import ops, runtime as rt  # noqa: E402
+
+dev = "cuda:0"
+R, D, M = 64 * 321, 192, 768
+x = torch.randn(R, D, device=dev)
+w1 = (torch.randn(M, D, device=dev) * 0.07).bfloat16()
+w2 = (torch.randn(D, M, device=dev) * 0.04).bfloat16()
+b1, b2, lw, lb = torch.zeros(M, device=dev), torch.zeros(D, device=dev), torch.ones(D, device=dev), torch.zeros(D, device=dev)
+for _ in range(5):
+    ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, "bf16")
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * 64)()
+fn = rt.lib.sitk_mlp_debug_stamps
+fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
+assert fn(buf) == 0
+names = ["vmcnt wait", "barrier", "product 1", "elementwise", "product 2", "-", "-", "loop back"]
+print("cycles summed over the 12 chunks, workgroup 0 (s_memtime ticks):")
+for w in range(8):
+    print(f"wave {w}: " + "  ".join(f"{names[i]}={buf[w * 8 + i]}" for i in (7, 0, 1, 2, 3, 4)) +
+          f"  total={sum(buf[w * 8 + i] for i in range(8))}")
