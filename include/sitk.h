@@ -36,7 +36,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 2
+#define SITK_ABI_VERSION 3
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -171,7 +171,8 @@ int sitk_layernorm_bwd(const void* dy, const float* x, const float* mean, const 
  *     u (rows, M) `dtype` pre-activation; g = gelu(u) (rows, M) `dtype` only when asked for.
  *   backward: dx = dy + LN'(dh), dh = du W1, du = (dy W2) * gelu'(u)
  *     dy fp32 + dy_c its `dtype` copy; x/mean/rstd/u as saved; w2t_c = W2^T (M, D), w1t_c = W1^T (D, M);
- *     writes du and g = gelu(u) (rows, M) `dtype` (operands of the two weight gradients), dx fp32 and
+ *     writes du and (when g != NULL) g = gelu(u) (rows, M) `dtype` -- the operands of the two weight
+ *     gradients; pass NULL when forward saved g --, dx fp32 and
  *     dx_c its `dtype` copy, and per-workgroup LayerNorm dgamma/dbeta sums to `partials`
  *     (sitk_mlp_bwd_partial_floats(rows) floats, layout [workgroup][2][D], workgroup = 128 rows).   */
 int sitk_mlp_fused_supported(int D, int M, int dtype);
@@ -183,6 +184,23 @@ int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float*
                  const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,
                  float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
                  sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused LayerNorm + bias-free projection of the attention half of a block, PreNorm(LayerNorm, Attention)
+ * up to to_qkv (state-dict keys transformer.layers.i.0.{norm, fn.to_qkv}, utils/utils.py:18-24), one
+ * launch per direction.  Specialised: dtype bf16, D == 192, N % 64 == 0 (sitk_ln_gemm_fused_supported).
+ *   forward : y = LN(x) W^T          x (rows, D) fp32, w_c (N, D) `dtype`, y (rows, N) `dtype`;
+ *             saved (each may be NULL): h = LN(x) (rows, D) `dtype`, mean/rstd (rows) fp32
+ *   backward: dx = dres + LN'(dy W)  dy (rows, N) `dtype`, wt_c = W^T (D, N) `dtype`, dres fp32 (may be NULL),
+ *             dx fp32 and dx_c its `dtype` copy (may be NULL); per-workgroup dgamma/dbeta sums go to
+ *             `partials` (sitk_ln_gemm_bwd_partial_floats(rows) floats, [workgroup][2][D], 128 rows each) */
+int sitk_ln_gemm_fused_supported(int D, int N, int dtype);
+int sitk_ln_gemm_fwd(const float* x, const float* ln_w, const float* ln_b, const void* w_c, void* h, float* mean,
+                     float* rstd, void* y, int64_t rows, int D, int N, int dtype, sitk_stream_t stream);
+size_t sitk_ln_gemm_bwd_partial_floats(int64_t rows);
+int sitk_ln_gemm_bwd(const void* dy, const void* wt_c, const float* x, const float* mean, const float* rstd,
+                     const float* ln_w, const float* dres, float* dx, void* dx_c, float* partials, int64_t rows,
+                     int D, int N, int dtype, sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-head self-attention core of vit_pytorch.vit.Attention (dim_head = 64):

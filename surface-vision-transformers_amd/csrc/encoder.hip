@@ -3,6 +3,7 @@
 // (no allocation, no sync): 7 launches per layer forward, 13 backward, plus one weight-staging
 // launch per 12 layers.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -87,6 +88,11 @@ struct Layout {
 
 // the fused LayerNorm + MLP kernels (mlp_fused.hip) cover the bf16 tiny shape
 static bool mlp_fused(const sitk_encoder_cfg& c) { return sitk_mlp_fused_supported(c.dim, c.mlp_dim, c.dtype) != 0; }
+// gelu(u) is stored by the fused forward (the stores hide under its VALU-bound loop) rather than recomputed
+// and re-stored by the fused backward, whose loop carries more memory traffic: 0.7 % of the step, measured.
+static bool g_in_fwd() { return true; }
+// the fused LayerNorm + to_qkv kernels (ln_gemm_fused.hip)
+static bool qkv_fused(const sitk_encoder_cfg& c) { return sitk_ln_gemm_fused_supported(c.dim, 3 * c.heads * 64, c.dtype) != 0; }
 
 static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) {
   Layout L;
@@ -111,7 +117,7 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
     a.xmid = (float*)take(R * D * 4);
     a.h1 = take(R * D * es); a.qkv = take(R * 3 * I * es); a.o = take(R * I * es);
     a.h2 = take(R * D * es); a.u = take(R * M * es);
-    a.g = mlp_fused(c) ? nullptr : take(R * M * es);   // the fused MLP recomputes gelu(u) in backward
+    a.g = (mlp_fused(c) && !g_in_fwd()) ? nullptr : take(R * M * es);   // the fused MLP recomputes gelu(u) in backward
   }
   L.acts_bytes = off;
   off = 0;
@@ -233,15 +239,19 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     const void* w2 = f32 ? (const void*)P[l].w2 : w.w2_c;
     float* xnext = (l == c.depth - 1) ? x_out : (save ? L.layers[l + 1].x_in : ((l & 1) ? L.scratch.pong : L.scratch.ping));
 
-    SITK_TRY(sitk_layernorm_fwd(x, P[l].ln1_w, P[l].ln1_b, a.h1, a.mean1, a.rstd1, R, D, dt, stream));
-    sitk_gemm_desc g1 = gemm_desc(R, 3 * I, D, a.h1, D, 0, wqkv, SITK_EPI_STORE, a.qkv, 3 * I, 0);
-    SITK_TRY(sitk_gemm_nt(&g1, dt, stream));
+    if (qkv_fused(c)) {
+      SITK_TRY(sitk_ln_gemm_fwd(x, P[l].ln1_w, P[l].ln1_b, wqkv, a.h1, a.mean1, a.rstd1, a.qkv, R, D, 3 * I, dt, stream));
+    } else {
+      SITK_TRY(sitk_layernorm_fwd(x, P[l].ln1_w, P[l].ln1_b, a.h1, a.mean1, a.rstd1, R, D, dt, stream));
+      sitk_gemm_desc g1 = gemm_desc(R, 3 * I, D, a.h1, D, 0, wqkv, SITK_EPI_STORE, a.qkv, 3 * I, 0);
+      SITK_TRY(sitk_gemm_nt(&g1, dt, stream));
+    }
     SITK_TRY(sitk_attention_fwd(a.qkv, a.o, a.lse, c.B, c.N, c.heads, scale, dt, stream));
     sitk_gemm_desc g2 = gemm_desc(R, D, I, a.o, I, 0, wo, SITK_EPI_BIAS_RES, a.xmid, D, 1);
     g2.bias = P[l].bo; g2.aux = x; g2.ldaux = D;
     SITK_TRY(sitk_gemm_nt(&g2, dt, stream));
     if (mlp_fused(c)) {
-      SITK_TRY(sitk_mlp_fwd(a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2, a.mean2, a.rstd2, a.u, nullptr,
+      SITK_TRY(sitk_mlp_fwd(a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2, a.mean2, a.rstd2, a.u, save ? a.g : nullptr,
                             xnext, R, D, M, dt, stream));
       x = xnext;
       continue;
@@ -288,10 +298,10 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     float* part2 = S.ln_partials + (size_t)(2 * l + 1) * S.ln_partial_floats;
     const void* gact = a.g;
     if (mlp_fused(c)) {
-      SITK_TRY(sitk_mlp_bwd(dx, S.dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, S.du, S.g, S.dxB, S.dxBc,
+      SITK_TRY(sitk_mlp_bwd(dx, S.dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, S.du, a.g ? nullptr : S.g, S.dxB, S.dxBc,
                             part2, R, D, M, dt, stream));
       ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, cdiv(R, 128)});
-      gact = S.g;
+      gact = a.g ? a.g : S.g;
     } else {
       sitk_gemm_desc d1 = gemm_desc(R, M, D, S.dxAc, D, 0, a.w2_t, SITK_EPI_DGELU, S.du, M, 0);
       d1.aux = a.u; d1.ldaux = M;
@@ -313,11 +323,17 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
         wgrad_desc(R, 3 * I, D, S.dqkv, 0, a.h1, G[l].wqkv, nullptr),
     };
     SITK_TRY(sitk_gemm_wgrad_group_ws(wg, 4, dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
-    sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, S.dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
-    SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
     float* part1 = S.ln_partials + (size_t)(2 * l) * S.ln_partial_floats;
-    SITK_TRY(layernorm_bwd_deferred(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, part1, R, D, dt, hs));
-    ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, 0});
+    if (qkv_fused(c)) {
+      SITK_TRY(sitk_ln_gemm_bwd(S.dqkv, a.wqkv_t, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, part1, R, D, 3 * I, dt,
+                                stream));
+      ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, cdiv(R, 128)});
+    } else {
+      sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, S.dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
+      SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
+      SITK_TRY(layernorm_bwd_deferred(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, part1, R, D, dt, hs));
+      ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, 0});
+    }
   }
   // every LayerNorm parameter gradient of the slice in one reduction launch
   return layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs);

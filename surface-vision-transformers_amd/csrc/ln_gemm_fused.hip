@@ -1,0 +1,436 @@
+// sitk fused LayerNorm + projection kernels of the attention half of an encoder block (bf16, dim = 192):
+//
+//   forward   h = LayerNorm(x) ;  y = h W^T                      layers.i.0.norm + layers.i.0.fn.to_qkv (no bias)
+//   backward  dh = dy W ;  dx = dres + LayerNorm'(dh)             + per-workgroup dgamma / dbeta partials
+//
+// They are the two halves of the fused MLP kernel (mlp_fused.hip) taken apart: forward is its LayerNorm
+// prologue + FIRST product with the accumulators stored instead of chained; backward is its SECOND product
+// (B operand streamed from HBM instead of produced in registers) + LayerNorm-backward epilogue.  Same
+// geometry: a workgroup owns 128 tokens, wave (tg, hh) = 32 tokens x one half of every 64-wide chunk of the
+// streamed dimension; weight chunks (24 KB) travel global -> LDS by LDS-DMA through a 2-slot ring with one
+// raw barrier per chunk; fragment reads sit in asm blocks and are software pipelined (see mlp_fused.hip for
+// the layouts, the slot permutation that makes a lane's 8 accumulator values consecutive features, the
+// buffer-descriptor row I/O and the store keep-alive).  One launch replaces LayerNorm + GEMM (forward) or
+// GEMM + LayerNorm backward (backward) and the (tokens x 192) round trip through HBM between them.
+#include "common.h"
+
+namespace sitk {
+
+struct LnGemmParams {
+  // forward                                   backward
+  const float* x;      // (R,192) layer input            | same (saved)
+  const float* gamma;  // LayerNorm weight
+  const float* beta;   // LayerNorm bias                  | unused
+  const bf16* w;       // W (N,192), N = 3 heads 64       | W^T (192,N)
+  bf16* h;             // (R,192) LN output, saved        | unused
+  float* mean;         // (R) written                     | read
+  float* rstd;
+  bf16* y;             // (R,N) written                   | dy (R,N) read
+  const float* dres;   // -                               | (R,192) fp32 residual gradient added to LN'(dh)
+  float* dx;           // -                               | (R,192) fp32
+  bf16* dxc;           // -                               | (R,192) compute-dtype copy of dx
+  float* partials;     // -                               | (gridDim.x, 2, 192)
+  int R, N;
+};
+
+constexpr int LG_D = 192;
+constexpr int LG_WB = 24576;                   // one weight chunk: 24 pieces of 8 rows x 128 B
+constexpr int LG_OFF_H = 2 * LG_WB;            // forward: operand strip 3 k-panels x 128 rows x 128 B = 48 KB
+constexpr int LG_SMEM_FWD = LG_OFF_H + 3 * 128 * 128;
+constexpr int LG_CP = 2 * LG_D + 4;            // backward: column-sum pitch (floats)
+constexpr int LG_OFF_RED = 64 * LG_CP * 4;     // backward: row-sum exchange area behind the column sums
+constexpr int LG_SMEM_BWD = LG_OFF_RED + 2048;
+
+SITK_DEV uint32_t lg_pack_bf16(float a, float b) {
+  bf16x2 v;
+  v[0] = (bf16)a; v[1] = (bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+SITK_DEV __amdgpu_buffer_rsrc_t lg_rsrc(const void* p, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+#define SITK_LG_WAIT_ISSUE4(c0, c1, c2, c3, n0, n1, n2, n3, aA, aB, oA0, oA1, oB0, oB1)                     \
+  asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                  \
+               "ds_read_b128 %4, %8 offset:" #oA0 "\n\tds_read_b128 %5, %8 offset:" #oA1 "\n\t"            \
+               "ds_read_b128 %6, %9 offset:" #oB0 "\n\tds_read_b128 %7, %9 offset:" #oB1                   \
+               : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)        \
+               : "v"(aA), "v"(aB)                                                                          \
+               : "memory")
+#define SITK_LG_ISSUE4(n0, n1, n2, n3, aA, aB, oA0, oA1, oB0, oB1)                                          \
+  asm volatile("ds_read_b128 %0, %4 offset:" #oA0 "\n\tds_read_b128 %1, %4 offset:" #oA1 "\n\t"            \
+               "ds_read_b128 %2, %5 offset:" #oB0 "\n\tds_read_b128 %3, %5 offset:" #oB1                   \
+               : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)                                                \
+               : "v"(aA), "v"(aB)                                                                          \
+               : "memory")
+#define SITK_LG_WAIT4(c0, c1, c2, c3)                                                                       \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "memory")
+
+// ------------------------------------------------------------------------------------------------------
+// forward: y = LayerNorm(x) W^T
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
+  constexpr int D = LG_D;
+  __shared__ __attribute__((aligned(256))) char smem[LG_SMEM_FWD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tg = wave >> 1, hh = wave & 1;
+  const int blk0 = blockIdx.x * 128;
+  const int N = p.N, nchunks = N / 64;
+
+  // ---- W chunk DMA: 24 pieces of 8 slot rows x 128 B (3 k-panels x 64 rows), 3 per wave.  Slot row
+  //      32 hs + 16 it + r holds output feature 32 hs + 8 (r >> 2) + 4 it + (r & 3) of the chunk ----
+  const int r8 = lane >> 3;
+  int soff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int qq = wave * 3 + i;
+    const int kt = qq >> 3, s = (qq & 7) * 8 + r8;
+    const int r = s & 15, it = (s >> 4) & 1, hs = s >> 5;
+    const int feat = 32 * hs + 8 * (r >> 2) + 4 * it + (r & 3);
+    const int key = ((s >> 1) & 1) | (((s >> 3) & 1) << 1);
+    soff[i] = feat * D + kt * 64 + (((lane & 7) ^ (key << 1)) * 8);
+  }
+  auto issue = [&](int c, int buf) {
+    char* base = smem + buf * LG_WB + wave * 3 * 1024;
+    const bf16* src = p.w + (size_t)c * 64 * D;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+  };
+  issue(0, 0);
+
+  // per-workgroup buffer descriptors (see mlp_fused.hip): rows past R read 0 / are not written
+  const size_t nrows = (size_t)(p.R - blk0 < 128 ? p.R - blk0 : 128);
+  const size_t RD = nrows * D, oD = (size_t)blk0 * D;
+  const __amdgpu_buffer_rsrc_t r_x = lg_rsrc(p.x + oD, RD * 4);
+  const __amdgpu_buffer_rsrc_t r_h = lg_rsrc(p.h + oD, p.h ? RD * 2 : 0);
+  const __amdgpu_buffer_rsrc_t r_y = lg_rsrc(p.y + (size_t)blk0 * N, nrows * N * 2);
+
+  // ---- LayerNorm of the block's rows: wave = 16 rows, 16 lanes per row, 4 rows per pass, all loads in flight ----
+  char* sH = smem + LG_OFF_H;
+  {
+    const int j = lane & 15, sub = lane >> 4;
+    f32x4 gm[3], bt[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gm[i] = load4(p.gamma + 4 * (j + 16 * i)); bt[i] = load4(p.beta + 4 * (j + 16 * i)); }
+    f32x4 v[4][3];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        v[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int r = wave * 16 + pass * 4 + sub, row = blk0 + r;
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) s += v[pass][i][0] + v[pass][i][1] + v[pass][i][2] + v[pass][i][3];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mu = s * (1.0f / D);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[pass][i][e] - mu; ss += d * d; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      const float rs = rsqrtf(ss * (1.0f / D) + 1e-5f);
+      const bool ok = row < p.R;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c4 = j + 16 * i;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ok ? (v[pass][i][e] - mu) * rs * gm[i][e] + bt[i][e] : 0.f;
+        const int byte = c4 * 8;
+        const u32x2 ob = {lg_pack_bf16(o[0], o[1]), lg_pack_bf16(o[2], o[3])};
+        *reinterpret_cast<u32x2*>(sH + (byte >> 7) * (128 * 128) + lds_off(r, byte & 127)) = ob;
+        if (p.h) __builtin_amdgcn_raw_buffer_store_b64(ob, r_h, (r * D + 4 * c4) * 2, 0, 0);
+      }
+      if (ok && j == 0 && p.mean) { p.mean[row] = mu; p.rstd[row] = rs; }
+    }
+    __syncthreads();
+  }
+  u32x4 hf[2][6];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      hf[t][k] = *reinterpret_cast<const u32x4*>(sH + (k >> 1) * (128 * 128) +
+                                                 lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
+
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
+  uint32_t aw[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) aw[ks] = lbase + (32 * hh + fr) * 128 + ((ks * 64 + fq * 16) ^ (keyl << 5));
+  const int vo[2] = {((32 * tg + fr) * N + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * N + 32 * hh + 8 * fq) * 2};
+
+  for (int c = 0; c < nchunks; ++c) {
+    // chunk c's DMA precedes the previous iteration's 2 stores (pinned by the "memory" clobbers)
+    if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint32_t bo = (c & 1) * LG_WB;
+    const uint32_t a0 = aw[0] + bo, a1 = aw[1] + bo;
+    u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
+    SITK_LG_ISSUE4(x0, x1, x2, x3, a0, a1, 0, 2048, 0, 2048);
+    if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#define SITK_LG_MMAS(KT, f0, f1, f2, f3)                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    acc[0][0] = Mma<bf16>::mma(f0, hf[0][2 * KT], acc[0][0]);                                               \
+    acc[0][1] = Mma<bf16>::mma(f0, hf[1][2 * KT], acc[0][1]);                                               \
+    acc[1][0] = Mma<bf16>::mma(f1, hf[0][2 * KT], acc[1][0]);                                               \
+    acc[1][1] = Mma<bf16>::mma(f1, hf[1][2 * KT], acc[1][1]);                                               \
+    acc[0][0] = Mma<bf16>::mma(f2, hf[0][2 * KT + 1], acc[0][0]);                                           \
+    acc[0][1] = Mma<bf16>::mma(f2, hf[1][2 * KT + 1], acc[0][1]);                                           \
+    acc[1][0] = Mma<bf16>::mma(f3, hf[0][2 * KT + 1], acc[1][0]);                                           \
+    acc[1][1] = Mma<bf16>::mma(f3, hf[1][2 * KT + 1], acc[1][1]);                                           \
+    __builtin_amdgcn_sched_barrier(0);
+    SITK_LG_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a0, a1, 8192, 10240, 8192, 10240);
+    SITK_LG_MMAS(0, x0, x1, x2, x3)
+    SITK_LG_WAIT_ISSUE4(y0, y1, y2, y3, x0, x1, x2, x3, a0, a1, 16384, 18432, 16384, 18432);
+    SITK_LG_MMAS(1, y0, y1, y2, y3)
+    SITK_LG_WAIT4(x0, x1, x2, x3);
+    SITK_LG_MMAS(2, x0, x1, x2, x3)
+#undef SITK_LG_MMAS
+    // lane holds features c*64 + 32 hh + 8 fq + 4 i + e of token 32 tg + 16 t + fr: one 16-byte store per tile
+    u32x4 sd[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const f32x4 v0 = acc[0][t], v1 = acc[1][t];
+      sd[t] = u32x4{lg_pack_bf16(v0[0], v0[1]), lg_pack_bf16(v0[2], v0[3]), lg_pack_bf16(v1[0], v1[1]), lg_pack_bf16(v1[2], v1[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_y, vo[t], c * 128, 0);
+    }
+    asm volatile("" : : "v"(sd[0]), "v"(sd[1]));             // store keep-alive (mlp_fused.hip)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward: dx = dres + LayerNorm'(dy W)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void ln_gemm_bwd_kernel(LnGemmParams p) {
+  constexpr int D = LG_D;
+  __shared__ __attribute__((aligned(256))) char smem[LG_SMEM_BWD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int tg = wave >> 1, hh = wave & 1;
+  const int blk0 = blockIdx.x * 128;
+  const int N = p.N, nchunks = N / 64;
+
+  // ---- W^T chunk DMA: 192 rows x 64 k (128 B), 24 pieces of 8 rows, 3 per wave ----
+  const int r8 = lane >> 3;
+  int soff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int row = (wave * 3 + i) * 8 + r8;
+    const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    soff[i] = row * N + (((lane & 7) ^ (key << 1)) * 8);
+  }
+  auto issue = [&](int c, int buf) {
+    char* base = smem + buf * LG_WB + wave * 3 * 1024;
+    const bf16* src = p.w + (size_t)c * 64;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+  };
+
+  const size_t nrows = (size_t)(p.R - blk0 < 128 ? p.R - blk0 : 128);
+  const __amdgpu_buffer_rsrc_t r_y = lg_rsrc(p.y + (size_t)blk0 * N, nrows * N * 2);
+  const int vo[2] = {((32 * tg + fr) * N + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * N + 32 * hh + 8 * fq) * 2};
+  // B fragments of chunk c: the lane's 8 consecutive k of token tile t, fetched one chunk ahead (before the DMA)
+  u32x4 bn[2];
+  bn[0] = __builtin_amdgcn_raw_buffer_load_b128(r_y, vo[0], 0, 0);
+  bn[1] = __builtin_amdgcn_raw_buffer_load_b128(r_y, vo[1], 0, 0);
+  issue(0, 0);
+
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
+  const uint32_t aw2 = lbase + fr * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));        // + dt*2048 (+ buffer)
+
+  f32x4 yacc[12][2];
+#pragma unroll
+  for (int dt = 0; dt < 12; ++dt) { yacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; yacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int c = 0; c < nchunks; ++c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk c: W piece DMA and B fragments
+    __builtin_amdgcn_s_barrier();
+    const u32x4 pf[2] = {bn[0], bn[1]};
+    const uint32_t a2 = aw2 + (c & 1) * LG_WB;
+    u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
+    SITK_LG_ISSUE4(y0, y1, y2, y3, a2, a2, 0, 2048, 4096, 6144);
+    if (c + 1 < nchunks) {
+      bn[0] = __builtin_amdgcn_raw_buffer_load_b128(r_y, vo[0], (c + 1) * 128, 0);
+      bn[1] = __builtin_amdgcn_raw_buffer_load_b128(r_y, vo[1], (c + 1) * 128, 0);
+      issue(c + 1, (c + 1) & 1);
+    }
+#define SITK_LG_MMAS2(J, f0, f1, f2, f3)                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    yacc[4 * J + 0][0] = Mma<bf16>::mma(f0, pf[0], yacc[4 * J + 0][0]);                                     \
+    yacc[4 * J + 0][1] = Mma<bf16>::mma(f0, pf[1], yacc[4 * J + 0][1]);                                     \
+    yacc[4 * J + 1][0] = Mma<bf16>::mma(f1, pf[0], yacc[4 * J + 1][0]);                                     \
+    yacc[4 * J + 1][1] = Mma<bf16>::mma(f1, pf[1], yacc[4 * J + 1][1]);                                     \
+    yacc[4 * J + 2][0] = Mma<bf16>::mma(f2, pf[0], yacc[4 * J + 2][0]);                                     \
+    yacc[4 * J + 2][1] = Mma<bf16>::mma(f2, pf[1], yacc[4 * J + 2][1]);                                     \
+    yacc[4 * J + 3][0] = Mma<bf16>::mma(f3, pf[0], yacc[4 * J + 3][0]);                                     \
+    yacc[4 * J + 3][1] = Mma<bf16>::mma(f3, pf[1], yacc[4 * J + 3][1]);                                     \
+    __builtin_amdgcn_sched_barrier(0);
+    SITK_LG_WAIT_ISSUE4(y0, y1, y2, y3, x0, x1, x2, x3, a2, a2, 8192, 10240, 12288, 14336);
+    SITK_LG_MMAS2(0, y0, y1, y2, y3)
+    SITK_LG_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a2, a2, 16384, 18432, 20480, 22528);
+    SITK_LG_MMAS2(1, x0, x1, x2, x3)
+    SITK_LG_WAIT4(y0, y1, y2, y3);
+    SITK_LG_MMAS2(2, y0, y1, y2, y3)
+#undef SITK_LG_MMAS2
+  }
+
+  // ---- pair exchange: wave hh finishes features [96 hh, 96 hh + 96) (12 tiles x 1 KB per wave) ----
+  __syncthreads();
+  {
+    char* mine = smem + wave * 12288;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        *reinterpret_cast<f32x4*>(mine + ((i * 2 + t) * 64 + lane) * 16) = hh ? yacc[i][t] : yacc[6 + i][t];
+  }
+  __syncthreads();
+  f32x4 v[6][2];
+  {
+    const char* theirs = smem + (wave ^ 1) * 12288;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + ((i * 2 + t) * 64 + lane) * 16);
+        v[i][t] = (hh ? yacc[6 + i][t] : yacc[i][t]) + o;
+      }
+  }
+  const int n0 = 96 * hh + 4 * fq;
+  const int trow0 = blk0 + 32 * tg + fr, trow1 = trow0 + 16;
+
+  // ---- LayerNorm backward on dh = v:  dx = dres + rstd (dh gamma - mean(dh gamma) - xhat mean(dh gamma xhat)) ----
+  float* red = reinterpret_cast<float*>(smem + LG_OFF_RED);    // [wave][t][16 tokens][2] row sums
+  f32x4 gmv[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) gmv[i] = load4(p.gamma + n0 + 16 * i);
+  f32x4 xh[6][2];
+  float mu[2], rs[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = t ? trow1 : trow0;
+    const bool ok = row < p.R;
+    mu[t] = ok ? p.mean[row] : 0.f;
+    rs[t] = ok ? p.rstd[row] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const f32x4 xv = ok ? load4(p.x + (size_t)row * D + n0 + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[i][t][e] = (xv[e] - mu[t]) * rs[t];
+        const float gy = v[i][t][e] * gmv[i][e];
+        s1 += gy;
+        s2 += gy * xh[i][t][e];
+      }
+    }
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (fq == 0) { red[((wave * 2 + t) * 16 + fr) * 2] = s1; red[((wave * 2 + t) * 16 + fr) * 2 + 1] = s2; }
+  }
+  __syncthreads();
+  f32x4 dgs[6], dbs[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { dgs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int row = t ? trow1 : trow0;
+    const bool ok = row < p.R;
+    const float o1 = red[(((wave ^ 1) * 2 + t) * 16 + fr) * 2], o2 = red[(((wave ^ 1) * 2 + t) * 16 + fr) * 2 + 1];
+    const float m1 = (red[((wave * 2 + t) * 16 + fr) * 2] + o1) * (1.0f / D);
+    const float m2 = (red[((wave * 2 + t) * 16 + fr) * 2 + 1] + o2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int n = n0 + 16 * i;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = rs[t] * (v[i][t][e] * gmv[i][e] - m1 - xh[i][t][e] * m2);
+        dgs[i][e] += v[i][t][e] * xh[i][t][e];                 // rows past R carry v = 0 (zero B fragments)
+        dbs[i][e] += v[i][t][e];
+      }
+      if (ok) {
+        if (p.dres) o += load4(p.dres + (size_t)row * D + n);
+        store4(p.dx + (size_t)row * D + n, o);
+        if (p.dxc) store4(p.dxc + (size_t)row * D + n, o);
+      }
+    }
+  }
+  // column sums over the block's 128 tokens (see mlp_fused.hip)
+  __syncthreads();                                             // everybody has read the exchange area
+  float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    *reinterpret_cast<f32x4*>(cs + (tg * 16 + fr) * LG_CP + n0 + 16 * i) = dgs[i];
+    *reinterpret_cast<f32x4*>(cs + (tg * 16 + fr) * LG_CP + D + n0 + 16 * i) = dbs[i];
+  }
+  __syncthreads();
+  if (tid < 2 * D) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) s += cs[r * LG_CP + tid];
+    p.partials[(size_t)blockIdx.x * 2 * D + tid] = s;
+  }
+}
+
+static int lg_check(const char* what, int64_t rows, int D, int N, int dtype) {
+  SITK_REQUIRE(dtype == SITK_BF16 && D == LG_D && N % 64 == 0 && N >= 64 && rows > 0 && rows * (int64_t)N < (1ll << 30),
+               "%s: the fused path is specialised for bf16, dim 192, N %% 64 == 0 (got dtype %d dim %d N %d)", what, dtype, D, N);
+  return SITK_OK;
+}
+
+}  // namespace sitk
+
+using namespace sitk;
+
+extern "C" int sitk_ln_gemm_fused_supported(int D, int N, int dtype) {
+  return dtype == SITK_BF16 && D == LG_D && N % 64 == 0 && N >= 64;
+}
+
+extern "C" int sitk_ln_gemm_fwd(const float* x, const float* ln_w, const float* ln_b, const void* w_c, void* h, float* mean,
+                                float* rstd, void* y, int64_t rows, int D, int N, int dtype, sitk_stream_t stream) {
+  SITK_REQUIRE(x && ln_w && ln_b && w_c && y, "ln_gemm_fwd: null pointer");
+  SITK_REQUIRE((mean == nullptr) == (rstd == nullptr), "ln_gemm_fwd: mean and rstd go together");
+  SITK_TRY(lg_check("ln_gemm_fwd", rows, D, N, dtype));
+  LnGemmParams p = {};
+  p.x = x; p.gamma = ln_w; p.beta = ln_b; p.w = reinterpret_cast<const bf16*>(w_c);
+  p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd; p.y = reinterpret_cast<bf16*>(y);
+  p.R = (int)rows; p.N = N;
+  hipLaunchKernelGGL(ln_gemm_fwd_kernel, dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("ln_gemm_fwd");
+}
+
+extern "C" size_t sitk_ln_gemm_bwd_partial_floats(int64_t rows) { return rows > 0 ? (size_t)cdiv64(rows, 128) * 2 * LG_D : 0; }
+
+extern "C" int sitk_ln_gemm_bwd(const void* dy, const void* wt_c, const float* x, const float* mean, const float* rstd,
+                                const float* ln_w, const float* dres, float* dx, void* dx_c, float* partials, int64_t rows,
+                                int D, int N, int dtype, sitk_stream_t stream) {
+  SITK_REQUIRE(dy && wt_c && x && mean && rstd && ln_w && dx && partials, "ln_gemm_bwd: null pointer");
+  SITK_TRY(lg_check("ln_gemm_bwd", rows, D, N, dtype));
+  LnGemmParams p = {};
+  p.x = x; p.gamma = ln_w; p.w = reinterpret_cast<const bf16*>(wt_c);
+  p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
+  p.y = const_cast<bf16*>(reinterpret_cast<const bf16*>(dy));
+  p.dres = dres; p.dx = dx; p.dxc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
+  p.R = (int)rows; p.N = N;
+  hipLaunchKernelGGL(ln_gemm_bwd_kernel, dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("ln_gemm_bwd");
+}

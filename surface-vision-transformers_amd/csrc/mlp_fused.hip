@@ -262,9 +262,26 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   const uint32_t ab1 = lbase + MLP_OFF_B1 + (32 * hh + 8 * fq) * 4;                   // + c*256
   const uint32_t ltabf = lbase + MLP_OFF_TAB_F, ltabb = lbase + MLP_OFF_TAB_B;
 
+  // Accumulators of the second product.  Forward starts the half this wave will finish at x + b2, so the
+  // residual rides through the pair exchange and the epilogue never re-reads x (the rows are L2-hot here:
+  // the LayerNorm above has just read them).
   f32x4 yacc[12][2];
 #pragma unroll
   for (int dt = 0; dt < 12; ++dt) { yacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; yacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if constexpr (!BWD) {
+    const __amdgpu_buffer_rsrc_t r_x2 = make_rsrc(p.x + oD, RD * 4);
+    const int nb = 96 * hh + 4 * fq;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const f32x4 bb = load4(p.b2 + nb + 16 * i);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            r_x2, ((32 * tg + 16 * t + fr) * D + nb + 16 * i) * 4, 0, 0));
+        if (hh) yacc[6 + i][t] = xv + bb; else yacc[i][t] = xv + bb;
+      }
+    }
+  }
 
   // (rows x M) operands: lane's 16 bytes of token tile t sit at vo[t] + (block, chunk) scalar offset
   const int trow0 = blk0 + 32 * tg + fr, trow1 = trow0 + 16;
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   // its elementwise phase while the other is still in its MFMAs, and the phases interleave from there.
   if (VAR != 5 && wave < 4) __builtin_amdgcn_s_setprio(2);
   // global stores each wave issues per chunk after the next chunk's DMA
-  const int nstores = BWD ? 4 : (p.u ? 2 : 0) + (p.g ? 2 : 0);
+  const int nstores = BWD ? (p.g ? 4 : 2) : (p.u ? 2 : 0) + (p.g ? 2 : 0);
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define SITK_STAMP(i)                                                                    \
   if constexpr (VAR == 6) {                                                              \
@@ -424,7 +441,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
         pf[t] = u32x4{pack_bf16(dv[0], dv[1]), pack_bf16(dv[2], dv[3]), pack_bf16(dv[4], dv[5]), pack_bf16(dv[6], dv[7])};
         sd[t] = u32x4{pack_bf16(gv[0], gv[1]), pack_bf16(gv[2], gv[3]), pack_bf16(gv[4], gv[5]), pack_bf16(gv[6], gv[7])};
         __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_du, vo[t], so, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_g, vo[t], so, 0);
+        if (p.g) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_g, vo[t], so, 0);
       }
     }
 
@@ -487,16 +504,13 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   const int n0 = 96 * hh + 4 * fq;                             // + 16 i : this lane's 4 features of tile i
 
   if constexpr (!BWD) {
-    // out = v + b2 + x
+    // out = v (x + b2 entered through the accumulator start values)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = t ? trow1 : trow0;
       if (row < p.R) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          const int n = n0 + 16 * i;
-          store4(p.out + (size_t)row * D + n, v[i][t] + load4(p.b2 + n) + load4(p.x + (size_t)row * D + n));
-        }
+        for (int i = 0; i < 6; ++i) store4(p.out + (size_t)row * D + n0 + 16 * i, v[i][t]);
       }
     }
   } else {
@@ -628,7 +642,7 @@ extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, c
                             const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,
                             float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
                             sitk_stream_t stream) {
-  SITK_REQUIRE(dy && dy_c && x && mean && rstd && ln_w && w2t_c && w1t_c && u && du && g && dx && dx_c && partials,
+  SITK_REQUIRE(dy && dy_c && x && mean && rstd && ln_w && w2t_c && w1t_c && u && du && dx && dx_c && partials,
                "mlp_bwd: null pointer");
   SITK_TRY(mlp_check("mlp_bwd", rows, D, M, dtype));
   MlpParams p = {};

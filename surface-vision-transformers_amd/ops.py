@@ -217,6 +217,41 @@ def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, dtype):
     return dx, dx_c, du, g, partials.view(-1, 2, D)
 
 
+# ---- fused LayerNorm + to_qkv ----------------------------------------------------------------------
+def ln_gemm_fused_supported(D, N, dtype):
+    return bool(rt.lib.sitk_ln_gemm_fused_supported(D, N, rt.dtype_code(dtype)))
+
+
+def ln_gemm_fwd(x, ln_w, ln_b, w_c, dtype, save=True):
+    """y = LN(x) W^T; returns (y, h, mean, rstd)"""
+    rt.require_cuda(x, ln_w, ln_b, w_c)
+    rows, D = x.shape
+    N = w_c.shape[0]
+    code = rt.dtype_code(dtype)
+    td = rt.torch_dtype(code)
+    y = torch.empty((rows, N), dtype=td, device=x.device)
+    h = torch.empty((rows, D), dtype=td, device=x.device) if save else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    rt.check(rt.lib.sitk_ln_gemm_fwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w_c.data_ptr(), rt.ptr(h), rt.ptr(mean),
+                                     rt.ptr(rstd), y.data_ptr(), rows, D, N, code, rt.stream_ptr()))
+    return y, h, mean, rstd
+
+
+def ln_gemm_bwd(dy, wt_c, x, mean, rstd, ln_w, dres, dtype):
+    """dx = dres + LN'(dy W); returns (dx, dx_c, partials (workgroups, 2, D))"""
+    rows, D = x.shape
+    N = dy.shape[1]
+    code = rt.dtype_code(dtype)
+    dx = torch.empty_like(x)
+    dx_c = torch.empty((rows, D), dtype=dy.dtype, device=x.device)
+    partials = torch.empty(rt.lib.sitk_ln_gemm_bwd_partial_floats(rows), dtype=torch.float32, device=x.device)
+    rt.check(rt.lib.sitk_ln_gemm_bwd(dy.data_ptr(), wt_c.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     ln_w.data_ptr(), rt.ptr(dres), dx.data_ptr(), dx_c.data_ptr(), partials.data_ptr(), rows,
+                                     D, N, code, rt.stream_ptr()))
+    return dx, dx_c, partials.view(-1, 2, D)
+
+
 # ---- attention -------------------------------------------------------------------------------------
 def attention_fwd(qkv, B, N, H, scale, dtype):
     code = rt.dtype_code(dtype)

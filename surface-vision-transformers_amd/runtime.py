@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libsitk.so")
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SitkError(RuntimeError):
@@ -75,6 +75,10 @@ _SIGS = {
     "sitk_mlp_fwd": (C.c_int, [_P] * 13 + [_L, _I, _I, _I, _P]),
     "sitk_mlp_bwd_partial_floats": (_Z, [_L]),
     "sitk_mlp_bwd": (C.c_int, [_P] * 14 + [_L, _I, _I, _I, _P]),
+    "sitk_ln_gemm_fused_supported": (C.c_int, [_I, _I, _I]),
+    "sitk_ln_gemm_fwd": (C.c_int, [_P] * 8 + [_L, _I, _I, _I, _P]),
+    "sitk_ln_gemm_bwd_partial_floats": (_Z, [_L]),
+    "sitk_ln_gemm_bwd": (C.c_int, [_P] * 10 + [_L, _I, _I, _I, _P]),
     "sitk_attention_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "sitk_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "sitk_encoder_acts_bytes": (_Z, [C.POINTER(EncoderCfg)]),

@@ -117,3 +117,41 @@ def test_reference_style_import_resolves_to_sitk(sitk_pkg):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd="/tmp")
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == str(4 + 11 + 4)
+
+
+def test_timm_weight_import_mapping(sitk_pkg):
+    """utils/utils.py:11-35 (`load_weights_imagenet`): every encoder tensor of a timm ViT-tiny-shaped state
+    dict lands on the SiT key with the same shape, nothing else changes, and exactly the App. B encoder key
+    set (11 per layer) plus the head LayerNorm is covered.  The timm dict is synthetic (no network)."""
+    import torch
+    from sitk.models.sit import SiT
+    from sitk.utils import TIMM_TO_SIT, load_weights_imagenet
+    depth, dim, mlp = 3, 192, 768
+    model = SiT(dim=dim, depth=depth, heads=3, mlp_dim=mlp, num_patches=320, num_vertices=153)
+    sd = model.state_dict()
+    before = {k: v.clone() for k, v in sd.items()}
+    g = torch.Generator().manual_seed(1)
+    timm = {"norm.weight": torch.randn(dim, generator=g), "norm.bias": torch.randn(dim, generator=g)}
+    shapes = {"norm1.weight": (dim,), "norm1.bias": (dim,), "norm2.weight": (dim,), "norm2.bias": (dim,),
+              "attn.qkv.weight": (3 * dim, dim), "attn.qkv.bias": (3 * dim,), "attn.proj.weight": (dim, dim),
+              "attn.proj.bias": (dim,), "mlp.fc1.weight": (mlp, dim), "mlp.fc1.bias": (mlp,),
+              "mlp.fc2.weight": (dim, mlp), "mlp.fc2.bias": (dim,)}
+    for i in range(depth):
+        for k, s in shapes.items():
+            timm[f"blocks.{i}.{k}"] = torch.randn(*s, generator=g)
+    out = load_weights_imagenet(sd, timm, depth)
+    model.load_state_dict(out)                                   # same key set, same shapes
+    enc_keys = {k for k in before if k.startswith("transformer.")}
+    assert enc_keys == {d.format(i=i) for i in range(depth) for d, _ in TIMM_TO_SIT}
+    for i in range(depth):
+        for d, s in TIMM_TO_SIT:
+            assert torch.equal(model.state_dict()[d.format(i=i)], timm[s.format(i=i)])
+    assert torch.equal(model.state_dict()["mlp_head.0.weight"], timm["norm.weight"])
+    for k in ("pos_embedding", "cls_token", "to_patch_embedding.1.weight", "to_patch_embedding.1.bias",
+              "mlp_head.1.weight", "mlp_head.1.bias"):
+        assert torch.equal(model.state_dict()[k], before[k])     # untouched, as in the reference
+    import pytest
+    bad = dict(timm)
+    bad["blocks.0.mlp.fc1.weight"] = torch.zeros(mlp + 8, dim)
+    with pytest.raises(ValueError):
+        load_weights_imagenet(model.state_dict(), bad, depth)

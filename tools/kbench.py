@@ -1,7 +1,7 @@
 """Micro-benchmark of single hot-path kernels at the headline shapes (for rocprofv3 --pmc runs).
 
     python tools/kbench.py <kernel> [--reps 20] [--batch 64]
-kernels: wgrad_w1 wgrad_w2 wgrad_qkv wgrad_layer gemm_qkv gemm_fc1 gemm_fc2 gemm_dfc2 gemm_dfc1 attn_fwd attn_bwd ln_fwd ln_bwd mlp_fwd mlp_fwd_nosave mlp_bwd
+kernels: wgrad_w1 wgrad_w2 wgrad_qkv wgrad_layer gemm_qkv gemm_fc1 gemm_fc2 gemm_dfc2 gemm_dfc1 attn_fwd attn_bwd ln_fwd ln_bwd mlp_fwd mlp_fwd_nosave mlp_bwd lnqkv_fwd lnqkv_bwd
 """
 import argparse
 import os
@@ -58,6 +58,8 @@ def main():
         "mlp_fwd": lambda: ops.mlp_fwd(x32, bD, bD, w["w1"], bM, w["w2"], bD, dt),
         "mlp_fwd_nosave": lambda: ops.mlp_fwd(x32, bD, bD, w["w1"], bM, w["w2"], bD, dt, save=False),
         "mlp_bwd": lambda: ops.mlp_bwd(x32, dxT, x32, mean, rstd, bD, w["w2_t"], w["w1_t"], u, dt),
+        "lnqkv_fwd": lambda: ops.ln_gemm_fwd(x32, bD, bD, w["qkv"], dt),
+        "lnqkv_bwd": lambda: ops.ln_gemm_bwd(qkv, w["qkv_t"], x32, mean, rstd, bD, x32, dt),
         "ln_fwd": lambda: ops.layernorm_fwd(x32, bD, bD, dt),
         "ln_bwd": lambda: ops.layernorm_bwd(h, x32, mean, rstd, bD, x32, bD.clone(), bD.clone(), dt, dx=out_x),
     }
