@@ -87,6 +87,19 @@ SITK_DEV float wave_max(float v) {
   return v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), result in every lane: four v_add_f32 with a
+// row_ror DPP operand.  (__shfl_xor compiles to ds_bpermute: one LDS round trip per step, and a LayerNorm
+// needs 8 dependent ones per row group.)
+SITK_DEV float row16_sum(float v) {
+#define SITK_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+  v += SITK_ROR(8);
+  v += SITK_ROR(4);
+  v += SITK_ROR(2);
+  v += SITK_ROR(1);
+#undef SITK_ROR
+  return v;
+}
+
 SITK_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
 SITK_DEV float gelu_erf_grad(float x) {

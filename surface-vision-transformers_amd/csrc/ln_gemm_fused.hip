@@ -16,6 +16,8 @@
 
 namespace sitk {
 
+__device__ unsigned long long g_lg_stamps[8 * 16];   // diagnostic build only (SITK_LG_STAMPS)
+
 struct LnGemmParams {
   // forward                                   backward
   const float* x;      // (R,192) layer input            | same (saved)
@@ -100,6 +102,14 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
                                        (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
   };
   issue(0, 0);
+#ifdef SITK_LG_STAMPS
+  unsigned long long st[16];
+  int sn = 0;
+  st[sn++] = __builtin_amdgcn_s_memtime();
+#define LGSTAMP() st[sn++] = __builtin_amdgcn_s_memtime();
+#else
+#define LGSTAMP()
+#endif
 
   // per-workgroup buffer descriptors (see mlp_fused.hip): rows past R read 0 / are not written
   const size_t nrows = (size_t)(p.R - blk0 < 128 ? p.R - blk0 : 128);
@@ -122,22 +132,22 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
       for (int i = 0; i < 3; ++i)
         v[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
             r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LGSTAMP()   // 1: x loads landed
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = wave * 16 + pass * 4 + sub, row = blk0 + r;
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) s += v[pass][i][0] + v[pass][i][1] + v[pass][i][2] + v[pass][i][3];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = row16_sum(s);
       const float mu = s * (1.0f / D);
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[pass][i][e] - mu; ss += d * d; }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      ss = row16_sum(ss);
       const float rs = rsqrtf(ss * (1.0f / D) + 1e-5f);
       const bool ok = row < p.R;
 #pragma unroll
@@ -153,7 +163,9 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
       }
       if (ok && j == 0 && p.mean) { p.mean[row] = mu; p.rstd[row] = rs; }
     }
+    LGSTAMP()   // 2: LN computed, stores issued
     __syncthreads();
+    LGSTAMP()   // 3: barrier
   }
   u32x4 hf[2][6];
 #pragma unroll
@@ -170,7 +182,9 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
   for (int ks = 0; ks < 2; ++ks) aw[ks] = lbase + (32 * hh + fr) * 128 + ((ks * 64 + fq * 16) ^ (keyl << 5));
   const int vo[2] = {((32 * tg + fr) * N + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * N + 32 * hh + 8 * fq) * 2};
 
+  LGSTAMP()     // 4: frags loaded
   for (int c = 0; c < nchunks; ++c) {
+    if (c == 1 || c == 5) { LGSTAMP() }   // 5: end of chunk 0 ; 6: end of chunk 4
     // chunk c's DMA precedes the previous iteration's 2 stores (pinned by the "memory" clobbers)
     if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -211,6 +225,13 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
     }
     asm volatile("" : : "v"(sd[0]), "v"(sd[1]));             // store keep-alive (mlp_fused.hip)
   }
+  LGSTAMP()     // 7: loop done
+#ifdef SITK_LG_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st[sn++] = __builtin_amdgcn_s_memtime();   // 8: stores drained
+  if (blockIdx.x == 80 && lane == 0)
+    for (int i = 0; i < sn; ++i) g_lg_stamps[wave * 16 + i] = st[i] - st[0];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -400,6 +421,12 @@ static int lg_check(const char* what, int64_t rows, int D, int N, int dtype) {
 }  // namespace sitk
 
 using namespace sitk;
+
+#ifdef SITK_LG_STAMPS
+extern "C" int sitk_lg_debug_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lg_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int sitk_ln_gemm_fused_supported(int D, int N, int dtype) {
   return dtype == SITK_BF16 && D == LG_D && N % 64 == 0 && N >= 64;

@@ -62,15 +62,17 @@ __device__ unsigned long long g_mlp_stamps[8 * 8];   // diagnostic build (SITK_M
 // GELU without transcendentals in the loop.  v_exp_f32 / v_rcp_f32 run at a quarter of the VALU rate (16
 // cycles per wave instruction), and with one exp + one rcp per element the elementwise phase, not the
 // MFMAs, bounded the kernel.  Instead every workgroup tabulates Phi(x) = 0.5 (1 + erf(x / sqrt2)) -- and,
-// for backward, the density exp(-x^2/2)/sqrt(2 pi) -- once in LDS on the grid x_i = (i - 384) / 64,
-// i = 0..767 (exact erff / expf), and the loop interpolates linearly: 7 full-rate VALU operations and one
+// for backward, the density exp(-x^2/2)/sqrt(2 pi) -- in LDS on the grid x_i = (i - 384) / 64, i = 0..767
+// (values computed in float64 at build time), and the loop interpolates linearly: 7 full-rate VALU operations and one
 // ds_read per element.  Interpolation error <= h^2/8 max|f''| = 7.4e-6 (Phi), 1.2e-5 (density); outside
 // [-6, 6) the end entries apply (Phi(-6) = 1e-9).  The result is closer to the reference's exact-erf GELU
 // than the polynomial erfc of the unfused bf16 epilogues (2.5e-5, gemm.hip).
 constexpr int MLP_TAB_N = 768;
 constexpr float MLP_TAB_SCALE = 64.0f, MLP_TAB_ZERO = 384.0f, MLP_TAB_TMAX = 767.99f;
-SITK_DEV float phi_cdf(float x) { return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
-SITK_DEV float phi_pdf(float x) { return 0.39894228040143267794f * expf(-0.5f * x * x); }
+// {Phi(x_i), density(x_i)}, i = 0..768, computed in float64 by tools/gen_gelu_table.py (6 KB, L2 resident)
+__device__ const float g_gelu_table[MLP_TAB_N + 1][2] = {
+#include "gelu_table.inc"
+};
 // table position of x: t in [0, 768), entry = floor(t), weight of the next entry = fract(t)
 SITK_DEV float tab_pos(float x) { return __builtin_amdgcn_fmed3f(fmaf(x, MLP_TAB_SCALE, MLP_TAB_ZERO), 0.0f, MLP_TAB_TMAX); }
 
@@ -126,6 +128,8 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   const int blk0 = blockIdx.x * 128;
   const int nchunks = p.M / 64;
   const int M = p.M;
+  unsigned long long t_kernel0 = 0;
+  if constexpr (VAR == 6) t_kernel0 = __builtin_amdgcn_s_memtime();
 
   // ---- W chunk DMA: 48 pieces of 8 rows x 128 B; waves 0-3 carry Wa (24 pieces), waves 4-7 Wb ----
   const int r8 = lane >> 3;
@@ -158,15 +162,27 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   };
   issue(0, 0);
 
-  // ---- GELU tables (see above); visible to everybody after the first barrier of the loop ----
-  for (int i = tid; i < MLP_TAB_N; i += 512) {
-    const float x0 = (float)(i - 384) * (1.0f / MLP_TAB_SCALE), x1 = (float)(i - 383) * (1.0f / MLP_TAB_SCALE);
-    const float c0 = phi_cdf(x0), c1 = phi_cdf(x1);
-    if constexpr (!BWD) {
-      *reinterpret_cast<f32x2*>(smem + MLP_OFF_TAB_F + i * 8) = f32x2{c0, c1 - c0};
-    } else {
-      const float d0 = phi_pdf(x0), d1 = phi_pdf(x1);
-      *reinterpret_cast<f32x4*>(smem + MLP_OFF_TAB_B + i * 16) = f32x4{c0, c1 - c0, d0, d1 - d0};
+  // ---- GELU tables (see above): entry i = {f(x_i), f(x_i+1) - f(x_i)}; visible to everybody after the
+  //      first barrier of the loop.  Two entries per thread, straight-line (no loop-carried waits). ----
+  {
+    float tv[2][2][2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 512 * k;
+      const int ii = i < MLP_TAB_N ? i : 0;
+      tv[k][0][0] = g_gelu_table[ii][0]; tv[k][0][1] = g_gelu_table[ii][1];
+      tv[k][1][0] = g_gelu_table[ii + 1][0]; tv[k][1][1] = g_gelu_table[ii + 1][1];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + 512 * k;
+      if (i < MLP_TAB_N) {
+        if constexpr (!BWD)
+          *reinterpret_cast<f32x2*>(smem + MLP_OFF_TAB_F + i * 8) = f32x2{tv[k][0][0], tv[k][1][0] - tv[k][0][0]};
+        else
+          *reinterpret_cast<f32x4*>(smem + MLP_OFF_TAB_B + i * 16) =
+              f32x4{tv[k][0][0], tv[k][1][0] - tv[k][0][0], tv[k][0][1], tv[k][1][1] - tv[k][0][1]};
+      }
     }
   }
 
@@ -187,7 +203,11 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   char* sH = smem + MLP_OFF_H;
   u32x4 hf[2][6];
   if constexpr (!BWD) {
-    for (int i = tid; i < M; i += 512) reinterpret_cast<float*>(smem + MLP_OFF_B1)[i] = p.b1[i];
+    {
+      const float bA = tid < M ? p.b1[tid] : 0.f, bB = tid + 512 < M ? p.b1[tid + 512] : 0.f;
+      reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid] = bA;
+      reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid + 512] = bB;
+    }
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.x + oD, RD * 4);
     const __amdgpu_buffer_rsrc_t r_h = make_rsrc(p.h + oD, p.h ? RD * 2 : 0);
     const int j = lane & 15, sub = lane >> 4;
@@ -207,16 +227,14 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) s += v[pass][i][0] + v[pass][i][1] + v[pass][i][2] + v[pass][i][3];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = row16_sum(s);
       const float mu = s * (1.0f / D);
       float ss = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[pass][i][e] - mu; ss += d * d; }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      ss = row16_sum(ss);
       const float rs = rsqrtf(ss * (1.0f / D) + 1e-5f);
       const bool ok = row < p.R;
 #pragma unroll
@@ -287,12 +305,22 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   const int trow0 = blk0 + 32 * tg + fr, trow1 = trow0 + 16;
   const int vo[2] = {((32 * tg + fr) * M + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * M + 32 * hh + 8 * fq) * 2};
   const int so0 = 0;                                           // scalar offset: chunk only (c * 128 bytes)
-  // backward: the saved pre-activations of chunk c travel one chunk ahead of their use
-  u32x4 un[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+  // backward: the saved pre-activations u of chunk c + 1 are fetched as soon as chunk c's have been consumed,
+  // by buffer loads the COMPILER DOES NOT SEE (inline asm): a compiler-visible load that is live across the
+  // loop edge makes hipcc drain vmcnt to 0 -- every store of the chunk included -- twice per iteration.  The
+  // counted waits below cover them instead.
+  u32x4 uc[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+  u32x4 srd_u = {0u, 0u, 0u, 0u};
   if constexpr (BWD) {
-    un[0] = __builtin_amdgcn_raw_buffer_load_b128(r_u, vo[0], so0, 0);
-    un[1] = __builtin_amdgcn_raw_buffer_load_b128(r_u, vo[1], so0, 0);
+    const uint64_t ua = reinterpret_cast<uint64_t>(p.u + oM);
+    srd_u = u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ua),
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ua >> 32)) & 0xffffu,
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(RM * 2)), 0x00020000u};
   }
+#define SITK_MLP_LOAD_U(SOFF)                                                                              \
+  asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen"       \
+               : "=&v"(uc[0]), "=&v"(uc[1]) : "v"(vo[0]), "v"(vo[1]), "s"(srd_u), "s"(SOFF) : "memory")
+  if constexpr (BWD) { const int so_first = 0; SITK_MLP_LOAD_U(so_first); }
 
   // Waves w and w + 4 share a SIMD and the per-chunk barrier keeps them in lock step, so left alone they
   // would fight for the MFMA pipe in the product phases and for VALU issue in the elementwise phase without
@@ -300,7 +328,8 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   // its elementwise phase while the other is still in its MFMAs, and the phases interleave from there.
   if (VAR != 5 && wave < 4) __builtin_amdgcn_s_setprio(2);
   // global stores each wave issues per chunk after the next chunk's DMA
-  const int nstores = BWD ? (p.g ? 4 : 2) : (p.u ? 2 : 0) + (p.g ? 2 : 0);
+  // backward adds the 2 u loads issued at the end of the elementwise phase
+  const int nstores = BWD ? (p.g ? 6 : 4) : (p.u ? 2 : 0) + (p.g ? 2 : 0);
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define SITK_STAMP(i)                                                                    \
   if constexpr (VAR == 6) {                                                              \
@@ -308,7 +337,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
     st[i] += tn - tprev;                                                                 \
     tprev = tn;                                                                          \
   }
-  if constexpr (VAR == 6) tprev = __builtin_amdgcn_s_memtime();
+  if constexpr (VAR == 6) { tprev = __builtin_amdgcn_s_memtime(); st[5] = tprev - t_kernel0; }
   for (int c = 0; c < (VAR == 4 ? 0 : nchunks); ++c) {
     const int buf = c & 1;
     SITK_STAMP(7)
@@ -316,7 +345,8 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
     // (pinned there by the "memory" clobbers of the fragment-read blocks), so only those stores may stay in flight
     if (c == 0 || nstores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (nstores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (nstores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     SITK_STAMP(0)
     if (VAR != 3 || c == 0) __builtin_amdgcn_s_barrier();      // everybody's pieces landed; buffer buf^1 is free
     SITK_STAMP(1)
@@ -326,14 +356,6 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
     // {tile 0, tile 1} x {k-step 2 kt, 2 kt + 1}; second product, group j: feature tiles 4 j .. 4 j + 3.
     u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
     SITK_MLP_ISSUE4(x0, x1, x2, x3, a0, a1, 0, 2048, 0, 2048);
-    u32x4 uc[2];
-    if constexpr (BWD) {
-      uc[0] = un[0]; uc[1] = un[1];
-      if (c + 1 < nchunks) {
-        un[0] = __builtin_amdgcn_raw_buffer_load_b128(r_u, vo[0], so0 + (c + 1) * 128, 0);
-        un[1] = __builtin_amdgcn_raw_buffer_load_b128(r_u, vo[1], so0 + (c + 1) * 128, 0);
-      }
-    }
     if (VAR != 3 && c + 1 < nchunks) issue(c + 1, buf ^ 1);
 
     // ---- first product: uacc[i][t], hidden tile i (slot rows 32 hh + 16 i ..), token tile t; forward
@@ -408,6 +430,16 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
         }
       }
     } else {
+      // u(c) was requested at the end of the previous elementwise phase; only this iteration's 6 DMA pieces are
+      // younger (chunk 0's were drained by the vmcnt(0) at the top of the first iteration)
+      if (c > 0) {
+        if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      // The registers become "defined" for the compiler only HERE, in one unconditional statement behind the
+      // waits: tying them to the conditional wait statements themselves made hipcc merge the two branches
+      // through register copies placed in front of a wait, i.e. copies of registers whose loads were in flight.
+      asm volatile("" : "+v"(uc[0]), "+v"(uc[1]) : : "memory");
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         float dv[8], gv[8];
@@ -443,6 +475,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
         __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_du, vo[t], so, 0);
         if (p.g) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_g, vo[t], so, 0);
       }
+      if (c + 1 < nchunks) { const int so_next = so + 128; SITK_MLP_LOAD_U(so_next); }
     }
 
     SITK_STAMP(3)
@@ -472,9 +505,27 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
 #undef SITK_MLP_FC2_MMAS
     SITK_STAMP(4)
   }
-  if constexpr (VAR == 6) {
-    if (blockIdx.x == 0 && lane == 0)
-      for (int i = 0; i < 8; ++i) g_mlp_stamps[wave * 8 + i] = st[i];
+  const unsigned long long t_loop_end = VAR == 6 ? __builtin_amdgcn_s_memtime() : 0;
+
+  // backward epilogue operands (x_mid rows for xhat, LayerNorm statistics, gamma) are requested now, ahead of
+  // the exchange barriers, so that their HBM latency runs under the exchange
+  const int trow0e = blk0 + 32 * tg + fr;
+  const int n0e = 96 * hh + 4 * fq;
+  f32x4 xpre[6][2], gmpre[6];
+  float mupre[2] = {0.f, 0.f}, rspre[2] = {0.f, 0.f};
+  if constexpr (BWD) {
+    const __amdgpu_buffer_rsrc_t r_xe = make_rsrc(p.x + oD, RD * 4);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int row = trow0e + 16 * t;
+      if (row < p.R) { mupre[t] = p.mean[row]; rspre[t] = p.rstd[row]; }
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        xpre[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            r_xe, ((32 * tg + 16 * t + fr) * D + n0e + 16 * i) * 4, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) gmpre[i] = load4(p.gamma + n0e + 16 * i);
   }
 
   // ---- pair exchange: wave hh finishes features [96 hh, 96 hh + 96); the other half's partial sums
@@ -518,19 +569,30 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
     float* red = reinterpret_cast<float*>(smem + MLP_OFF_B1);  // [wave][t][16 tokens][2] row sums (2 KB)
     f32x4 gmv[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) gmv[i] = load4(p.gamma + n0 + 16 * i);
+    for (int i = 0; i < 6; ++i) gmv[i] = gmpre[i];
+    // the residual gradient rows: requested here, consumed after the row-sum exchange below
+    f32x4 dyv[6][2];
+    {
+      const __amdgpu_buffer_rsrc_t r_dye = make_rsrc(p.dy + oD, RD * 4);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          dyv[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+              r_dye, ((32 * tg + 16 * t + fr) * D + n0 + 16 * i) * 4, 0, 0));
+    }
     f32x4 xh[6][2];
     float mu[2], rs[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int row = t ? trow1 : trow0;
       const bool ok = row < p.R;
-      mu[t] = ok ? p.mean[row] : 0.f;
-      rs[t] = ok ? p.rstd[row] : 0.f;
+      mu[t] = mupre[t];
+      rs[t] = rspre[t];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const f32x4 xv = ok ? load4(p.x + (size_t)row * D + n0 + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 xv = xpre[i][t];                          // rows past R read 0 (buffer descriptor), mu = rs = 0
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[i][t][e] = (xv[e] - mu[t]) * rs[t];
@@ -565,7 +627,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
           dbs[i][e] += v[i][t][e];
         }
         if (ok) {
-          o += load4(p.dy + (size_t)row * D + n);
+          o += dyv[i][t];
           store4(p.out + (size_t)row * D + n, o);
           store4(p.outc + (size_t)row * D + n, o);
         }
@@ -587,6 +649,12 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
       for (int r = 0; r < 64; ++r) s += cs[r * CP + tid];
       p.partials[(size_t)blockIdx.x * 2 * D + tid] = s;
     }
+  }
+  if constexpr (VAR == 6) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st[6] = __builtin_amdgcn_s_memtime() - t_loop_end;
+    if (blockIdx.x == 80 && lane == 0)
+      for (int i = 0; i < 8; ++i) g_mlp_stamps[wave * 8 + i] = st[i];
   }
 }
 
@@ -652,6 +720,9 @@ extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, c
   p.du = reinterpret_cast<bf16*>(du); p.dy = dy; p.dyc = reinterpret_cast<const bf16*>(dy_c);
   p.out = dx; p.outc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.M = M;
+  static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;
+  if (var == 6) hipLaunchKernelGGL((mlp_kernel<true, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else
   hipLaunchKernelGGL((mlp_kernel<true, 0>), dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("mlp_bwd");
 }

@@ -16,15 +16,25 @@ x = torch.randn(R, D, device=dev)
 w1 = (torch.randn(M, D, device=dev) * 0.07).bfloat16()
 w2 = (torch.randn(D, M, device=dev) * 0.04).bfloat16()
 b1, b2, lw, lb = torch.zeros(M, device=dev), torch.zeros(D, device=dev), torch.ones(D, device=dev), torch.zeros(D, device=dev)
+bwd = len(sys.argv) > 1 and sys.argv[1] == "bwd"
+out, h, mean, rstd, u, g = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, "bf16")
+dy = torch.randn(R, D, device=dev)
+dyc = dy.bfloat16()
+w2t, w1t = w2.T.contiguous(), w1.T.contiguous()
+big = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 for _ in range(5):
-    ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, "bf16")
+    big.zero_()                                    # push the operands out of the caches, as in a real step
+    if bwd:
+        ops.mlp_bwd(dy, dyc, x, mean, rstd, lw, w2t, w1t, u, "bf16")
+    else:
+        ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, "bf16")
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * 64)()
 fn = rt.lib.sitk_mlp_debug_stamps
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
 assert fn(buf) == 0
-names = ["vmcnt wait", "barrier", "product 1", "elementwise", "product 2", "-", "-", "loop back"]
-print("cycles summed over the 12 chunks, workgroup 0 (s_memtime ticks):")
+names = ["vmcnt wait", "barrier", "product 1", "elementwise", "product 2", "PROLOGUE", "EPILOGUE", "loop back"]
+print("cycles (loop phases summed over the 12 chunks), workgroup 80 (s_memtime ticks):")
 for w in range(8):
-    print(f"wave {w}: " + "  ".join(f"{names[i]}={buf[w * 8 + i]}" for i in (7, 0, 1, 2, 3, 4)) +
+    print(f"wave {w}: " + "  ".join(f"{names[i]}={buf[w * 8 + i]}" for i in (5, 7, 0, 1, 2, 3, 4, 6)) +
           f"  total={sum(buf[w * 8 + i] for i in range(8))}")
