@@ -1,0 +1,174 @@
+// Shared epilogue of the fused backward kernels (mlp_fused.hip, ln_gemm_fused.hip): LayerNorm backward
+// of a 128-token block whose input gradient dh sits in MFMA accumulator layout.
+//
+//   dx = dres + rstd (dh gamma - mean(dh gamma) - xhat mean(dh gamma xhat)),  xhat = (x - mean) rstd
+//   per-workgroup partial sums of dgamma = sum_rows dh xhat and dbeta = sum_rows dh
+//
+// In accumulator layout a wave instruction touches 16 rows x 64 bytes: half cache lines, the other half
+// belonging to another wave.  Measured on MI355X the row-indexed traffic of this epilogue (x, dres in, dx and
+// its compute-dtype copy out: 55 MB for the BASELINE shape, all workgroups at once) then runs at ~2.3 TB/s.
+// So dh takes one trip through LDS into row-major fp32 (pitch 196 floats), and the LayerNorm backward runs
+// like the stand-alone kernel of norm.hip: 16 lanes per row, every load and store a run of whole rows
+// (256 contiguous bytes per row and instruction), row sums by DPP.
+#pragma once
+#include "common.h"
+
+namespace sitk {
+
+constexpr int FE_D = 192;
+constexpr int FE_PITCH = 196;                              // floats; rows shift by 16 B per row in the 256-B bank window
+constexpr int FE_ROWBUF_BYTES = 128 * FE_PITCH * 4;        // 100352
+constexpr int FE_COLBUF_BYTES = 32 * 2 * FE_D * 4;         // [wave][sub][2][192] column partials = 49152 (aliases the row buffer)
+constexpr int FE_SMEM_BYTES = FE_ROWBUF_BYTES;
+
+// v[i][t]: this wave's finished half of dh -- features 96 hh + 16 i + 4 fq + e of token 32 tg + 16 t + fr
+// (pair exchange already done).  smem: >= FE_SMEM_BYTES, free for use by every wave (callers sync before).
+// All 512 threads of the workgroup must call it.
+SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, int blk0, int R, const float* __restrict__ x,
+                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                   const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
+                                   bf16* __restrict__ dxc, float* __restrict__ partials_block) {
+  constexpr int D = FE_D;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4, tg = wave >> 1, hh = wave & 1;
+  const int j = lane & 15, sub = lane >> 4;                   // row pass: 16 lanes per row, 4 rows per pass
+  float* rowbuf = reinterpret_cast<float*>(smem);
+
+  // ---- request this wave's 16 rows of x and dres (4 passes x 3 x 16 B per lane each), statistics, gamma ----
+  const size_t nrows = (size_t)(R - blk0 < 128 ? R - blk0 : 128);
+  const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)blk0 * D, 0,
+                                                                       (int)(nrows * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dres ? dres : x) + (size_t)blk0 * D, 0,
+                                                                       dres ? (int)(nrows * D * 4) : 0, 0x00020000);
+  f32x4 xv[4][3], dv[4][3], gm[3];
+  float mu[4], rs[4];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = wave * 16 + pass * 4 + sub;
+    const bool ok = blk0 + r < R;
+    mu[pass] = ok ? mean[blk0 + r] : 0.f;
+    rs[pass] = ok ? rstd[blk0 + r] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int off = (r * D + 4 * (j + 16 * i)) * 4;
+      xv[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_x, off, 0, 0));
+      dv[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_d, off, 0, 0));   // 0 when dres == NULL
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) gm[i] = load4(gamma + 4 * (j + 16 * i));
+
+  // ---- dh: accumulator layout -> row-major fp32 (the callers' exchange area is being overwritten) ----
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      *reinterpret_cast<f32x4*>(rowbuf + (32 * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
+  __syncthreads();
+
+  // ---- LayerNorm backward, 4 rows per pass ----
+  f32x4 dgs[3], dbs[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { dgs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  f32x4 outv[4][3];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = wave * 16 + pass * 4 + sub;
+    f32x4 dh[3], xh[3];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      dh[i] = *reinterpret_cast<const f32x4*>(rowbuf + r * FE_PITCH + 4 * (j + 16 * i));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[i][e] = (xv[pass][i][e] - mu[pass]) * rs[pass];    // rows past R: x = 0, mu = rs = 0, dh = 0
+        const float gy = dh[i][e] * gm[i][e];
+        s1 += gy;
+        s2 += gy * xh[i][e];
+        dgs[i][e] += dh[i][e] * xh[i][e];
+        dbs[i][e] += dh[i][e];
+      }
+    }
+    const float m1 = row16_sum(s1) * (1.0f / D), m2 = row16_sum(s2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        outv[pass][i][e] = rs[pass] * (dh[i][e] * gm[i][e] - m1 - xh[i][e] * m2) + dv[pass][i][e];
+  }
+  // ---- stores: whole rows ----
+  const __amdgpu_buffer_rsrc_t r_o = __builtin_amdgcn_make_buffer_rsrc(dx + (size_t)blk0 * D, 0, (int)(nrows * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(dxc ? dxc + (size_t)blk0 * D : (bf16*)dx, 0,
+                                                                       dxc ? (int)(nrows * D * 2) : 0, 0x00020000);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = wave * 16 + pass * 4 + sub;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int col = 4 * (j + 16 * i);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outv[pass][i]), r_o, (r * D + col) * 4, 0, 0);
+      bf16x4 ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ob[e] = (bf16)outv[pass][i][e];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), r_c, (r * D + col) * 2, 0, 0);   // dropped when dxc == NULL
+    }
+  }
+  // ---- dgamma / dbeta partials of the block: [wave][sub] slots in LDS, then one thread per column ----
+  __syncthreads();                                            // every row of dh has been read
+  float* colbuf = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    *reinterpret_cast<f32x4*>(colbuf + ((wave * 4 + sub) * 2 + 0) * D + 4 * (j + 16 * i)) = dgs[i];
+    *reinterpret_cast<f32x4*>(colbuf + ((wave * 4 + sub) * 2 + 1) * D + 4 * (j + 16 * i)) = dbs[i];
+  }
+  __syncthreads();
+  if (tid < 2 * D) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int q = 0; q < 32; ++q) s += colbuf[q * 2 * D + tid];
+    partials_block[tid] = s;
+  }
+}
+
+// Forward counterpart: out = v + bias + x, rows of x re-read and rows of out written whole (same layouts as above).
+SITK_DEV void residual_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, int blk0, int R, const float* __restrict__ x,
+                                     const float* __restrict__ bias, float* __restrict__ out) {
+  constexpr int D = FE_D;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4, tg = wave >> 1, hh = wave & 1;
+  const int j = lane & 15, sub = lane >> 4;
+  float* rowbuf = reinterpret_cast<float*>(smem);
+  const size_t nrows = (size_t)(R - blk0 < 128 ? R - blk0 : 128);
+  const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)blk0 * D, 0,
+                                                                       (int)(nrows * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_o = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)blk0 * D, 0, (int)(nrows * D * 4), 0x00020000);
+  f32x4 xv[4][3], bb[3];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      xv[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) bb[i] = load4(bias + 4 * (j + 16 * i));
+  __syncthreads();                                            // the callers' exchange area is being overwritten
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      *reinterpret_cast<f32x4*>(rowbuf + (32 * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = wave * 16 + pass * 4 + sub;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int col = 4 * (j + 16 * i);
+      const f32x4 o = *reinterpret_cast<const f32x4*>(rowbuf + r * FE_PITCH + col) + bb[i] + xv[pass][i];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_o, (r * D + col) * 4, 0, 0);
+    }
+  }
+}
+
+}  // namespace sitk

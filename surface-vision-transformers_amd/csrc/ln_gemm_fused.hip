@@ -13,6 +13,7 @@
 // buffer-descriptor row I/O and the store keep-alive).  One launch replaces LayerNorm + GEMM (forward) or
 // GEMM + LayerNorm backward (backward) and the (tokens x 192) round trip through HBM between them.
 #include "common.h"
+#include "fused_epilogue.h"
 
 namespace sitk {
 
@@ -39,9 +40,7 @@ constexpr int LG_D = 192;
 constexpr int LG_WB = 24576;                   // one weight chunk: 24 pieces of 8 rows x 128 B
 constexpr int LG_OFF_H = 2 * LG_WB;            // forward: operand strip 3 k-panels x 128 rows x 128 B = 48 KB
 constexpr int LG_SMEM_FWD = LG_OFF_H + 3 * 128 * 128;
-constexpr int LG_CP = 2 * LG_D + 4;            // backward: column-sum pitch (floats)
-constexpr int LG_OFF_RED = 64 * LG_CP * 4;     // backward: row-sum exchange area behind the column sums
-constexpr int LG_SMEM_BWD = LG_OFF_RED + 2048;
+constexpr int LG_SMEM_BWD = FE_SMEM_BYTES > 8 * 12288 ? FE_SMEM_BYTES : 8 * 12288;   // exchange area / row-layout epilogue
 
 SITK_DEV uint32_t lg_pack_bf16(float a, float b) {
   bf16x2 v;
@@ -335,81 +334,9 @@ __global__ __launch_bounds__(512) void ln_gemm_bwd_kernel(LnGemmParams p) {
         v[i][t] = (hh ? yacc[6 + i][t] : yacc[i][t]) + o;
       }
   }
-  const int n0 = 96 * hh + 4 * fq;
-  const int trow0 = blk0 + 32 * tg + fr, trow1 = trow0 + 16;
-
-  // ---- LayerNorm backward on dh = v:  dx = dres + rstd (dh gamma - mean(dh gamma) - xhat mean(dh gamma xhat)) ----
-  float* red = reinterpret_cast<float*>(smem + LG_OFF_RED);    // [wave][t][16 tokens][2] row sums
-  f32x4 gmv[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) gmv[i] = load4(p.gamma + n0 + 16 * i);
-  f32x4 xh[6][2];
-  float mu[2], rs[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int row = t ? trow1 : trow0;
-    const bool ok = row < p.R;
-    mu[t] = ok ? p.mean[row] : 0.f;
-    rs[t] = ok ? p.rstd[row] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const f32x4 xv = ok ? load4(p.x + (size_t)row * D + n0 + 16 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xh[i][t][e] = (xv[e] - mu[t]) * rs[t];
-        const float gy = v[i][t][e] * gmv[i][e];
-        s1 += gy;
-        s2 += gy * xh[i][t][e];
-      }
-    }
-    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-    if (fq == 0) { red[((wave * 2 + t) * 16 + fr) * 2] = s1; red[((wave * 2 + t) * 16 + fr) * 2 + 1] = s2; }
-  }
-  __syncthreads();
-  f32x4 dgs[6], dbs[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) { dgs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int row = t ? trow1 : trow0;
-    const bool ok = row < p.R;
-    const float o1 = red[(((wave ^ 1) * 2 + t) * 16 + fr) * 2], o2 = red[(((wave ^ 1) * 2 + t) * 16 + fr) * 2 + 1];
-    const float m1 = (red[((wave * 2 + t) * 16 + fr) * 2] + o1) * (1.0f / D);
-    const float m2 = (red[((wave * 2 + t) * 16 + fr) * 2 + 1] + o2) * (1.0f / D);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int n = n0 + 16 * i;
-      f32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        o[e] = rs[t] * (v[i][t][e] * gmv[i][e] - m1 - xh[i][t][e] * m2);
-        dgs[i][e] += v[i][t][e] * xh[i][t][e];                 // rows past R carry v = 0 (zero B fragments)
-        dbs[i][e] += v[i][t][e];
-      }
-      if (ok) {
-        if (p.dres) o += load4(p.dres + (size_t)row * D + n);
-        store4(p.dx + (size_t)row * D + n, o);
-        if (p.dxc) store4(p.dxc + (size_t)row * D + n, o);
-      }
-    }
-  }
-  // column sums over the block's 128 tokens (see mlp_fused.hip)
-  __syncthreads();                                             // everybody has read the exchange area
-  float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    *reinterpret_cast<f32x4*>(cs + (tg * 16 + fr) * LG_CP + n0 + 16 * i) = dgs[i];
-    *reinterpret_cast<f32x4*>(cs + (tg * 16 + fr) * LG_CP + D + n0 + 16 * i) = dbs[i];
-  }
-  __syncthreads();
-  if (tid < 2 * D) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < 64; ++r) s += cs[r * LG_CP + tid];
-    p.partials[(size_t)blockIdx.x * 2 * D + tid] = s;
-  }
+  // ---- LayerNorm backward on dh = v, in row layout (fused_epilogue.h) ----
+  ln_bwd_rows_epilogue(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dres, p.dx, p.dxc,
+                       p.partials + (size_t)blockIdx.x * 2 * D);
 }
 
 static int lg_check(const char* what, int64_t rows, int D, int N, int dtype) {

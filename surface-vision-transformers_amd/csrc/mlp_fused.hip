@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "fused_epilogue.h"
 
 namespace sitk {
 
@@ -57,7 +58,7 @@ struct MlpParams {
 };
 
 __device__ u32x4 g_zero_page_mlp[4];
-__device__ unsigned long long g_mlp_stamps[8 * 8];   // diagnostic build (SITK_MLP_VAR=6): [wave][phase] cycle sums of workgroup 0
+__device__ unsigned long long g_mlp_stamps[2 * 8 * 8];   // diagnostic build (SITK_MLP_VAR=6): [wave][phase] cycle sums of workgroup 0
 
 // GELU without transcendentals in the loop.  v_exp_f32 / v_rcp_f32 run at a quarter of the VALU rate (16
 // cycles per wave instruction), and with one exp + one rcp per element the elementwise phase, not the
@@ -162,17 +163,20 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   };
   issue(0, 0);
 
+  if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 0] = __builtin_amdgcn_s_memtime() - t_kernel0; }
   // ---- GELU tables (see above): entry i = {f(x_i), f(x_i+1) - f(x_i)}; visible to everybody after the
-  //      first barrier of the loop.  Two entries per thread, straight-line (no loop-carried waits). ----
-  {
-    float tv[2][2][2];
+  //      first barrier of the loop.  Two entries per thread.  The global loads are issued here, the LDS stores
+  //      (in front of which hipcc drains every outstanding load: LDS-DMA aliasing) after the LayerNorm rows
+  //      have been requested too, so that the prologue pays one memory latency, not three. ----
+  float tv[2][2][2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int i = tid + 512 * k;
-      const int ii = i < MLP_TAB_N ? i : 0;
-      tv[k][0][0] = g_gelu_table[ii][0]; tv[k][0][1] = g_gelu_table[ii][1];
-      tv[k][1][0] = g_gelu_table[ii + 1][0]; tv[k][1][1] = g_gelu_table[ii + 1][1];
-    }
+  for (int k = 0; k < 2; ++k) {
+    const int i = tid + 512 * k;
+    const int ii = i < MLP_TAB_N ? i : 0;
+    tv[k][0][0] = g_gelu_table[ii][0]; tv[k][0][1] = g_gelu_table[ii][1];
+    tv[k][1][0] = g_gelu_table[ii + 1][0]; tv[k][1][1] = g_gelu_table[ii + 1][1];
+  }
+  auto store_tables = [&]() {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = tid + 512 * k;
@@ -184,7 +188,8 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
               f32x4{tv[k][0][0], tv[k][1][0] - tv[k][0][0], tv[k][0][1], tv[k][1][1] - tv[k][0][1]};
       }
     }
-  }
+  };
+  if constexpr (BWD) store_tables();
 
   // Row-indexed global traffic goes through buffer descriptors of THIS workgroup's rows (base = its first
   // row, num_records = its valid rows): rows past R fall outside num_records, so their loads return 0 and
@@ -203,17 +208,14 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   char* sH = smem + MLP_OFF_H;
   u32x4 hf[2][6];
   if constexpr (!BWD) {
-    {
-      const float bA = tid < M ? p.b1[tid] : 0.f, bB = tid + 512 < M ? p.b1[tid + 512] : 0.f;
-      reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid] = bA;
-      reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid + 512] = bB;
-    }
+    const float bA = tid < M ? p.b1[tid] : 0.f, bB = tid + 512 < M ? p.b1[tid + 512] : 0.f;
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.x + oD, RD * 4);
     const __amdgpu_buffer_rsrc_t r_h = make_rsrc(p.h + oD, p.h ? RD * 2 : 0);
     const int j = lane & 15, sub = lane >> 4;
     f32x4 gm[3], bt[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { gm[i] = load4(p.gamma + 4 * (j + 16 * i)); bt[i] = load4(p.beta + 4 * (j + 16 * i)); }
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 1] = __builtin_amdgcn_s_memtime() - t_kernel0; }
     f32x4 v[4][3];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass)
@@ -221,6 +223,9 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
       for (int i = 0; i < 3; ++i)
         v[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
             r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+    store_tables();
+    reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid] = bA;
+    reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid + 512] = bB;
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = wave * 16 + pass * 4 + sub, row = blk0 + r;
@@ -252,7 +257,9 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
       }
       if (ok && j == 0 && p.mean) { p.mean[row] = mu; p.rstd[row] = rs; }
     }
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 2] = __builtin_amdgcn_s_memtime() - t_kernel0; }
     __syncthreads();
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 3] = __builtin_amdgcn_s_memtime() - t_kernel0; }
     // this wave's operand fragments: token tile t, k-step k <-> 16 B of row 32 tg + 16 t + fr
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
         hf[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_dyc, ((32 * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
   }
 
+  if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 4] = __builtin_amdgcn_s_memtime() - t_kernel0; }
   // ---- per-lane LDS byte addresses ----
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
@@ -280,26 +288,9 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   const uint32_t ab1 = lbase + MLP_OFF_B1 + (32 * hh + 8 * fq) * 4;                   // + c*256
   const uint32_t ltabf = lbase + MLP_OFF_TAB_F, ltabb = lbase + MLP_OFF_TAB_B;
 
-  // Accumulators of the second product.  Forward starts the half this wave will finish at x + b2, so the
-  // residual rides through the pair exchange and the epilogue never re-reads x (the rows are L2-hot here:
-  // the LayerNorm above has just read them).
-  f32x4 yacc[12][2];
+  f32x4 yacc[12][2];                                          // accumulators of the second product
 #pragma unroll
   for (int dt = 0; dt < 12; ++dt) { yacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; yacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  if constexpr (!BWD) {
-    const __amdgpu_buffer_rsrc_t r_x2 = make_rsrc(p.x + oD, RD * 4);
-    const int nb = 96 * hh + 4 * fq;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const f32x4 bb = load4(p.b2 + nb + 16 * i);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f32x4 xv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            r_x2, ((32 * tg + 16 * t + fr) * D + nb + 16 * i) * 4, 0, 0));
-        if (hh) yacc[6 + i][t] = xv + bb; else yacc[i][t] = xv + bb;
-      }
-    }
-  }
 
   // (rows x M) operands: lane's 16 bytes of token tile t sit at vo[t] + (block, chunk) scalar offset
   const int trow0 = blk0 + 32 * tg + fr, trow1 = trow0 + 16;
@@ -507,27 +498,6 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   }
   const unsigned long long t_loop_end = VAR == 6 ? __builtin_amdgcn_s_memtime() : 0;
 
-  // backward epilogue operands (x_mid rows for xhat, LayerNorm statistics, gamma) are requested now, ahead of
-  // the exchange barriers, so that their HBM latency runs under the exchange
-  const int trow0e = blk0 + 32 * tg + fr;
-  const int n0e = 96 * hh + 4 * fq;
-  f32x4 xpre[6][2], gmpre[6];
-  float mupre[2] = {0.f, 0.f}, rspre[2] = {0.f, 0.f};
-  if constexpr (BWD) {
-    const __amdgpu_buffer_rsrc_t r_xe = make_rsrc(p.x + oD, RD * 4);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = trow0e + 16 * t;
-      if (row < p.R) { mupre[t] = p.mean[row]; rspre[t] = p.rstd[row]; }
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-        xpre[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            r_xe, ((32 * tg + 16 * t + fr) * D + n0e + 16 * i) * 4, 0, 0));
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gmpre[i] = load4(p.gamma + n0e + 16 * i);
-  }
-
   // ---- pair exchange: wave hh finishes features [96 hh, 96 hh + 96); the other half's partial sums
   //      cross through LDS (12 tiles x 1 KB per wave, in the W buffers that nobody reads any more) ----
   __syncthreads();
@@ -555,100 +525,12 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   const int n0 = 96 * hh + 4 * fq;                             // + 16 i : this lane's 4 features of tile i
 
   if constexpr (!BWD) {
-    // out = v (x + b2 entered through the accumulator start values)
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t ? trow1 : trow0;
-      if (row < p.R) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) store4(p.out + (size_t)row * D + n0 + 16 * i, v[i][t]);
-      }
-    }
+    // out = v + b2 + x, in row layout (fused_epilogue.h)
+    residual_rows_epilogue(smem, v, tid, blk0, p.R, p.x, p.b2, p.out);
   } else {
-    // LayerNorm backward on dh = v:  dx = dy + rstd (dh gamma - mean(dh gamma) - xhat mean(dh gamma xhat))
-    float* red = reinterpret_cast<float*>(smem + MLP_OFF_B1);  // [wave][t][16 tokens][2] row sums (2 KB)
-    f32x4 gmv[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) gmv[i] = gmpre[i];
-    // the residual gradient rows: requested here, consumed after the row-sum exchange below
-    f32x4 dyv[6][2];
-    {
-      const __amdgpu_buffer_rsrc_t r_dye = make_rsrc(p.dy + oD, RD * 4);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-          dyv[i][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-              r_dye, ((32 * tg + 16 * t + fr) * D + n0 + 16 * i) * 4, 0, 0));
-    }
-    f32x4 xh[6][2];
-    float mu[2], rs[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t ? trow1 : trow0;
-      const bool ok = row < p.R;
-      mu[t] = mupre[t];
-      rs[t] = rspre[t];
-      float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const f32x4 xv = xpre[i][t];                          // rows past R read 0 (buffer descriptor), mu = rs = 0
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[i][t][e] = (xv[e] - mu[t]) * rs[t];
-          const float gy = v[i][t][e] * gmv[i][e];
-          s1 += gy;
-          s2 += gy * xh[i][t][e];
-        }
-      }
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if (fq == 0) { red[((wave * 2 + t) * 16 + fr) * 2] = s1; red[((wave * 2 + t) * 16 + fr) * 2 + 1] = s2; }
-    }
-    __syncthreads();
-    f32x4 dgs[6], dbs[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { dgs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int row = t ? trow1 : trow0;
-      const bool ok = row < p.R;
-      const float o1 = red[(((wave ^ 1) * 2 + t) * 16 + fr) * 2], o2 = red[(((wave ^ 1) * 2 + t) * 16 + fr) * 2 + 1];
-      const float m1 = (red[((wave * 2 + t) * 16 + fr) * 2] + o1) * (1.0f / D);
-      const float m2 = (red[((wave * 2 + t) * 16 + fr) * 2 + 1] + o2) * (1.0f / D);
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int n = n0 + 16 * i;
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = rs[t] * (v[i][t][e] * gmv[i][e] - m1 - xh[i][t][e] * m2);
-          dgs[i][e] += v[i][t][e] * xh[i][t][e];               // rows past R carry v = 0 (zero operand rows)
-          dbs[i][e] += v[i][t][e];
-        }
-        if (ok) {
-          o += dyv[i][t];
-          store4(p.out + (size_t)row * D + n, o);
-          store4(p.outc + (size_t)row * D + n, o);
-        }
-      }
-    }
-    // column sums: every lane parks its 2 x 24 per-token-pair values in LDS (row = tg * 16 + fr, pitch 388
-    // floats: conflict-free 16-byte stores), then 384 threads each add up one column over the 64 rows
-    constexpr int CP = 2 * D + 4;
-    float* cs = reinterpret_cast<float*>(smem);                // 64 x 388 floats = 97 KB (W buffers + strip head)
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      *reinterpret_cast<f32x4*>(cs + (tg * 16 + fr) * CP + n0 + 16 * i) = dgs[i];
-      *reinterpret_cast<f32x4*>(cs + (tg * 16 + fr) * CP + D + n0 + 16 * i) = dbs[i];
-    }
-    __syncthreads();
-    if (tid < 2 * D) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < 64; ++r) s += cs[r * CP + tid];
-      p.partials[(size_t)blockIdx.x * 2 * D + tid] = s;
-    }
+    // LayerNorm backward on dh = v, in row layout (fused_epilogue.h)
+    ln_bwd_rows_epilogue(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dy, p.out, p.outc,
+                         p.partials + (size_t)blockIdx.x * 2 * D);
   }
   if constexpr (VAR == 6) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -701,7 +583,7 @@ extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b
 
 // diagnostic: per-phase cycle sums of workgroup 0 written by the SITK_MLP_VAR=6 build (not part of the ABI header)
 extern "C" int sitk_mlp_debug_stamps(unsigned long long* out64) {
-  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
 }
 
 extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) { return rows > 0 ? (size_t)cdiv64(rows, 128) * 2 * MLP_D : 0; }
