@@ -17,6 +17,7 @@
 //     second kernel: bitwise reproducible, and none of the 24 MB of partials goes through float
 //     atomics (1.3 TB/s chip-wide, MI355X_MICROARCH.md).
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -44,6 +45,15 @@ __device__ u32x4 g_zero_page_wb[4];
 #define SITK_WB_TR2(dlo, dhi, areg, off, offhi) \
   "ds_read_b64_tr_b16 " dlo ", " areg " offset:" #off "\n\tds_read_b64_tr_b16 " dhi ", " areg " offset:" #offhi "\n\t"
 
+// MFMA with the accumulator tile pinned to the AGPR half of the register file ("+a").  The kernel holds 60
+// accumulator tiles (240 registers); left to the allocator they are parked in AGPRs and copied through VGPRs
+// around every MFMA (441 v_accvgpr moves per 64-MFMA stage, more issue slots than the MFMAs themselves).
+// Every tile is touched once per stage, so no two of these instructions are dependent within a stage; the
+// first compiler-visible reader comes after the barrier that ends the loop.
+SITK_DEV void mma_acc(f32x4& acc, u32x4 a, u32x4 b) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __restrict__ slab) {
   constexpr int STG = 5 * 8192;  // panels: P0 P1 Q0 Q1 Q2, each 64 rows x 128 B
   constexpr int NSTG = 4;
@@ -62,23 +72,37 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   const int mbeg = split * P.chunk, mend = min(P.M, mbeg + P.chunk);
   const char* zero = reinterpret_cast<const char*>(g_zero_page_wb);
 
-  // LDS-DMA: 40 pieces (8 rows x 128 B) per stage; wave w moves P pieces 4w..4w+3 and Q pieces 6w..6w+5
+  // LDS-DMA: 40 pieces (8 rows x 128 B) per stage; wave w moves P pieces 4w..4w+3 and Q pieces 6w..6w+5.
+  // Per-lane source pointers of the first stage are set up once; a stage costs one compare, one select and
+  // one 64-bit add per piece (columns outside the matrix and rows past the split read the zero page).
   const int r8 = lane >> 3;
-  auto issue = [&](int mt, int stage) {
+  const bf16* zerop = reinterpret_cast<const bf16*>(zero);
+  const bf16* pbase[10];
+  int prow[10], pdst[10];
+  size_t pstep[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const bool isP = i < 4;
+    const int q = isP ? wave * 4 + i : wave * 6 + (i - 4);
+    const int panel = q >> 3, row = (q & 7) * 8 + r8;
+    const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    const int col = (isP ? p0 : q0) + panel * 64 + ((lane & 7) ^ (key << 1)) * 8;
+    const bool colok = col < (isP ? P.cp : P.cq);
+    const int ld = isP ? P.ldp : P.ldq;
+    pbase[i] = colok ? (isP ? P.P : P.Q) + (size_t)(mbeg + row) * ld + col : zerop;
+    pstep[i] = colok ? (size_t)64 * ld : 0;
+    prow[i] = colok ? row : (1 << 30);                       // invalid columns never leave the zero page
+    pdst[i] = (isP ? 0 : 2 * 8192) + q * 1024;
+  }
+  const int rows_total = mend - mbeg;
+  auto issue = [&](int st_idx, int stage) {
     char* sb = smem + stage * STG;
+    const int left = rows_total - st_idx * 64;               // rows of this split still ahead (uniform)
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-      const bool isP = i < 4;
-      const int q = isP ? wave * 4 + i : wave * 6 + (i - 4);
-      const int panel = q >> 3, row = (q & 7) * 8 + r8;
-      const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
-      const int col = (isP ? p0 : q0) + panel * 64 + ((lane & 7) ^ (key << 1)) * 8;
-      const int m = mt + row;
-      const bool ok = m < mend && col < (isP ? P.cp : P.cq);
-      const bf16* src = ok ? (isP ? P.P + (size_t)m * P.ldp : P.Q + (size_t)m * P.ldq) + col : reinterpret_cast<const bf16*>(zero);
-      char* dst = sb + (isP ? 0 : 2 * 8192) + q * 1024;
+      const bf16* src = prow[i] < left ? pbase[i] + (size_t)st_idx * pstep[i] : zerop;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(sb + pdst[i]), 16, 0, 0);
     }
   };
 
@@ -111,55 +135,63 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   const int nstage = (mend - mbeg + 63) / 64;
 #pragma unroll
   for (int i = 0; i < NSTG - 1; ++i)
-    if (i < nstage) issue(mbeg + i * 64, i);
-  for (int s = 0; s < nstage; ++s) {
-    const int rem = min(NSTG - 2, nstage - 1 - s);
-    if (rem >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (rem == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (s + NSTG - 1 < nstage) issue(mbeg + (s + NSTG - 1) * 64, (s + NSTG - 1) % NSTG);
-    const uint32_t so = (s % NSTG) * STG;
-    const uint32_t b0 = toff[0] + so, b1 = toff[1] + so, b2 = toff[2] + so, b3 = toff[3] + so;
-    const uint32_t a0 = b0 + wh * 8192, a1 = b1 + wh * 8192, a2 = b2 + wh * 8192, a3 = b3 + wh * 8192;
-    u32x2 pl[4], ph[4], ql[12], qh[12];
-    asm volatile(
-        SITK_WB_TR2("%0", "%1", "%16", 0, 512) SITK_WB_TR2("%2", "%3", "%17", 0, 512)
-        SITK_WB_TR2("%4", "%5", "%18", 0, 512) SITK_WB_TR2("%6", "%7", "%19", 0, 512)
-        SITK_WB_TR2("%8", "%9", "%20", 16384, 16896) SITK_WB_TR2("%10", "%11", "%21", 16384, 16896)
-        SITK_WB_TR2("%12", "%13", "%22", 16384, 16896) SITK_WB_TR2("%14", "%15", "%23", 16384, 16896)
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(pl[0]), "=&v"(ph[0]), "=&v"(pl[1]), "=&v"(ph[1]), "=&v"(pl[2]), "=&v"(ph[2]), "=&v"(pl[3]), "=&v"(ph[3]),
-          "=&v"(ql[0]), "=&v"(qh[0]), "=&v"(ql[1]), "=&v"(qh[1]), "=&v"(ql[2]), "=&v"(qh[2]), "=&v"(ql[3]), "=&v"(qh[3])
-        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
-    asm volatile(
-        SITK_WB_TR2("%0", "%1", "%16", 24576, 25088) SITK_WB_TR2("%2", "%3", "%17", 24576, 25088)
-        SITK_WB_TR2("%4", "%5", "%18", 24576, 25088) SITK_WB_TR2("%6", "%7", "%19", 24576, 25088)
-        SITK_WB_TR2("%8", "%9", "%16", 32768, 33280) SITK_WB_TR2("%10", "%11", "%17", 32768, 33280)
-        SITK_WB_TR2("%12", "%13", "%18", 32768, 33280) SITK_WB_TR2("%14", "%15", "%19", 32768, 33280)
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(ql[4]), "=&v"(qh[4]), "=&v"(ql[5]), "=&v"(qh[5]), "=&v"(ql[6]), "=&v"(qh[6]), "=&v"(ql[7]), "=&v"(qh[7]),
-          "=&v"(ql[8]), "=&v"(qh[8]), "=&v"(ql[9]), "=&v"(qh[9]), "=&v"(ql[10]), "=&v"(qh[10]), "=&v"(ql[11]), "=&v"(qh[11])
-        : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
-    __builtin_amdgcn_sched_barrier(0);
-    u32x4 fp[4], fqv[12];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fp[i] = u32x4{pl[i][0], pl[i][1], ph[i][0], ph[i][1]};
-#pragma unroll
-    for (int j = 0; j < 12; ++j) fqv[j] = u32x4{ql[j][0], ql[j][1], qh[j][0], qh[j][1]};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 12; ++j) acc[i][j] = Mma<bf16>::mma(fp[i], fqv[j], acc[i][j]);
-    if (biasP) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) accb[i] = Mma<bf16>::mma(fp[i], ones, accb[i]);
+    if (i < nstage) issue(i, i);
+  // The stage loop exists in three instantiations (no bias / dY on the P side / dY on the Q side), chosen once per
+  // workgroup: with the bias MFMAs under a run-time condition inside ONE loop, hipcc carried the 12 bias tiles
+  // through VGPR copies of their AGPRs in every stage (441 v_accvgpr moves per 64 MFMAs).
+  auto stages = [&](auto bp, auto bq) {
+    for (int s = 0; s < nstage; ++s) {
+      const int rem = min(NSTG - 2, nstage - 1 - s);
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + NSTG - 1 < nstage) issue(s + NSTG - 1, (s + NSTG - 1) % NSTG);
+      const uint32_t so = (s % NSTG) * STG;
+      const uint32_t b0 = toff[0] + so, b1 = toff[1] + so, b2 = toff[2] + so, b3 = toff[3] + so;
+      const uint32_t a0 = b0 + wh * 8192, a1 = b1 + wh * 8192, a2 = b2 + wh * 8192, a3 = b3 + wh * 8192;
+      u32x2 pl[4], ph[4], ql[12], qh[12];
+      asm volatile(
+          SITK_WB_TR2("%0", "%1", "%16", 0, 512) SITK_WB_TR2("%2", "%3", "%17", 0, 512)
+          SITK_WB_TR2("%4", "%5", "%18", 0, 512) SITK_WB_TR2("%6", "%7", "%19", 0, 512)
+          SITK_WB_TR2("%8", "%9", "%20", 16384, 16896) SITK_WB_TR2("%10", "%11", "%21", 16384, 16896)
+          SITK_WB_TR2("%12", "%13", "%22", 16384, 16896) SITK_WB_TR2("%14", "%15", "%23", 16384, 16896)
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(pl[0]), "=&v"(ph[0]), "=&v"(pl[1]), "=&v"(ph[1]), "=&v"(pl[2]), "=&v"(ph[2]), "=&v"(pl[3]), "=&v"(ph[3]),
+            "=&v"(ql[0]), "=&v"(qh[0]), "=&v"(ql[1]), "=&v"(qh[1]), "=&v"(ql[2]), "=&v"(qh[2]), "=&v"(ql[3]), "=&v"(qh[3])
+          : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+      asm volatile(
+          SITK_WB_TR2("%0", "%1", "%16", 24576, 25088) SITK_WB_TR2("%2", "%3", "%17", 24576, 25088)
+          SITK_WB_TR2("%4", "%5", "%18", 24576, 25088) SITK_WB_TR2("%6", "%7", "%19", 24576, 25088)
+          SITK_WB_TR2("%8", "%9", "%16", 32768, 33280) SITK_WB_TR2("%10", "%11", "%17", 32768, 33280)
+          SITK_WB_TR2("%12", "%13", "%18", 32768, 33280) SITK_WB_TR2("%14", "%15", "%19", 32768, 33280)
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(ql[4]), "=&v"(qh[4]), "=&v"(ql[5]), "=&v"(qh[5]), "=&v"(ql[6]), "=&v"(qh[6]), "=&v"(ql[7]), "=&v"(qh[7]),
+            "=&v"(ql[8]), "=&v"(qh[8]), "=&v"(ql[9]), "=&v"(qh[9]), "=&v"(ql[10]), "=&v"(qh[10]), "=&v"(ql[11]), "=&v"(qh[11])
+          : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+      __builtin_amdgcn_sched_barrier(0);
+      u32x4 fp[4], fqv[12];
+  #pragma unroll
+      for (int i = 0; i < 4; ++i) fp[i] = u32x4{pl[i][0], pl[i][1], ph[i][0], ph[i][1]};
+  #pragma unroll
+      for (int j = 0; j < 12; ++j) fqv[j] = u32x4{ql[j][0], ql[j][1], qh[j][0], qh[j][1]};
+  #pragma unroll
+      for (int i = 0; i < 4; ++i)
+  #pragma unroll
+        for (int j = 0; j < 12; ++j) mma_acc(acc[i][j], fp[i], fqv[j]);
+      if constexpr (decltype(bp)::value) {
+  #pragma unroll
+        for (int i = 0; i < 4; ++i) mma_acc(accb[i], fp[i], ones);
+      }
+      if constexpr (decltype(bq)::value) {
+  #pragma unroll
+        for (int j = 0; j < 12; ++j) mma_acc(accb[j], ones, fqv[j]);
+      }
     }
-    if (biasQ) {
-#pragma unroll
-      for (int j = 0; j < 12; ++j) accb[j] = Mma<bf16>::mma(ones, fqv[j], accb[j]);
-    }
-  }
+  };
+  if (biasP) stages(std::true_type{}, std::false_type{});
+  else if (biasQ) stages(std::false_type{}, std::true_type{});
+  else stages(std::false_type{}, std::false_type{});
   __builtin_amdgcn_s_barrier();   // every wave is done with the ring: reuse it for the token-half reduction
 
   // acc[i][j][jj] <-> P column (row of the tile) wh*64 + 16i + 4fq + jj, Q column 16j + fr
