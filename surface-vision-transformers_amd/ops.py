@@ -199,20 +199,21 @@ def mlp_fwd(x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
     return out, h, mean, rstd, u, g
 
 
-def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, dtype):
-    """returns (dx, dx_c, du, g, partials (workgroups, 2, D))"""
+def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, dtype, want_g=True):
+    """returns (dx, dx_c, du, g, partials (workgroups, 2, D)); g = gelu(u) is recomputed and returned when want_g
+    (callers that saved g in forward pass want_g=False: g is None)"""
     rows, D = x.shape
     M = u.shape[1]
     code = rt.dtype_code(dtype)
     du = torch.empty_like(u)
-    g = torch.empty_like(u)
+    g = torch.empty_like(u) if want_g else None
     dx = torch.empty_like(x)
     dx_c = torch.empty((rows, D), dtype=u.dtype, device=x.device)
     nfl = rt.lib.sitk_mlp_bwd_partial_floats(rows)
     partials = torch.empty(nfl, dtype=torch.float32, device=x.device)
     rt.check(rt.lib.sitk_mlp_bwd(dy.data_ptr(), dy_c.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                  ln_w.data_ptr(), w2t_c.data_ptr(), w1t_c.data_ptr(), u.data_ptr(), du.data_ptr(),
-                                 g.data_ptr(), dx.data_ptr(), dx_c.data_ptr(), partials.data_ptr(), rows, D, M, code,
+                                 rt.ptr(g), dx.data_ptr(), dx_c.data_ptr(), partials.data_ptr(), rows, D, M, code,
                                  rt.stream_ptr()))
     return dx, dx_c, du, g, partials.view(-1, 2, D)
 

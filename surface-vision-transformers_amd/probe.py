@@ -1,7 +1,8 @@
 """Per-kernel timing of the hot path at the live workload's shapes (bench.py's `roofline` object).
 
 Every kernel family of one encoder layer is launched exactly as csrc/encoder.hip launches it (same
-entry point, operand dtypes, epilogue, workspace) `reps` times inside a hipGraph, and the replay is
+entry point, operand dtypes, epilogue, workspace; the fused LayerNorm+MLP / LayerNorm+to_qkv kernels where
+the shape supports them, the separate kernels otherwise) `reps` times inside a hipGraph, and the replay is
 timed between two HIP events on the replay stream: no host launch gap is included.  The family with
 the largest (average duration x launches per step) is the dominant kernel; its achieved rate =
 algorithmic FLOPs (or bytes) per launch / average duration.  The rocprofv3 --kernel-trace --stats
@@ -67,29 +68,57 @@ def layer_kernels(eng):
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     att = 4.0 * B * H * N * N * 64
     wg_flops = 2.0 * R * (D * M * 2 + D * I + 3 * I * D)
-    return [
-        ("layernorm_fwd", "layernorm_fwd_kernel", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), 2 * L),
-        ("to_qkv", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(h, wqkv, out_qkv, dt), 2.0 * R * 3 * I * D, R * (D + 3 * I) * es, L),
-        ("attention forward", "attn_fwd_res_kernel", lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt), att, R * 4 * I * es, L),
-        ("to_out + residual", "gemm_nt_wres_kernel",
-         lambda: ops.gemm_nt(o, wo, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * I, R * (I * es + 8 * D), L),
-        ("net.0 + GELU", "gemm_nt_wres_kernel",
-         lambda: ops.gemm_nt(h, w1, out_u, dt, epilogue=ops.EPI_BIAS_GELU, bias=bM, out2=out_g), 2.0 * R * M * D, R * (D + 2 * M) * es, L),
-        ("net.3 + residual", "gemm_nt_n192_kernel",
-         lambda: ops.gemm_nt(gg, w2, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * M, R * (M * es + 8 * D), L),
-        ("d net.3 (x GELU')", "gemm_nt_wres_kernel",
-         lambda: ops.gemm_nt(dxc, w2_t, out_u, dt, epilogue=ops.EPI_DGELU, aux=u), 2.0 * R * D * M, R * (D + 2 * M) * es, L),
-        ("d net.0", "gemm_nt_n192_kernel", lambda: ops.gemm_nt(u, w1_t, out_h, dt), 2.0 * R * D * M, R * (M + D) * es, L),
-        ("layernorm_bwd", "layernorm_bwd_kernel",
-         lambda: ops.layernorm_bwd(h, x32, mean, rstd, gam, dx32, dbD, dbD2, dt, dx=out_x, dx_c=out_xc, partials=part),
-         0, R * D * (2 * es + 12), 2 * L),
-        ("d to_out", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(dxc, wo_t, out_o, dt), 2.0 * R * D * I, R * (D + I) * es, L),
-        ("attention backward", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
-         lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt), 2.5 * att, R * 8 * I * es, L),
-        ("weight gradients of the layer", "wgrad_big_kernel + wgrad_big_reduce_kernel",
-         lambda: ops.gemm_wgrad_group(probs, dt, workspace=ws), wg_flops, R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L),
-        ("d to_qkv", "gemm_nt_n192_kernel", lambda: ops.gemm_nt(qkv, wqkv_t, out_h, dt), 2.0 * R * 3 * I * D, R * (3 * I + D) * es, L),
-    ]
+    mlp_flops = 4.0 * R * D * M
+    fused_mlp = ops.mlp_fused_supported(D, M, dt)
+    fused_qkv = ops.ln_gemm_fused_supported(D, 3 * I, dt)
+    rows = []
+    # ---- forward ----
+    if fused_qkv:
+        rows.append(("norm + to_qkv (fused)", "ln_gemm_fwd_kernel", lambda: ops.ln_gemm_fwd(x32, gam, bD, wqkv, dt),
+                     2.0 * R * 3 * I * D, R * (4 * D + (D + 3 * I) * es), L))
+    else:
+        rows.append(("layernorm_fwd", "layernorm_fwd_kernel", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), L))
+        rows.append(("to_qkv", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(h, wqkv, out_qkv, dt), 2.0 * R * 3 * I * D, R * (D + 3 * I) * es, L))
+    rows.append(("attention forward", "attn_fwd_res_kernel", lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt), att, R * 4 * I * es, L))
+    rows.append(("to_out + residual", "gemm_nt_wres_kernel",
+                 lambda: ops.gemm_nt(o, wo, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * I, R * (I * es + 8 * D), L))
+    if fused_mlp:
+        rows.append(("norm + net.0 + GELU + net.3 + residual (fused)", "mlp_kernel<false>",
+                     lambda: ops.mlp_fwd(x32, gam, bD, w1, bM, w2, bD, dt, want_g=True), mlp_flops,
+                     R * (8 * D + (D + 2 * M) * es), L))
+    else:
+        rows.append(("layernorm_fwd (2)", "layernorm_fwd_kernel", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), L))
+        rows.append(("net.0 + GELU", "gemm_nt_wres_kernel",
+                     lambda: ops.gemm_nt(h, w1, out_u, dt, epilogue=ops.EPI_BIAS_GELU, bias=bM, out2=out_g), 2.0 * R * M * D, R * (D + 2 * M) * es, L))
+        rows.append(("net.3 + residual", "gemm_nt_n192_kernel",
+                     lambda: ops.gemm_nt(gg, w2, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * M, R * (M * es + 8 * D), L))
+    # ---- backward ----
+    if fused_mlp:
+        rows.append(("d net.3 x GELU' + d net.0 + norm backward (fused)", "mlp_kernel<true>",
+                     lambda: ops.mlp_bwd(dx32, dxc, x32, mean, rstd, gam, w2_t, w1_t, u, dt, want_g=False), mlp_flops,
+                     R * (D * es + 2 * M * es + 12 * D + D * es), L))
+    else:
+        rows.append(("d net.3 (x GELU')", "gemm_nt_wres_kernel",
+                     lambda: ops.gemm_nt(dxc, w2_t, out_u, dt, epilogue=ops.EPI_DGELU, aux=u), 2.0 * R * D * M, R * (D + 2 * M) * es, L))
+        rows.append(("d net.0", "gemm_nt_n192_kernel", lambda: ops.gemm_nt(u, w1_t, out_h, dt), 2.0 * R * D * M, R * (M + D) * es, L))
+        rows.append(("layernorm_bwd (2)", "layernorm_bwd_kernel",
+                     lambda: ops.layernorm_bwd(h, x32, mean, rstd, gam, dx32, dbD, dbD2, dt, dx=out_x, dx_c=out_xc, partials=part),
+                     0, R * D * (2 * es + 12), L))
+    rows.append(("d to_out", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(dxc, wo_t, out_o, dt), 2.0 * R * D * I, R * (D + I) * es, L))
+    rows.append(("attention backward", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
+                 lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt), 2.5 * att, R * 8 * I * es, L))
+    rows.append(("weight gradients of the layer", "wgrad_big_kernel + wgrad_big_reduce_kernel",
+                 lambda: ops.gemm_wgrad_group(probs, dt, workspace=ws), wg_flops, R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L))
+    if fused_qkv:
+        rows.append(("d to_qkv + norm backward (fused)", "ln_gemm_bwd_kernel",
+                     lambda: ops.ln_gemm_bwd(qkv, wqkv_t, x32, mean, rstd, gam, dx32, dt), 2.0 * R * 3 * I * D,
+                     R * (3 * I * es + 12 * D + D * es), L))
+    else:
+        rows.append(("d to_qkv", "gemm_nt_n192_kernel", lambda: ops.gemm_nt(qkv, wqkv_t, out_h, dt), 2.0 * R * 3 * I * D, R * (3 * I + D) * es, L))
+        rows.append(("layernorm_bwd", "layernorm_bwd_kernel",
+                     lambda: ops.layernorm_bwd(h, x32, mean, rstd, gam, dx32, dbD, dbD2, dt, dx=out_x, dx_c=out_xc, partials=part),
+                     0, R * D * (2 * es + 12), L))
+    return rows
 
 
 def _desc_array(problems):
