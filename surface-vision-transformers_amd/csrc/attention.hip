@@ -379,6 +379,15 @@ __device__ u32x4 g_zero_page_attn[4];
 // Per-lane byte offsets into a 64-row bf16 tile, computed ONCE per kernel: with them every fragment
 // read is `tile + lane offset + compile-time immediate` (the XOR swizzle of lds_off() depends only on
 // lane bits here; recomputing it per read cost more VALU than the softmax itself).
+// Swizzle of the sequence-resident tiles.  The transposed reads below take 4-row blocks that are FOUR rows apart
+// in the two 16-lane groups of a half wave (rows 4 fq + q: the accumulator layout of the probabilities), for which
+// the generic key of common.h (row bits 1 and 3, built for blocks eight rows apart) leaves rows r and r + 4 on the
+// same banks: a 2-way conflict on every ds_read_b64_tr_b16 (SQ_LDS_BANK_CONFLICT = 27 % of the LDS cycles of the
+// backward kernels, profiles/r01_pmc_attention_bwd.txt).  Row bits 1 and 2 give the 8 rows of a half-wave read 8
+// distinct (parity, window) slots and keep the 16-row ds_read_b128 pattern conflict-free.
+SITK_DEV int attn_res_key(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 1); }
+SITK_DEV int attn_res_off(int row, int byte_in_row) { return row * 128 + (byte_in_row ^ (attn_res_key(row) << 5)); }
+
 struct LaneOffs {
   int row[2];  // row-read (ds_read_b128) offset of k-step ks for row (lane&15):  + t * 2048 per 16-row block
   int tr[4];   // transposed-read offset of column block dt for row 4*(lane>>4) + ((lane>>2)&3): + s2*4096, + 2048 (second half)
@@ -387,10 +396,10 @@ SITK_DEV LaneOffs lane_offs_bf16(int lane) {
   LaneOffs o;
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) o.row[ks] = lds_off(fr, ks * 64 + fq * 16);
+  for (int ks = 0; ks < 2; ++ks) o.row[ks] = attn_res_off(fr, ks * 64 + fq * 16);
   const int r = 4 * fq + ((lane >> 2) & 3);
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) o.tr[dt] = lds_off(r, (16 * dt + 4 * (lane & 3)) * 2);
+  for (int dt = 0; dt < 4; ++dt) o.tr[dt] = attn_res_off(r, (16 * dt + 4 * (lane & 3)) * 2);
   return o;
 }
 SITK_DEV void row_mma_o(f32x4 (&s)[4], const char* tile, const u32x4 (&frag)[2], const LaneOffs& o) {
@@ -428,8 +437,7 @@ SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, 
   const char* zero = reinterpret_cast<const char*>(g_zero_page_attn);
   for (int q = wave; q < ntiles * 8; q += nwaves) {      // one piece = 8 rows x 128 B
     const int row = q * 8 + (lane >> 3), r64 = row & 63;
-    const int key = ((r64 >> 1) & 1) | (((r64 >> 3) & 1) << 1);
-    const int chunk = (lane & 7) ^ (key << 1);
+    const int chunk = (lane & 7) ^ (attn_res_key(r64) << 1);
     const char* g = row < nrows ? reinterpret_cast<const char*>(src + (size_t)row * ld + chunk * 8) : zero;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);

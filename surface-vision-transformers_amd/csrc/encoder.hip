@@ -300,7 +300,7 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     if (mlp_fused(c)) {
       SITK_TRY(sitk_mlp_bwd(dx, S.dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, S.du, a.g ? nullptr : S.g, S.dxB, S.dxBc,
                             part2, R, D, M, dt, stream));
-      ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, cdiv(R, 128)});
+      ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, (int)(sitk_mlp_bwd_partial_floats(R) / (2 * D))});
       gact = a.g ? a.g : S.g;
     } else {
       sitk_gemm_desc d1 = gemm_desc(R, M, D, S.dxAc, D, 0, a.w2_t, SITK_EPI_DGELU, S.du, M, 0);
@@ -327,7 +327,7 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     if (qkv_fused(c)) {
       SITK_TRY(sitk_ln_gemm_bwd(S.dqkv, a.wqkv_t, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, part1, R, D, 3 * I, dt,
                                 stream));
-      ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, cdiv(R, 128)});
+      ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, (int)(sitk_ln_gemm_bwd_partial_floats(R) / (2 * D))});
     } else {
       sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, S.dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
       SITK_TRY(sitk_gemm_nt(&d4, dt, stream));

@@ -17,13 +17,20 @@ namespace sitk {
 
 constexpr int FE_D = 192;
 constexpr int FE_PITCH = 196;                              // floats; rows shift by 16 B per row in the 256-B bank window
-constexpr int FE_ROWBUF_BYTES = 128 * FE_PITCH * 4;        // 100352
-constexpr int FE_COLBUF_BYTES = 32 * 2 * FE_D * 4;         // [wave][sub][2][192] column partials = 49152 (aliases the row buffer)
-constexpr int FE_SMEM_BYTES = FE_ROWBUF_BYTES;
+// A workgroup owns 32 TG rows (TG token groups of 32 rows = 2 TG waves); TG = 4 or 3 (see fused_block_rows()).
+constexpr int fe_smem_bytes(int tg) { return 32 * tg * FE_PITCH * 4; }   // row buffer (the column partials alias it)
+constexpr int FE_SMEM_BYTES = fe_smem_bytes(4);            // 100352
+
+// Rows per workgroup of the fused kernels for a problem of `rows` tokens.  Every such kernel is a single wave of
+// workgroups (one per CU), so its duration is that of ONE workgroup: 96-row workgroups are 25 % shorter than
+// 128-row ones as long as all of them still fit on the 256 CUs at once (BASELINE config 2: 20 544 rows = 214
+// workgroups of 96 instead of 161 of 128).
+static inline int fused_block_rows(int64_t rows) { return (rows + 95) / 96 <= 256 ? 96 : 128; }
 
 // v[i][t]: this wave's finished half of dh -- features 96 hh + 16 i + 4 fq + e of token 32 tg + 16 t + fr
 // (pair exchange already done).  smem: >= FE_SMEM_BYTES, free for use by every wave (callers sync before).
-// All 512 threads of the workgroup must call it.
+// All threads of the workgroup must call it.
+template <int TG>
 SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, int blk0, int R, const float* __restrict__ x,
                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                    const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
@@ -35,7 +42,8 @@ SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, 
   float* rowbuf = reinterpret_cast<float*>(smem);
 
   // ---- request this wave's 16 rows of x and dres (4 passes x 3 x 16 B per lane each), statistics, gamma ----
-  const size_t nrows = (size_t)(R - blk0 < 128 ? R - blk0 : 128);
+  constexpr int BLK = 32 * TG;
+  const size_t nrows = (size_t)(R - blk0 < BLK ? R - blk0 : BLK);
   const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)blk0 * D, 0,
                                                                        (int)(nrows * D * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dres ? dres : x) + (size_t)blk0 * D, 0,
@@ -126,12 +134,13 @@ SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, 
   if (tid < 2 * D) {
     float s = 0.f;
 #pragma unroll 8
-    for (int q = 0; q < 32; ++q) s += colbuf[q * 2 * D + tid];
+    for (int q = 0; q < 8 * TG; ++q) s += colbuf[q * 2 * D + tid];
     partials_block[tid] = s;
   }
 }
 
 // Forward counterpart: out = v + bias + x, rows of x re-read and rows of out written whole (same layouts as above).
+template <int TG>
 SITK_DEV void residual_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, int blk0, int R, const float* __restrict__ x,
                                      const float* __restrict__ bias, float* __restrict__ out) {
   constexpr int D = FE_D;
@@ -139,7 +148,8 @@ SITK_DEV void residual_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid
   const int fr = lane & 15, fq = lane >> 4, tg = wave >> 1, hh = wave & 1;
   const int j = lane & 15, sub = lane >> 4;
   float* rowbuf = reinterpret_cast<float*>(smem);
-  const size_t nrows = (size_t)(R - blk0 < 128 ? R - blk0 : 128);
+  constexpr int BLK = 32 * TG;
+  const size_t nrows = (size_t)(R - blk0 < BLK ? R - blk0 : BLK);
   const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)blk0 * D, 0,
                                                                        (int)(nrows * D * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_o = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)blk0 * D, 0, (int)(nrows * D * 4), 0x00020000);

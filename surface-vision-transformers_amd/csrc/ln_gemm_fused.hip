@@ -39,7 +39,7 @@ struct LnGemmParams {
 constexpr int LG_D = 192;
 constexpr int LG_WB = 24576;                   // one weight chunk: 24 pieces of 8 rows x 128 B
 constexpr int LG_OFF_H = 2 * LG_WB;            // forward: operand strip 3 k-panels x 128 rows x 128 B = 48 KB
-constexpr int LG_SMEM_FWD = LG_OFF_H + 3 * 128 * 128;
+constexpr int LG_SMEM_FWD = LG_OFF_H + 3 * 128 * 128;   // (TG = 4; TG = 3 uses the first 3 x 96 rows of every panel)
 constexpr int LG_SMEM_BWD = FE_SMEM_BYTES > 8 * 12288 ? FE_SMEM_BYTES : 8 * 12288;   // exchange area / row-layout epilogue
 
 SITK_DEV uint32_t lg_pack_bf16(float a, float b) {
@@ -70,22 +70,23 @@ SITK_DEV __amdgpu_buffer_rsrc_t lg_rsrc(const void* p, size_t bytes) {
 // ------------------------------------------------------------------------------------------------------
 // forward: y = LayerNorm(x) W^T
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
-  constexpr int D = LG_D;
+template <int TG>
+__global__ __launch_bounds__(128 * TG) void ln_gemm_fwd_kernel(LnGemmParams p) {
+  constexpr int D = LG_D, BLK = 32 * TG, NW = 2 * TG, PPW = 24 / NW;   // rows, waves, DMA pieces per wave and chunk
   __shared__ __attribute__((aligned(256))) char smem[LG_SMEM_FWD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int tg = wave >> 1, hh = wave & 1;
-  const int blk0 = blockIdx.x * 128;
+  const int blk0 = blockIdx.x * BLK;
   const int N = p.N, nchunks = N / 64;
 
-  // ---- W chunk DMA: 24 pieces of 8 slot rows x 128 B (3 k-panels x 64 rows), 3 per wave.  Slot row
+  // ---- W chunk DMA: 24 pieces of 8 slot rows x 128 B (3 k-panels x 64 rows), PPW per wave.  Slot row
   //      32 hs + 16 it + r holds output feature 32 hs + 8 (r >> 2) + 4 it + (r & 3) of the chunk ----
   const int r8 = lane >> 3;
-  int soff[3];
+  int soff[PPW];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int qq = wave * 3 + i;
+  for (int i = 0; i < PPW; ++i) {
+    const int qq = wave * PPW + i;
     const int kt = qq >> 3, s = (qq & 7) * 8 + r8;
     const int r = s & 15, it = (s >> 4) & 1, hs = s >> 5;
     const int feat = 32 * hs + 8 * (r >> 2) + 4 * it + (r & 3);
@@ -93,10 +94,10 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
     soff[i] = feat * D + kt * 64 + (((lane & 7) ^ (key << 1)) * 8);
   }
   auto issue = [&](int c, int buf) {
-    char* base = smem + buf * LG_WB + wave * 3 * 1024;
+    char* base = smem + buf * LG_WB + wave * PPW * 1024;
     const bf16* src = p.w + (size_t)c * 64 * D;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < PPW; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
                                        (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
   };
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
 #endif
 
   // per-workgroup buffer descriptors (see mlp_fused.hip): rows past R read 0 / are not written
-  const size_t nrows = (size_t)(p.R - blk0 < 128 ? p.R - blk0 : 128);
+  const size_t nrows = (size_t)(p.R - blk0 < BLK ? p.R - blk0 : BLK);
   const size_t RD = nrows * D, oD = (size_t)blk0 * D;
   const __amdgpu_buffer_rsrc_t r_x = lg_rsrc(p.x + oD, RD * 4);
   const __amdgpu_buffer_rsrc_t r_h = lg_rsrc(p.h + oD, p.h ? RD * 2 : 0);
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
         for (int e = 0; e < 4; ++e) o[e] = ok ? (v[pass][i][e] - mu) * rs * gm[i][e] + bt[i][e] : 0.f;
         const int byte = c4 * 8;
         const u32x2 ob = {lg_pack_bf16(o[0], o[1]), lg_pack_bf16(o[2], o[3])};
-        *reinterpret_cast<u32x2*>(sH + (byte >> 7) * (128 * 128) + lds_off(r, byte & 127)) = ob;
+        *reinterpret_cast<u32x2*>(sH + (byte >> 7) * (BLK * 128) + lds_off(r, byte & 127)) = ob;
         if (p.h) __builtin_amdgcn_raw_buffer_store_b64(ob, r_h, (r * D + 4 * c4) * 2, 0, 0);
       }
       if (ok && j == 0 && p.mean) { p.mean[row] = mu; p.rstd[row] = rs; }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int k = 0; k < 6; ++k)
-      hf[t][k] = *reinterpret_cast<const u32x4*>(sH + (k >> 1) * (128 * 128) +
+      hf[t][k] = *reinterpret_cast<const u32x4*>(sH + (k >> 1) * (BLK * 128) +
                                                  lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
 
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -236,34 +237,35 @@ __global__ __launch_bounds__(512) void ln_gemm_fwd_kernel(LnGemmParams p) {
 // ------------------------------------------------------------------------------------------------------
 // backward: dx = dres + LayerNorm'(dy W)
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void ln_gemm_bwd_kernel(LnGemmParams p) {
-  constexpr int D = LG_D;
+template <int TG>
+__global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
+  constexpr int D = LG_D, BLK = 32 * TG, NW = 2 * TG, PPW = 24 / NW;
   __shared__ __attribute__((aligned(256))) char smem[LG_SMEM_BWD];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int tg = wave >> 1, hh = wave & 1;
-  const int blk0 = blockIdx.x * 128;
+  const int blk0 = blockIdx.x * BLK;
   const int N = p.N, nchunks = N / 64;
 
-  // ---- W^T chunk DMA: 192 rows x 64 k (128 B), 24 pieces of 8 rows, 3 per wave ----
+  // ---- W^T chunk DMA: 192 rows x 64 k (128 B), 24 pieces of 8 rows, PPW per wave ----
   const int r8 = lane >> 3;
-  int soff[3];
+  int soff[PPW];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int row = (wave * 3 + i) * 8 + r8;
+  for (int i = 0; i < PPW; ++i) {
+    const int row = (wave * PPW + i) * 8 + r8;
     const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
     soff[i] = row * N + (((lane & 7) ^ (key << 1)) * 8);
   }
   auto issue = [&](int c, int buf) {
-    char* base = smem + buf * LG_WB + wave * 3 * 1024;
+    char* base = smem + buf * LG_WB + wave * PPW * 1024;
     const bf16* src = p.w + (size_t)c * 64;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < PPW; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
                                        (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
   };
 
-  const size_t nrows = (size_t)(p.R - blk0 < 128 ? p.R - blk0 : 128);
+  const size_t nrows = (size_t)(p.R - blk0 < BLK ? p.R - blk0 : BLK);
   const __amdgpu_buffer_rsrc_t r_y = lg_rsrc(p.y + (size_t)blk0 * N, nrows * N * 2);
   const int vo[2] = {((32 * tg + fr) * N + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * N + 32 * hh + 8 * fq) * 2};
   // B fragments of chunk c: the lane's 8 consecutive k of token tile t, fetched one chunk ahead (before the DMA)
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(512) void ln_gemm_bwd_kernel(LnGemmParams p) {
       }
   }
   // ---- LayerNorm backward on dh = v, in row layout (fused_epilogue.h) ----
-  ln_bwd_rows_epilogue(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dres, p.dx, p.dxc,
+  ln_bwd_rows_epilogue<TG>(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dres, p.dx, p.dxc,
                        p.partials + (size_t)blockIdx.x * 2 * D);
 }
 
@@ -368,11 +370,15 @@ extern "C" int sitk_ln_gemm_fwd(const float* x, const float* ln_w, const float* 
   p.x = x; p.gamma = ln_w; p.beta = ln_b; p.w = reinterpret_cast<const bf16*>(w_c);
   p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd; p.y = reinterpret_cast<bf16*>(y);
   p.R = (int)rows; p.N = N;
-  hipLaunchKernelGGL(ln_gemm_fwd_kernel, dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  if (fused_block_rows(rows) == 96) hipLaunchKernelGGL(ln_gemm_fwd_kernel<3>, dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  else hipLaunchKernelGGL(ln_gemm_fwd_kernel<4>, dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("ln_gemm_fwd");
 }
 
-extern "C" size_t sitk_ln_gemm_bwd_partial_floats(int64_t rows) { return rows > 0 ? (size_t)cdiv64(rows, 128) * 2 * LG_D : 0; }
+extern "C" size_t sitk_ln_gemm_bwd_partial_floats(int64_t rows) {
+  return rows > 0 ? (size_t)cdiv64(rows, fused_block_rows(rows)) * 2 * LG_D : 0;
+}
 
 extern "C" int sitk_ln_gemm_bwd(const void* dy, const void* wt_c, const float* x, const float* mean, const float* rstd,
                                 const float* ln_w, const float* dres, float* dx, void* dx_c, float* partials, int64_t rows,
@@ -385,6 +391,8 @@ extern "C" int sitk_ln_gemm_bwd(const void* dy, const void* wt_c, const float* x
   p.y = const_cast<bf16*>(reinterpret_cast<const bf16*>(dy));
   p.dres = dres; p.dx = dx; p.dxc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.N = N;
-  hipLaunchKernelGGL(ln_gemm_bwd_kernel, dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  if (fused_block_rows(rows) == 96) hipLaunchKernelGGL(ln_gemm_bwd_kernel<3>, dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  else hipLaunchKernelGGL(ln_gemm_bwd_kernel<4>, dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("ln_gemm_bwd");
 }

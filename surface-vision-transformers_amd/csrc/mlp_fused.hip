@@ -118,29 +118,32 @@ constexpr int MLP_OFF_TAB_F = MLP_OFF_B1 + MLP_MAX_M * 4;        // forward: {Ph
 constexpr int MLP_OFF_TAB_B = MLP_OFF_B1;                        // backward (no bias): {Phi, dPhi, pdf, dpdf} x 768 = 12 KB
 constexpr int MLP_SMEM = MLP_OFF_B1 + 12288;
 
-template <bool BWD, int VAR = 0>
-__global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
-  constexpr int D = MLP_D;
+// TG = token groups (of 32 rows = 2 waves) per workgroup: 4 (128 rows, 8 waves) or 3 (96 rows, 6 waves);
+// see fused_block_rows() in fused_epilogue.h.
+template <bool BWD, int VAR = 0, int TG = 4>
+__global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
+  constexpr int D = MLP_D, BLK = 32 * TG, NT = 128 * TG, PPW = 24 / TG;   // rows, threads, DMA pieces per wave and chunk
   constexpr int W1B = MLP_W1B, W2B = MLP_W2B;
   __shared__ __attribute__((aligned(256))) char smem[MLP_SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int tg = wave >> 1, hh = wave & 1;
-  const int blk0 = blockIdx.x * 128;
+  const int blk0 = blockIdx.x * BLK;
   const int nchunks = p.M / 64;
   const int M = p.M;
   unsigned long long t_kernel0 = 0;
   if constexpr (VAR == 6) t_kernel0 = __builtin_amdgcn_s_memtime();
 
-  // ---- W chunk DMA: 48 pieces of 8 rows x 128 B; waves 0-3 carry Wa (24 pieces), waves 4-7 Wb ----
+  // ---- W chunk DMA: 48 pieces of 8 rows x 128 B; waves 0..TG-1 carry Wa (24 pieces), waves TG..2TG-1 Wb ----
   const int r8 = lane >> 3;
-  const bool isA = wave < 4;
+  const bool isA = wave < TG;
+  const int wsub = isA ? wave : wave - TG;                    // index among the waves that carry the same matrix
   const bf16* wsrc = isA ? p.wa : p.wb;
   const int cstep = isA ? 64 * D : 64;                         // element step per chunk
-  int soff[6];
+  int soff[PPW];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int qq = (wave & 3) * 6 + i;                         // piece within its matrix, 0..23
+  for (int i = 0; i < PPW; ++i) {
+    const int qq = wsub * PPW + i;                             // piece within its matrix, 0..23
     if (isA) {
       const int kt = qq >> 3, s = (qq & 7) * 8 + r8;           // slot row in the 64-row panel
       const int r = s & 15, it = (s >> 4) & 1, hs = s >> 5;
@@ -154,10 +157,10 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
     }
   }
   auto issue = [&](int c, int buf) {
-    char* base = smem + buf * (W1B + W2B) + (isA ? 0 : W1B) + (wave & 3) * 6 * 1024;
+    char* base = smem + buf * (W1B + W2B) + (isA ? 0 : W1B) + wsub * PPW * 1024;
     const bf16* src = wsrc + (size_t)c * cstep;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < PPW; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
                                        (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
   };
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   float tv[2][2][2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int i = tid + 512 * k;
+    const int i = tid + NT * k;
     const int ii = i < MLP_TAB_N ? i : 0;
     tv[k][0][0] = g_gelu_table[ii][0]; tv[k][0][1] = g_gelu_table[ii][1];
     tv[k][1][0] = g_gelu_table[ii + 1][0]; tv[k][1][1] = g_gelu_table[ii + 1][1];
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   auto store_tables = [&]() {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int i = tid + 512 * k;
+      const int i = tid + NT * k;
       if (i < MLP_TAB_N) {
         if constexpr (!BWD)
           *reinterpret_cast<f32x2*>(smem + MLP_OFF_TAB_F + i * 8) = f32x2{tv[k][0][0], tv[k][1][0] - tv[k][0][0]};
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   // operations (the vmcnt bookkeeping below relies on it), and the chunk offset rides in the scalar offset
   // (no VALU address arithmetic).  The hardware range-checks the VGPR offset only -- never the scalar
   // offset -- which is why the descriptor is per workgroup and the scalar offset stays inside a row.
-  const size_t nrows = (size_t)(p.R - blk0 < 128 ? p.R - blk0 : 128);
+  const size_t nrows = (size_t)(p.R - blk0 < BLK ? p.R - blk0 : BLK);
   const size_t RD = nrows * D, RM = nrows * M, oD = (size_t)blk0 * D, oM = (size_t)blk0 * M;
   const __amdgpu_buffer_rsrc_t r_u = make_rsrc(p.u + oM, p.u ? RM * 2 : 0);
   const __amdgpu_buffer_rsrc_t r_g = make_rsrc(p.g + oM, p.g ? RM * 2 : 0);
@@ -208,7 +211,9 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   char* sH = smem + MLP_OFF_H;
   u32x4 hf[2][6];
   if constexpr (!BWD) {
-    const float bA = tid < M ? p.b1[tid] : 0.f, bB = tid + 512 < M ? p.b1[tid + 512] : 0.f;
+    float bvals[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bvals[k] = tid + NT * k < M ? p.b1[tid + NT * k] : 0.f;
     const __amdgpu_buffer_rsrc_t r_x = make_rsrc(p.x + oD, RD * 4);
     const __amdgpu_buffer_rsrc_t r_h = make_rsrc(p.h + oD, p.h ? RD * 2 : 0);
     const int j = lane & 15, sub = lane >> 4;
@@ -224,8 +229,9 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
         v[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
             r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
     store_tables();
-    reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid] = bA;
-    reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid + 512] = bB;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (tid + NT * k < MLP_MAX_M) reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid + NT * k] = bvals[k];
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int r = wave * 16 + pass * 4 + sub, row = blk0 + r;
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
         bf16x4 ob;
 #pragma unroll
         for (int e = 0; e < 4; ++e) ob[e] = (bf16)o[e];
-        *reinterpret_cast<bf16x4*>(sH + (byte >> 7) * (128 * 128) + lds_off(r, byte & 127)) = ob;
+        *reinterpret_cast<bf16x4*>(sH + (byte >> 7) * (BLK * 128) + lds_off(r, byte & 127)) = ob;
         if (p.h) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), r_h, (r * D + 4 * c4) * 2, 0, 0);
       }
       if (ok && j == 0 && p.mean) { p.mean[row] = mu; p.rstd[row] = rs; }
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int k = 0; k < 6; ++k)
-        hf[t][k] = *reinterpret_cast<const u32x4*>(sH + (k >> 1) * (128 * 128) +
+        hf[t][k] = *reinterpret_cast<const u32x4*>(sH + (k >> 1) * (BLK * 128) +
                                                    lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
   } else {
     const __amdgpu_buffer_rsrc_t r_dyc = make_rsrc(p.dyc + oD, RD * 2);
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
   // would fight for the MFMA pipe in the product phases and for VALU issue in the elementwise phase without
   // ever overlapping the two.  A static priority lets one wave of each pair win the matrix pipe: it reaches
   // its elementwise phase while the other is still in its MFMAs, and the phases interleave from there.
-  if (VAR != 5 && wave < 4) __builtin_amdgcn_s_setprio(2);
+  if (VAR != 5 && wave < TG) __builtin_amdgcn_s_setprio(2);
   // global stores each wave issues per chunk after the next chunk's DMA
   // backward adds the 2 u loads issued at the end of the elementwise phase
   const int nstores = BWD ? (p.g ? 6 : 4) : (p.u ? 2 : 0) + (p.g ? 2 : 0);
@@ -424,7 +430,10 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
       // u(c) was requested at the end of the previous elementwise phase; only this iteration's 6 DMA pieces are
       // younger (chunk 0's were drained by the vmcnt(0) at the top of the first iteration)
       if (c > 0) {
-        if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (c + 1 < nchunks) {                                  // younger: this iteration's PPW DMA pieces
+          if constexpr (TG == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       // The registers become "defined" for the compiler only HERE, in one unconditional statement behind the
@@ -526,10 +535,10 @@ __global__ __launch_bounds__(512) void mlp_kernel(MlpParams p) {
 
   if constexpr (!BWD) {
     // out = v + b2 + x, in row layout (fused_epilogue.h)
-    residual_rows_epilogue(smem, v, tid, blk0, p.R, p.x, p.b2, p.out);
+    residual_rows_epilogue<TG>(smem, v, tid, blk0, p.R, p.x, p.b2, p.out);
   } else {
     // LayerNorm backward on dh = v, in row layout (fused_epilogue.h)
-    ln_bwd_rows_epilogue(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dy, p.out, p.outc,
+    ln_bwd_rows_epilogue<TG>(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dy, p.out, p.outc,
                          p.partials + (size_t)blockIdx.x * 2 * D);
   }
   if constexpr (VAR == 6) {
@@ -567,17 +576,17 @@ extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b
   p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd;
   p.u = reinterpret_cast<bf16*>(u); p.g = reinterpret_cast<bf16*>(g); p.out = out;
   p.R = (int)rows; p.M = M;
-  static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;
-  const dim3 grid(cdiv((int)rows, 128));
+  static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;   // diagnostic variants (128-row form)
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(cdiv((int)rows, 128));
   if (var == 1) hipLaunchKernelGGL((mlp_kernel<false, 1>), grid, dim3(512), 0, hs, p);
   else if (var == 2) hipLaunchKernelGGL((mlp_kernel<false, 2>), grid, dim3(512), 0, hs, p);
   else if (var == 3) hipLaunchKernelGGL((mlp_kernel<false, 3>), grid, dim3(512), 0, hs, p);
   else if (var == 4) hipLaunchKernelGGL((mlp_kernel<false, 4>), grid, dim3(512), 0, hs, p);
   else if (var == 5) hipLaunchKernelGGL((mlp_kernel<false, 5>), grid, dim3(512), 0, hs, p);
   else if (var == 6) hipLaunchKernelGGL((mlp_kernel<false, 6>), grid, dim3(512), 0, hs, p);
-  else
-  hipLaunchKernelGGL((mlp_kernel<false, 0>), dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<false, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  else hipLaunchKernelGGL((mlp_kernel<false, 0, 4>), grid, dim3(512), 0, hs, p);
   return check_launch("mlp_fwd");
 }
 
@@ -586,7 +595,9 @@ extern "C" int sitk_mlp_debug_stamps(unsigned long long* out64) {
   return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
 }
 
-extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) { return rows > 0 ? (size_t)cdiv64(rows, 128) * 2 * MLP_D : 0; }
+extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) {
+  return rows > 0 ? (size_t)cdiv64(rows, fused_block_rows(rows)) * 2 * MLP_D : 0;
+}
 
 extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
                             const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,
@@ -603,8 +614,9 @@ extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, c
   p.out = dx; p.outc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.M = M;
   static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;
-  if (var == 6) hipLaunchKernelGGL((mlp_kernel<true, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
-  else
-  hipLaunchKernelGGL((mlp_kernel<true, 0>), dim3(cdiv((int)rows, 128)), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), p);
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  if (var == 6) hipLaunchKernelGGL((mlp_kernel<true, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
+  else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<true, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  else hipLaunchKernelGGL((mlp_kernel<true, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_bwd");
 }
