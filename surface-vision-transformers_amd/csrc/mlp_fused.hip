@@ -323,7 +323,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   // would fight for the MFMA pipe in the product phases and for VALU issue in the elementwise phase without
   // ever overlapping the two.  A static priority lets one wave of each pair win the matrix pipe: it reaches
   // its elementwise phase while the other is still in its MFMAs, and the phases interleave from there.
-  if (VAR != 5 && wave < TG) __builtin_amdgcn_s_setprio(2);
+  if (wave < TG) __builtin_amdgcn_s_setprio(2);
   // global stores each wave issues per chunk after the next chunk's DMA
   // backward adds the 2 u loads issued at the end of the elementwise phase
   const int nstores = BWD ? (p.g ? 6 : 4) : (p.u ? 2 : 0) + (p.g ? 2 : 0);
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     tprev = tn;                                                                          \
   }
   if constexpr (VAR == 6) { tprev = __builtin_amdgcn_s_memtime(); st[5] = tprev - t_kernel0; }
-  for (int c = 0; c < (VAR == 4 ? 0 : nchunks); ++c) {
+  for (int c = 0; c < nchunks; ++c) {
     const int buf = c & 1;
     SITK_STAMP(7)
     // chunk c's DMA (and, backward, its u loads) were issued before the previous iteration's stores
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     else if (nstores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     SITK_STAMP(0)
-    if (VAR != 3 || c == 0) __builtin_amdgcn_s_barrier();      // everybody's pieces landed; buffer buf^1 is free
+    __builtin_amdgcn_s_barrier();                                   // everybody's pieces landed; buffer buf^1 is free
     SITK_STAMP(1)
     const uint32_t bo = buf * (W1B + W2B);
     const uint32_t a0 = aw1[0] + bo, a1 = aw1[1] + bo, a2 = aw2 + bo;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     // {tile 0, tile 1} x {k-step 2 kt, 2 kt + 1}; second product, group j: feature tiles 4 j .. 4 j + 3.
     u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
     SITK_MLP_ISSUE4(x0, x1, x2, x3, a0, a1, 0, 2048, 0, 2048);
-    if (VAR != 3 && c + 1 < nchunks) issue(c + 1, buf ^ 1);
+    if (c + 1 < nchunks) issue(c + 1, buf ^ 1);
 
     // ---- first product: uacc[i][t], hidden tile i (slot rows 32 hh + 16 i ..), token tile t; forward
     //      starts the accumulators at the bias ----
@@ -417,14 +417,12 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const f32x2 en = __builtin_bit_cast(f32x2, te[e]);
-          gv[e] = xs[e] * (VAR == 1 ? 0.5f : fmaf(fw[e], en[1], en[0]));
+          gv[e] = xs[e] * fmaf(fw[e], en[1], en[0]);
         }
         pf[t] = u32x4{pack_bf16(gv[0], gv[1]), pack_bf16(gv[2], gv[3]), pack_bf16(gv[4], gv[5]), pack_bf16(gv[6], gv[7])};
-        if (VAR != 2) {
-          sd[t] = u32x4{pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
-          if (p.u) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_u, vo[t], so, 0);
-          if (p.g) __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_g, vo[t], so, 0);
-        }
+        sd[t] = u32x4{pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+        if (p.u) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_u, vo[t], so, 0);
+        if (p.g) __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_g, vo[t], so, 0);
       }
     } else {
       // u(c) was requested at the end of the previous elementwise phase; only this iteration's 6 DMA pieces are
@@ -497,7 +495,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     // issues when stores queue back to back (observed on gfx950: a VALU result written three instructions
     // after the second store of a pair reached memory).  Holding the stored vectors live across the first
     // MFMA group keeps the allocator from recycling their registers while the stores may still be reading.
-    if (VAR != 2) asm volatile("" : : "v"(sd[0]), "v"(sd[1]), "v"(pf[0]), "v"(pf[1]));
+    asm volatile("" : : "v"(sd[0]), "v"(sd[1]), "v"(pf[0]), "v"(pf[1]));
     SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a2, a2, 16384, 18432, 20480, 22528);
     SITK_MLP_FC2_MMAS(1, x0, x1, x2, x3)
     SITK_MLP_WAIT4(y0, y1, y2, y3);
@@ -576,17 +574,11 @@ extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b
   p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd;
   p.u = reinterpret_cast<bf16*>(u); p.g = reinterpret_cast<bf16*>(g); p.out = out;
   p.R = (int)rows; p.M = M;
-  static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;   // diagnostic variants (128-row form)
+  static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;   // 6: stamped build (tools/mlp_stamps.py)
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid(cdiv((int)rows, 128));
-  if (var == 1) hipLaunchKernelGGL((mlp_kernel<false, 1>), grid, dim3(512), 0, hs, p);
-  else if (var == 2) hipLaunchKernelGGL((mlp_kernel<false, 2>), grid, dim3(512), 0, hs, p);
-  else if (var == 3) hipLaunchKernelGGL((mlp_kernel<false, 3>), grid, dim3(512), 0, hs, p);
-  else if (var == 4) hipLaunchKernelGGL((mlp_kernel<false, 4>), grid, dim3(512), 0, hs, p);
-  else if (var == 5) hipLaunchKernelGGL((mlp_kernel<false, 5>), grid, dim3(512), 0, hs, p);
-  else if (var == 6) hipLaunchKernelGGL((mlp_kernel<false, 6>), grid, dim3(512), 0, hs, p);
+  if (var == 6) hipLaunchKernelGGL((mlp_kernel<false, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<false, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
-  else hipLaunchKernelGGL((mlp_kernel<false, 0, 4>), grid, dim3(512), 0, hs, p);
+  else hipLaunchKernelGGL((mlp_kernel<false, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_fwd");
 }
 
