@@ -36,7 +36,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 3
+#define SITK_ABI_VERSION 4
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -179,6 +179,15 @@ int sitk_mlp_fused_supported(int D, int M, int dtype);
 int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b, const void* w1_c, const float* b1,
                  const void* w2_c, const float* b2, void* h, float* mean, float* rstd, void* u, void* g,
                  float* out, int64_t rows, int D, int M, int dtype, sitk_stream_t stream);
+/* forward with the attention output projection folded in (state-dict keys layers.i.0.fn.to_out.0 + the first
+ * residual add of the block): x_mid = x + o Wo^T + bo is computed in the kernel's prologue, written to `xmid`
+ * (saved for backward) and fed to the LayerNorm; out = x_mid + MLP(LN(x_mid)).  Needs heads * 64 == 192 and at
+ * most 24 576 rows (sitk_attn_out_mlp_fused_supported); o_c (rows, 192) and wo_c (192, 192) are `dtype`.       */
+int sitk_attn_out_mlp_fused_supported(int64_t rows, int D, int I, int M, int dtype);
+int sitk_attn_out_mlp_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
+                          const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
+                          const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
+                          int64_t rows, int D, int I, int M, int dtype, sitk_stream_t stream);
 size_t sitk_mlp_bwd_partial_floats(int64_t rows);
 int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
                  const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,

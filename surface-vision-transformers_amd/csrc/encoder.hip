@@ -247,6 +247,12 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
       SITK_TRY(sitk_gemm_nt(&g1, dt, stream));
     }
     SITK_TRY(sitk_attention_fwd(a.qkv, a.o, a.lse, c.B, c.N, c.heads, scale, dt, stream));
+    if (mlp_fused(c) && sitk_attn_out_mlp_fused_supported(R, D, I, M, dt)) {   // to_out + residual + norm + MLP + residual
+      SITK_TRY(sitk_attn_out_mlp_fwd(a.o, wo, P[l].bo, x, a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2, a.mean2,
+                                     a.rstd2, a.u, save ? a.g : nullptr, xnext, R, D, I, M, dt, stream));
+      x = xnext;
+      continue;
+    }
     sitk_gemm_desc g2 = gemm_desc(R, D, I, a.o, I, 0, wo, SITK_EPI_BIAS_RES, a.xmid, D, 1);
     g2.bias = P[l].bo; g2.aux = x; g2.ldaux = D;
     SITK_TRY(sitk_gemm_nt(&g2, dt, stream));

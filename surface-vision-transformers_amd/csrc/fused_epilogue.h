@@ -181,4 +181,79 @@ SITK_DEV void residual_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid
   }
 }
 
+// Prologue of the fused attention-output + MLP forward: v = o Wo^T sits in accumulator layout (same layout as
+// above).  Rows take the trip through LDS, then per row: x_mid = v + bias + x (stored whole), LayerNorm
+// statistics, h = LN(x_mid) into the operand strip `strip` ([k-panel][32 TG rows][128 B], swizzled with lds_off)
+// and, when asked for, to global memory.  Ends with a workgroup barrier (the strip is complete).
+template <int TG>
+SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4 (&v)[6][2], int tid, int blk0, int R,
+                                    const float* __restrict__ x, const float* __restrict__ bias,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    float* __restrict__ xmid, bf16* __restrict__ h, float* __restrict__ mean,
+                                    float* __restrict__ rstd) {
+  constexpr int D = FE_D, BLK = 32 * TG;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4, tg = wave >> 1, hh = wave & 1;
+  const int j = lane & 15, sub = lane >> 4;
+  float* rowbuf = reinterpret_cast<float*>(rowbuf_bytes);
+  const size_t nrows = (size_t)(R - blk0 < BLK ? R - blk0 : BLK);
+  const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)blk0 * D, 0,
+                                                                       (int)(nrows * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_m = __builtin_amdgcn_make_buffer_rsrc(xmid + (size_t)blk0 * D, 0, (int)(nrows * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc(h ? h + (size_t)blk0 * D : (bf16*)xmid, 0,
+                                                                       h ? (int)(nrows * D * 2) : 0, 0x00020000);
+  f32x4 xv[4][3], bb[3], gm[3], bt[3];
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      xv[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    bb[i] = load4(bias + 4 * (j + 16 * i));
+    gm[i] = load4(gamma + 4 * (j + 16 * i));
+    bt[i] = load4(beta + 4 * (j + 16 * i));
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      *reinterpret_cast<f32x4*>(rowbuf + (32 * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int r = wave * 16 + pass * 4 + sub, row = blk0 + r;
+    const bool ok = row < R;
+    f32x4 xm[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int col = 4 * (j + 16 * i);
+      xm[i] = *reinterpret_cast<const f32x4*>(rowbuf + r * FE_PITCH + col) + bb[i] + xv[pass][i];
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xm[i]), r_m, (r * D + col) * 4, 0, 0);
+      s += xm[i][0] + xm[i][1] + xm[i][2] + xm[i][3];
+    }
+    const float mu = row16_sum(s) * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = xm[i][e] - mu; ss += d * d; }
+    const float rs = rsqrtf(row16_sum(ss) * (1.0f / D) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c4 = j + 16 * i;
+      bf16x4 ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ob[e] = (bf16)(ok ? (xm[i][e] - mu) * rs * gm[i][e] + bt[i][e] : 0.f);
+      const int byte = c4 * 8;
+      *reinterpret_cast<bf16x4*>(strip + (byte >> 7) * (BLK * 128) + lds_off(r, byte & 127)) = ob;
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), r_h, (r * D + 4 * c4) * 2, 0, 0);   // dropped when h == NULL
+    }
+    if (ok && j == 0 && mean) { mean[row] = mu; rstd[row] = rs; }
+  }
+  __syncthreads();
+}
+
 }  // namespace sitk

@@ -54,6 +54,11 @@ struct MlpParams {
   bf16* du;            // (R,M)
   bf16* outc;          // (R,192) compute-dtype copy of dx
   float* partials;     // (gridDim.x, 2, 192) dgamma / dbeta partial sums
+  // forward with the attention output projection folded in (PROJ): x_mid = x + o Wo^T + bo is computed here
+  const bf16* o;       // (R,192) attention output, 'b n (h d)'
+  const bf16* wo;      // (192,192) to_out weight
+  const float* bo;     // (192)
+  float* xmid;         // (R,192) fp32, written (saved for backward); the LayerNorm input and the residual of `out`
   int R, M;
 };
 
@@ -120,9 +125,11 @@ constexpr int MLP_SMEM = MLP_OFF_B1 + 12288;
 
 // TG = token groups (of 32 rows = 2 waves) per workgroup: 4 (128 rows, 8 waves) or 3 (96 rows, 6 waves);
 // see fused_block_rows() in fused_epilogue.h.
-template <bool BWD, int VAR = 0, int TG = 4>
+template <bool BWD, int VAR = 0, int TG = 4, bool PROJ = false>
 __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   constexpr int D = MLP_D, BLK = 32 * TG, NT = 128 * TG, PPW = 24 / TG;   // rows, threads, DMA pieces per wave and chunk
+  static_assert(!PROJ || (!BWD && TG == 3), "the projection prologue needs Wo (72 KB) + a 96-row fp32 row buffer in LDS");
+  constexpr int PAR = PROJ ? 1 : 0;                                      // ring slot of chunk 0
   constexpr int W1B = MLP_W1B, W2B = MLP_W2B;
   __shared__ __attribute__((aligned(256))) char smem[MLP_SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
                                        (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
   };
-  issue(0, 0);
+  if constexpr (!PROJ) issue(0, 0);
 
   if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 0] = __builtin_amdgcn_s_memtime() - t_kernel0; }
   // ---- GELU tables (see above): entry i = {f(x_i), f(x_i+1) - f(x_i)}; visible to everybody after the
@@ -210,7 +217,58 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   //      per pass, all 12 loads in flight together); backward = the compute-dtype copy of dy ----
   char* sH = smem + MLP_OFF_H;
   u32x4 hf[2][6];
-  if constexpr (!BWD) {
+  if constexpr (PROJ) {
+    // ---- attention output projection + residual + LayerNorm (layers.i.0.fn.to_out.0, layers.i.1.norm) ----
+    // LDS: Wo [0, 72 KB) as [k-panel][192 rows][128 B]; fp32 row buffer [72 KB, 145.5 KB); afterwards the operand
+    // strip takes [0, 36 KB) and chunk 0 of the weight ring lands in slot 1 (48 KB ..), so the ring starts odd.
+    constexpr int NW = 2 * TG, WPW = 72 / NW;
+    float bvals[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) bvals[k] = tid + NT * k < M ? p.b1[tid + NT * k] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+      const int q = wave * WPW + i, kt = q / 24, row = (q % 24) * 8 + r8;
+      const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+      const bf16* src = p.wo + (size_t)row * D + kt * 64 + (((lane & 7) ^ (key << 1)) * 8);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem + kt * 24576 + (q % 24) * 1024), 16, 0, 0);
+    }
+    const __amdgpu_buffer_rsrc_t r_o = make_rsrc(p.o + oD, RD * 2);
+    u32x4 of[2][6];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        of[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_o, ((32 * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 pacc[6][2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { pacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int keyp = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(smem + (k >> 1) * 24576 + (96 * hh + 16 * i + fr) * 128 +
+                                                        (((k & 1) * 64 + fq * 16) ^ (keyp << 5)));
+        pacc[i][0] = Mma<bf16>::mma(a, of[0][k], pacc[i][0]);
+        pacc[i][1] = Mma<bf16>::mma(a, of[1][k], pacc[i][1]);
+      }
+    proj_residual_ln_rows<TG>(smem + 73728, smem, pacc, tid, blk0, p.R, p.x, p.bo, p.gamma, p.beta, p.xmid, p.h, p.mean, p.rstd);
+    issue(0, 1);                                               // the row buffer is dead: ring slot 1 takes chunk 0
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        hf[t][k] = *reinterpret_cast<const u32x4*>(smem + (k >> 1) * (BLK * 128) +
+                                                   lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
+    store_tables();
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (tid + NT * k < MLP_MAX_M) reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid + NT * k] = bvals[k];
+    __syncthreads();                                           // tables visible; every wave holds its fragments of the strip
+  } else if constexpr (!BWD) {
     float bvals[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) bvals[k] = tid + NT * k < M ? p.b1[tid + NT * k] : 0.f;
@@ -336,7 +394,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   }
   if constexpr (VAR == 6) { tprev = __builtin_amdgcn_s_memtime(); st[5] = tprev - t_kernel0; }
   for (int c = 0; c < nchunks; ++c) {
-    const int buf = c & 1;
+    const int buf = (c + PAR) & 1;
     SITK_STAMP(7)
     // chunk c's DMA (and, backward, its u loads) were issued before the previous iteration's stores
     // (pinned there by the "memory" clobbers of the fragment-read blocks), so only those stores may stay in flight
@@ -533,7 +591,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 
   if constexpr (!BWD) {
     // out = v + b2 + x, in row layout (fused_epilogue.h)
-    residual_rows_epilogue<TG>(smem, v, tid, blk0, p.R, p.x, p.b2, p.out);
+    residual_rows_epilogue<TG>(smem, v, tid, blk0, p.R, PROJ ? p.xmid : p.x, p.b2, p.out);
   } else {
     // LayerNorm backward on dh = v, in row layout (fused_epilogue.h)
     ln_bwd_rows_epilogue<TG>(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dy, p.out, p.outc,
@@ -580,6 +638,30 @@ extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<false, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL((mlp_kernel<false, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_fwd");
+}
+
+extern "C" int sitk_attn_out_mlp_fused_supported(int64_t rows, int D, int I, int M, int dtype) {
+  return sitk_mlp_fused_supported(D, M, dtype) && I == MLP_D && rows > 0 && fused_block_rows(rows) == 96;
+}
+
+extern "C" int sitk_attn_out_mlp_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
+                                     const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
+                                     const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
+                                     int64_t rows, int D, int I, int M, int dtype, sitk_stream_t stream) {
+  SITK_REQUIRE(o_c && wo_c && bo && x && xmid && ln_w && ln_b && w1_c && b1 && w2_c && b2 && out, "attn_out_mlp_fwd: null pointer");
+  SITK_REQUIRE((mean == nullptr) == (rstd == nullptr), "attn_out_mlp_fwd: mean and rstd go together");
+  SITK_TRY(mlp_check("attn_out_mlp_fwd", rows, D, M, dtype));
+  SITK_REQUIRE(sitk_attn_out_mlp_fused_supported(rows, D, I, M, dtype),
+               "attn_out_mlp_fwd: needs heads * 64 == 192 and at most 24576 rows (got I %d rows %lld)", I, (long long)rows);
+  MlpParams p = {};
+  p.o = reinterpret_cast<const bf16*>(o_c); p.wo = reinterpret_cast<const bf16*>(wo_c); p.bo = bo; p.xmid = xmid;
+  p.x = x; p.gamma = ln_w; p.beta = ln_b;
+  p.wa = reinterpret_cast<const bf16*>(w1_c); p.b1 = b1; p.wb = reinterpret_cast<const bf16*>(w2_c); p.b2 = b2;
+  p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd;
+  p.u = reinterpret_cast<bf16*>(u); p.g = reinterpret_cast<bf16*>(g); p.out = out;
+  p.R = (int)rows; p.M = M;
+  hipLaunchKernelGGL((mlp_kernel<false, 0, 3, true>), dim3(cdiv((int)rows, 96)), dim3(384), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("attn_out_mlp_fwd");
 }
 
 // diagnostic: per-phase cycle sums of workgroup 0 written by the SITK_MLP_VAR=6 build (not part of the ABI header)

@@ -199,6 +199,31 @@ def mlp_fwd(x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
     return out, h, mean, rstd, u, g
 
 
+def attn_out_mlp_fused_supported(rows, D, I, M, dtype):
+    return bool(rt.lib.sitk_attn_out_mlp_fused_supported(rows, D, I, M, rt.dtype_code(dtype)))
+
+
+def attn_out_mlp_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
+    """x_mid = x + o Wo^T + bo; out = x_mid + gelu(LN(x_mid) W1^T + b1) W2^T + b2.
+    Returns (out, xmid, h, mean, rstd, u, g)."""
+    rt.require_cuda(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2)
+    rows, D = x.shape
+    M, I = w1_c.shape[0], o_c.shape[1]
+    code = rt.dtype_code(dtype)
+    td = rt.torch_dtype(code)
+    out, xmid = torch.empty_like(x), torch.empty_like(x)
+    h = torch.empty((rows, D), dtype=td, device=x.device) if save else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
+    u = torch.empty((rows, M), dtype=td, device=x.device) if save else None
+    g = torch.empty((rows, M), dtype=td, device=x.device) if want_g else None
+    rt.check(rt.lib.sitk_attn_out_mlp_fwd(o_c.data_ptr(), wo_c.data_ptr(), bo.data_ptr(), x.data_ptr(), xmid.data_ptr(),
+                                          ln_w.data_ptr(), ln_b.data_ptr(), w1_c.data_ptr(), b1.data_ptr(), w2_c.data_ptr(),
+                                          b2.data_ptr(), rt.ptr(h), rt.ptr(mean), rt.ptr(rstd), rt.ptr(u), rt.ptr(g),
+                                          out.data_ptr(), rows, D, I, M, code, rt.stream_ptr()))
+    return out, xmid, h, mean, rstd, u, g
+
+
 def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, dtype, want_g=True):
     """returns (dx, dx_c, du, g, partials (workgroups, 2, D)); g = gelu(u) is recomputed and returned when want_g
     (callers that saved g in forward pass want_g=False: g is None)"""

@@ -80,9 +80,17 @@ def layer_kernels(eng):
         rows.append(("layernorm_fwd", "layernorm_fwd_kernel", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), L))
         rows.append(("to_qkv", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(h, wqkv, out_qkv, dt), 2.0 * R * 3 * I * D, R * (D + 3 * I) * es, L))
     rows.append(("attention forward", "attn_fwd_res_kernel", lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt), att, R * 4 * I * es, L))
-    rows.append(("to_out + residual", "gemm_nt_wres_kernel",
-                 lambda: ops.gemm_nt(o, wo, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * I, R * (I * es + 8 * D), L))
-    if fused_mlp:
+    fused_proj = fused_mlp and ops.attn_out_mlp_fused_supported(R, D, I, M, dt)
+    if fused_proj:
+        rows.append(("to_out + residual + norm + net.0 + GELU + net.3 + residual (fused)", "mlp_kernel<false>",
+                     lambda: ops.attn_out_mlp_fwd(o, wo, bD, x32, gam, bD, w1, bM, w2, bD, dt, want_g=True),
+                     mlp_flops + 2.0 * R * D * I, R * (I * es + 12 * D + (D + 2 * M) * es), L))
+    else:
+        rows.append(("to_out + residual", "gemm_nt_wres_kernel",
+                     lambda: ops.gemm_nt(o, wo, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * I, R * (I * es + 8 * D), L))
+    if fused_proj:
+        pass
+    elif fused_mlp:
         rows.append(("norm + net.0 + GELU + net.3 + residual (fused)", "mlp_kernel<false>",
                      lambda: ops.mlp_fwd(x32, gam, bD, w1, bM, w2, bD, dt, want_g=True), mlp_flops,
                      R * (8 * D + (D + 2 * M) * es), L))

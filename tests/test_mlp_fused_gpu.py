@@ -185,3 +185,39 @@ def test_mlp_fused_repeatable_and_in_bounds(ops):
     for t, r in ((out_b, ref[0]), (h_b, ref[1]), (u_b, ref[2]), (g_b, ref[3])):
         assert torch.equal(t[:rows], r)
         assert bool((t[rows:].float() == 7.0).all())
+
+
+@pytest.mark.parametrize("rows", [96, 321 * 3, 1000, 20544])
+def test_attn_out_mlp_fwd(ops, rows):
+    """to_out + residual folded into the fused forward: x_mid = x + o Wo^T + bo, out = x_mid + MLP(LN(x_mid)).
+    Checked against float64 torch math on bf16-rounded operands, and the MLP part against the stand-alone fused
+    kernel run on the kernel's own x_mid (identical bits: same code path after the prologue)."""
+    M = 768
+    assert ops.attn_out_mlp_fused_supported(rows, D, 192, M, "bf16")
+    assert not ops.attn_out_mlp_fused_supported(30000, D, 192, M, "bf16")      # 128-row workgroups: separate kernels
+    assert not ops.attn_out_mlp_fused_supported(rows, D, 384, M, "bf16")
+    x = rnd("aom/x", (rows, D), 1.5)
+    o = rnd("aom/o", (rows, D), 1.0).bfloat16()
+    wo, bo = rnd("aom/wo", (D, D), D ** -0.5), rnd("aom/bo", (D,), 0.1)
+    ln_w, ln_b, w1, b1, w2, b2 = params("aom", M)
+    out, xmid, h, mean, rstd, u, g = ops.attn_out_mlp_fwd(o, wo.bfloat16(), bo, x, ln_w, ln_b, w1.bfloat16(), b1,
+                                                          w2.bfloat16(), b2, "bf16", want_g=True)
+    torch.cuda.synchronize()
+    xm_r = x.double() + o.double() @ r16(wo).T + bo.double()
+    assert rel(xmid, xm_r) < 2e-6                              # fp32 accumulation of bf16 x bf16 products
+    assert rel(xmid - x, xm_r - x.double()) < 2e-5
+    ref = ops.mlp_fwd(xmid, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16", want_g=True)
+    for a, b in zip((out, h, mean, rstd, u, g), ref):
+        assert torch.equal(a, b)
+    # sentinel rows behind x_mid
+    from sitk import runtime as rt
+    pad = 128
+    xm_b = torch.full((rows + pad, D), 7.0, device=DEV)
+    out_b = torch.empty((rows, D), device=DEV)
+    woc, w1c, w2c = wo.bfloat16(), w1.bfloat16(), w2.bfloat16()          # keep the operands alive across the raw call
+    rt.check(rt.lib.sitk_attn_out_mlp_fwd(o.data_ptr(), woc.data_ptr(), bo.data_ptr(), x.data_ptr(), xm_b.data_ptr(),
+                                          ln_w.data_ptr(), ln_b.data_ptr(), w1c.data_ptr(), b1.data_ptr(),
+                                          w2c.data_ptr(), b2.data_ptr(), 0, 0, 0, 0, 0, out_b.data_ptr(), rows, D, 192,
+                                          M, rt.BF16, rt.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(xm_b[:rows], xmid) and bool((xm_b[rows:] == 7.0).all()) and torch.equal(out_b, out)
