@@ -36,7 +36,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 4
+#define SITK_ABI_VERSION 5
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -188,6 +188,15 @@ int sitk_attn_out_mlp_fwd(const void* o_c, const void* wo_c, const float* bo, co
                           const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
                           const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
                           int64_t rows, int D, int I, int M, int dtype, sitk_stream_t stream);
+/* ... and with the NEXT block's LayerNorm + to_qkv appended (layers.{i+1}.0.norm, layers.{i+1}.0.fn.to_qkv):
+ * n_h = LN(out) (may be NULL), n_mean/n_rstd, n_qkv = n_h Wqkv^T (rows, N3) -- one launch from the attention
+ * output of block i to the attention input of block i + 1.                                                    */
+int sitk_attn_out_mlp_next_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
+                               const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
+                               const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
+                               const float* n_ln_w, const float* n_ln_b, const void* n_wqkv_c, void* n_h, float* n_mean,
+                               float* n_rstd, void* n_qkv, int N3, int64_t rows, int D, int I, int M, int dtype,
+                               sitk_stream_t stream);
 size_t sitk_mlp_bwd_partial_floats(int64_t rows);
 int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
                  const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,

@@ -230,6 +230,7 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   SITK_TRY(stage_all(c, P, L, s));
 
   const float* x = x_in;
+  bool have_qkv = false;   // the previous block's fused kernel already produced this block's h1 / statistics / qkv
   for (int l = 0; l < c.depth; ++l) {
     const LayerActs& a = L.layers[save ? l : 0];
     const LayerActs& w = L.layers[l];
@@ -239,17 +240,29 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     const void* w2 = f32 ? (const void*)P[l].w2 : w.w2_c;
     float* xnext = (l == c.depth - 1) ? x_out : (save ? L.layers[l + 1].x_in : ((l & 1) ? L.scratch.pong : L.scratch.ping));
 
-    if (qkv_fused(c)) {
+    if (have_qkv) {
+      // this block's LayerNorm + to_qkv were appended to the previous block's fused kernel
+    } else if (qkv_fused(c)) {
       SITK_TRY(sitk_ln_gemm_fwd(x, P[l].ln1_w, P[l].ln1_b, wqkv, a.h1, a.mean1, a.rstd1, a.qkv, R, D, 3 * I, dt, stream));
     } else {
       SITK_TRY(sitk_layernorm_fwd(x, P[l].ln1_w, P[l].ln1_b, a.h1, a.mean1, a.rstd1, R, D, dt, stream));
       sitk_gemm_desc g1 = gemm_desc(R, 3 * I, D, a.h1, D, 0, wqkv, SITK_EPI_STORE, a.qkv, 3 * I, 0);
       SITK_TRY(sitk_gemm_nt(&g1, dt, stream));
     }
+    have_qkv = false;
     SITK_TRY(sitk_attention_fwd(a.qkv, a.o, a.lse, c.B, c.N, c.heads, scale, dt, stream));
     if (mlp_fused(c) && sitk_attn_out_mlp_fused_supported(R, D, I, M, dt)) {   // to_out + residual + norm + MLP + residual
-      SITK_TRY(sitk_attn_out_mlp_fwd(a.o, wo, P[l].bo, x, a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2, a.mean2,
-                                     a.rstd2, a.u, save ? a.g : nullptr, xnext, R, D, I, M, dt, stream));
+      if (l + 1 < c.depth && qkv_fused(c)) {                                    // ... + the next block's norm + to_qkv
+        const LayerActs& an = L.layers[save ? l + 1 : 0];
+        const void* wqkv_n = L.layers[l + 1].wqkv_c;
+        SITK_TRY(sitk_attn_out_mlp_next_fwd(a.o, wo, P[l].bo, x, a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2,
+                                            a.mean2, a.rstd2, a.u, save ? a.g : nullptr, xnext, P[l + 1].ln1_w, P[l + 1].ln1_b,
+                                            wqkv_n, an.h1, an.mean1, an.rstd1, an.qkv, 3 * I, R, D, I, M, dt, stream));
+        have_qkv = true;
+      } else {
+        SITK_TRY(sitk_attn_out_mlp_fwd(a.o, wo, P[l].bo, x, a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2,
+                                       a.mean2, a.rstd2, a.u, save ? a.g : nullptr, xnext, R, D, I, M, dt, stream));
+      }
       x = xnext;
       continue;
     }

@@ -59,6 +59,15 @@ struct MlpParams {
   const bf16* wo;      // (192,192) to_out weight
   const float* bo;     // (192)
   float* xmid;         // (R,192) fp32, written (saved for backward); the LayerNorm input and the residual of `out`
+  // forward with the NEXT block's LayerNorm + to_qkv appended (NEXT): h1 = LN(out), qkv = h1 Wqkv^T
+  const float* n_gamma;  // next block's layers.{i+1}.0.norm weight / bias
+  const float* n_beta;
+  const bf16* n_w;       // (N3,192) next block's to_qkv weight
+  bf16* n_h;             // (R,192) saved LN output of the next block (or null)
+  float* n_mean;         // (R)
+  float* n_rstd;
+  bf16* n_y;             // (R,N3) qkv of the next block
+  int N3;
   int R, M;
 };
 
@@ -125,8 +134,9 @@ constexpr int MLP_SMEM = MLP_OFF_B1 + 12288;
 
 // TG = token groups (of 32 rows = 2 waves) per workgroup: 4 (128 rows, 8 waves) or 3 (96 rows, 6 waves);
 // see fused_block_rows() in fused_epilogue.h.
-template <bool BWD, int VAR = 0, int TG = 4, bool PROJ = false>
+template <bool BWD, int VAR = 0, int TG = 4, bool PROJ = false, bool NEXT = false>
 __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
+  static_assert(!NEXT || PROJ, "the appended LayerNorm + to_qkv shares the 96-row LDS plan of the projection prologue");
   constexpr int D = MLP_D, BLK = 32 * TG, NT = 128 * TG, PPW = 24 / TG;   // rows, threads, DMA pieces per wave and chunk
   static_assert(!PROJ || (!BWD && TG == 3), "the projection prologue needs Wo (72 KB) + a 96-row fp32 row buffer in LDS");
   constexpr int PAR = PROJ ? 1 : 0;                                      // ring slot of chunk 0
@@ -590,8 +600,96 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   const int n0 = 96 * hh + 4 * fq;                             // + 16 i : this lane's 4 features of tile i
 
   if constexpr (!BWD) {
-    // out = v + b2 + x, in row layout (fused_epilogue.h)
-    residual_rows_epilogue<TG>(smem, v, tid, blk0, p.R, PROJ ? p.xmid : p.x, p.b2, p.out);
+    if constexpr (!NEXT) {
+      // out = v + b2 + x, in row layout (fused_epilogue.h)
+      residual_rows_epilogue<TG>(smem, v, tid, blk0, p.R, PROJ ? p.xmid : p.x, p.b2, p.out);
+    } else {
+      // ---- out = v + b2 + x_mid (stored), then the NEXT block's attention input: h1 = LN(out), qkv = h1 Wqkv^T.
+      //      The finished rows never leave the chip between the two blocks' kernels: rows -> fp32 row buffer
+      //      [72 KB ..) -> LayerNorm -> bf16 operand strip [0, 36 KB) -> 12 register fragments per wave; Wqkv
+      //      streams in 24-KB chunks through a 2-slot ring at [48 KB, 96 KB) exactly as in ln_gemm_fused.hip. ----
+      constexpr int NW = 2 * TG, QPW = 24 / NW;
+      proj_residual_ln_rows<TG>(smem + 73728, smem, v, tid, blk0, p.R, p.xmid, p.b2, p.n_gamma, p.n_beta, p.out, p.n_h,
+                                p.n_mean, p.n_rstd);
+      // Lane-derived addresses of this phase are rebuilt from an opaque copy of the lane id: derived from `lane`
+      // itself, hipcc computes them at kernel entry and carries them through the main loop, whose register budget
+      // (254 of 256) has no room for them.
+      int lane_q = lane;
+      asm volatile("" : "+v"(lane_q));
+      const int fr = lane_q & 15, fq = lane_q >> 4, r8 = lane_q >> 3;
+      const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
+      const int N3 = p.N3, nq = N3 / 64;
+      int qoff[QPW];
+#pragma unroll
+      for (int i = 0; i < QPW; ++i) {
+        const int qq = wave * QPW + i;
+        const int kt = qq >> 3, sr = (qq & 7) * 8 + r8;
+        const int r = sr & 15, it = (sr >> 4) & 1, hs = sr >> 5;
+        const int feat = 32 * hs + 8 * (r >> 2) + 4 * it + (r & 3);
+        const int key = ((sr >> 1) & 1) | (((sr >> 3) & 1) << 1);
+        qoff[i] = feat * D + kt * 64 + (((lane_q & 7) ^ (key << 1)) * 8);
+      }
+      auto qissue = [&](int c, int slot) {
+        char* base = smem + 49152 + slot * 24576 + wave * QPW * 1024;
+        const bf16* src = p.n_w + (size_t)c * 64 * D;
+#pragma unroll
+        for (int i = 0; i < QPW; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + qoff[i]),
+                                           (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+      };
+      qissue(0, 0);
+      u32x4 qf[2][6];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          qf[t][k] = *reinterpret_cast<const u32x4*>(smem + (k >> 1) * (BLK * 128) +
+                                                     lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
+      const __amdgpu_buffer_rsrc_t r_y = make_rsrc(p.n_y + (size_t)blk0 * N3, nrows * N3 * 2);
+      const int qvo[2] = {((32 * tg + fr) * N3 + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * N3 + 32 * hh + 8 * fq) * 2};
+      uint32_t qa[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) qa[ks] = lbase + 49152 + (32 * hh + fr) * 128 + ((ks * 64 + fq * 16) ^ (keyl << 5));
+      for (int c = 0; c < nq; ++c) {
+        if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // chunk c's DMA precedes the previous iteration's 2 stores
+        __builtin_amdgcn_s_barrier();
+        const uint32_t qbo = (c & 1) * 24576;
+        const uint32_t a0 = qa[0] + qbo, a1 = qa[1] + qbo;
+        u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
+        SITK_MLP_ISSUE4(x0, x1, x2, x3, a0, a1, 0, 2048, 0, 2048);
+        if (c + 1 < nq) qissue(c + 1, (c + 1) & 1);
+        f32x4 qacc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { qacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; qacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#define SITK_MLP_Q_MMAS(KT, f0, f1, f2, f3)                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                  \
+        qacc[0][0] = Mma<bf16>::mma(f0, qf[0][2 * KT], qacc[0][0]);                                         \
+        qacc[0][1] = Mma<bf16>::mma(f0, qf[1][2 * KT], qacc[0][1]);                                         \
+        qacc[1][0] = Mma<bf16>::mma(f1, qf[0][2 * KT], qacc[1][0]);                                         \
+        qacc[1][1] = Mma<bf16>::mma(f1, qf[1][2 * KT], qacc[1][1]);                                         \
+        qacc[0][0] = Mma<bf16>::mma(f2, qf[0][2 * KT + 1], qacc[0][0]);                                     \
+        qacc[0][1] = Mma<bf16>::mma(f2, qf[1][2 * KT + 1], qacc[0][1]);                                     \
+        qacc[1][0] = Mma<bf16>::mma(f3, qf[0][2 * KT + 1], qacc[1][0]);                                     \
+        qacc[1][1] = Mma<bf16>::mma(f3, qf[1][2 * KT + 1], qacc[1][1]);                                     \
+        __builtin_amdgcn_sched_barrier(0);
+        SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a0, a1, 8192, 10240, 8192, 10240);
+        SITK_MLP_Q_MMAS(0, x0, x1, x2, x3)
+        SITK_MLP_WAIT_ISSUE4(y0, y1, y2, y3, x0, x1, x2, x3, a0, a1, 16384, 18432, 16384, 18432);
+        SITK_MLP_Q_MMAS(1, y0, y1, y2, y3)
+        SITK_MLP_WAIT4(x0, x1, x2, x3);
+        SITK_MLP_Q_MMAS(2, x0, x1, x2, x3)
+#undef SITK_MLP_Q_MMAS
+        u32x4 qsd[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 v0 = qacc[0][t], v1 = qacc[1][t];
+          qsd[t] = u32x4{pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(qsd[t], r_y, qvo[t], c * 128, 0);
+        }
+        asm volatile("" : : "v"(qsd[0]), "v"(qsd[1]));         // store keep-alive (see the main loop)
+      }
+    }
   } else {
     // LayerNorm backward on dh = v, in row layout (fused_epilogue.h)
     ln_bwd_rows_epilogue<TG>(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dy, p.out, p.outc,
@@ -644,15 +742,17 @@ extern "C" int sitk_attn_out_mlp_fused_supported(int64_t rows, int D, int I, int
   return sitk_mlp_fused_supported(D, M, dtype) && I == MLP_D && rows > 0 && fused_block_rows(rows) == 96;
 }
 
-extern "C" int sitk_attn_out_mlp_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
-                                     const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
-                                     const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
-                                     int64_t rows, int D, int I, int M, int dtype, sitk_stream_t stream) {
-  SITK_REQUIRE(o_c && wo_c && bo && x && xmid && ln_w && ln_b && w1_c && b1 && w2_c && b2 && out, "attn_out_mlp_fwd: null pointer");
-  SITK_REQUIRE((mean == nullptr) == (rstd == nullptr), "attn_out_mlp_fwd: mean and rstd go together");
-  SITK_TRY(mlp_check("attn_out_mlp_fwd", rows, D, M, dtype));
+static int attn_out_mlp_launch(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
+                               const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
+                               const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
+                               const float* n_ln_w, const float* n_ln_b, const void* n_wqkv_c, void* n_h, float* n_mean,
+                               float* n_rstd, void* n_qkv, int N3, int64_t rows, int D, int I, int M, int dtype,
+                               sitk_stream_t stream, const char* what) {
+  SITK_REQUIRE(o_c && wo_c && bo && x && xmid && ln_w && ln_b && w1_c && b1 && w2_c && b2 && out, "%s: null pointer", what);
+  SITK_REQUIRE((mean == nullptr) == (rstd == nullptr), "%s: mean and rstd go together", what);
+  SITK_TRY(mlp_check(what, rows, D, M, dtype));
   SITK_REQUIRE(sitk_attn_out_mlp_fused_supported(rows, D, I, M, dtype),
-               "attn_out_mlp_fwd: needs heads * 64 == 192 and at most 24576 rows (got I %d rows %lld)", I, (long long)rows);
+               "%s: needs heads * 64 == 192 and at most 24576 rows (got I %d rows %lld)", what, I, (long long)rows);
   MlpParams p = {};
   p.o = reinterpret_cast<const bf16*>(o_c); p.wo = reinterpret_cast<const bf16*>(wo_c); p.bo = bo; p.xmid = xmid;
   p.x = x; p.gamma = ln_w; p.beta = ln_b;
@@ -660,8 +760,36 @@ extern "C" int sitk_attn_out_mlp_fwd(const void* o_c, const void* wo_c, const fl
   p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd;
   p.u = reinterpret_cast<bf16*>(u); p.g = reinterpret_cast<bf16*>(g); p.out = out;
   p.R = (int)rows; p.M = M;
-  hipLaunchKernelGGL((mlp_kernel<false, 0, 3, true>), dim3(cdiv((int)rows, 96)), dim3(384), 0, reinterpret_cast<hipStream_t>(stream), p);
-  return check_launch("attn_out_mlp_fwd");
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  if (n_qkv) {
+    SITK_REQUIRE(n_ln_w && n_ln_b && n_wqkv_c && N3 % 64 == 0 && N3 >= 64 && (n_mean == nullptr) == (n_rstd == nullptr),
+                 "%s: bad next-block arguments (N3 %d)", what, N3);
+    p.n_gamma = n_ln_w; p.n_beta = n_ln_b; p.n_w = reinterpret_cast<const bf16*>(n_wqkv_c);
+    p.n_h = reinterpret_cast<bf16*>(n_h); p.n_mean = n_mean; p.n_rstd = n_rstd; p.n_y = reinterpret_cast<bf16*>(n_qkv); p.N3 = N3;
+    hipLaunchKernelGGL((mlp_kernel<false, 0, 3, true, true>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  } else {
+    hipLaunchKernelGGL((mlp_kernel<false, 0, 3, true, false>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  }
+  return check_launch(what);
+}
+
+extern "C" int sitk_attn_out_mlp_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
+                                     const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
+                                     const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
+                                     int64_t rows, int D, int I, int M, int dtype, sitk_stream_t stream) {
+  return attn_out_mlp_launch(o_c, wo_c, bo, x, xmid, ln_w, ln_b, w1_c, b1, w2_c, b2, h, mean, rstd, u, g, out, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, nullptr, 0, rows, D, I, M, dtype, stream, "attn_out_mlp_fwd");
+}
+
+extern "C" int sitk_attn_out_mlp_next_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
+                                          const float* ln_w, const float* ln_b, const void* w1_c, const float* b1,
+                                          const void* w2_c, const float* b2, void* h, float* mean, float* rstd, void* u, void* g,
+                                          float* out, const float* n_ln_w, const float* n_ln_b, const void* n_wqkv_c, void* n_h,
+                                          float* n_mean, float* n_rstd, void* n_qkv, int N3, int64_t rows, int D, int I, int M,
+                                          int dtype, sitk_stream_t stream) {
+  SITK_REQUIRE(n_qkv != nullptr, "attn_out_mlp_next_fwd: null qkv output");
+  return attn_out_mlp_launch(o_c, wo_c, bo, x, xmid, ln_w, ln_b, w1_c, b1, w2_c, b2, h, mean, rstd, u, g, out, n_ln_w, n_ln_b,
+                             n_wqkv_c, n_h, n_mean, n_rstd, n_qkv, N3, rows, D, I, M, dtype, stream, "attn_out_mlp_next_fwd");
 }
 
 // diagnostic: per-phase cycle sums of workgroup 0 written by the SITK_MLP_VAR=6 build (not part of the ABI header)

@@ -224,6 +224,28 @@ def attn_out_mlp_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, sa
     return out, xmid, h, mean, rstd, u, g
 
 
+def attn_out_mlp_next_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, n_ln_w, n_ln_b, n_wqkv_c, dtype, want_g=False):
+    """attn_out_mlp_fwd + the next block's LayerNorm and to_qkv.  Returns (out, xmid, h, mean, rstd, u, g, n_h, n_mean,
+    n_rstd, n_qkv)."""
+    rows, D = x.shape
+    M, I, N3 = w1_c.shape[0], o_c.shape[1], n_wqkv_c.shape[0]
+    code = rt.dtype_code(dtype)
+    td = rt.torch_dtype(code)
+    dev = x.device
+    out, xmid = torch.empty_like(x), torch.empty_like(x)
+    h, n_h = torch.empty((rows, D), dtype=td, device=dev), torch.empty((rows, D), dtype=td, device=dev)
+    mean, rstd, n_mean, n_rstd = (torch.empty(rows, dtype=torch.float32, device=dev) for _ in range(4))
+    u = torch.empty((rows, M), dtype=td, device=dev)
+    g = torch.empty((rows, M), dtype=td, device=dev) if want_g else None
+    n_qkv = torch.empty((rows, N3), dtype=td, device=dev)
+    rt.check(rt.lib.sitk_attn_out_mlp_next_fwd(
+        o_c.data_ptr(), wo_c.data_ptr(), bo.data_ptr(), x.data_ptr(), xmid.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+        w1_c.data_ptr(), b1.data_ptr(), w2_c.data_ptr(), b2.data_ptr(), h.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+        u.data_ptr(), rt.ptr(g), out.data_ptr(), n_ln_w.data_ptr(), n_ln_b.data_ptr(), n_wqkv_c.data_ptr(), n_h.data_ptr(),
+        n_mean.data_ptr(), n_rstd.data_ptr(), n_qkv.data_ptr(), N3, rows, D, I, M, code, rt.stream_ptr()))
+    return out, xmid, h, mean, rstd, u, g, n_h, n_mean, n_rstd, n_qkv
+
+
 def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, dtype, want_g=True):
     """returns (dx, dx_c, du, g, partials (workgroups, 2, D)); g = gelu(u) is recomputed and returned when want_g
     (callers that saved g in forward pass want_g=False: g is None)"""

@@ -73,15 +73,24 @@ def layer_kernels(eng):
     fused_qkv = ops.ln_gemm_fused_supported(D, 3 * I, dt)
     rows = []
     # ---- forward ----
+    fused_chain = fused_mlp and fused_qkv and ops.attn_out_mlp_fused_supported(R, D, I, M, dt) and L > 1
     if fused_qkv:
         rows.append(("norm + to_qkv (fused)", "ln_gemm_fwd_kernel", lambda: ops.ln_gemm_fwd(x32, gam, bD, wqkv, dt),
-                     2.0 * R * 3 * I * D, R * (4 * D + (D + 3 * I) * es), L))
+                     2.0 * R * 3 * I * D, R * (4 * D + (D + 3 * I) * es), 1 if fused_chain else L))
     else:
         rows.append(("layernorm_fwd", "layernorm_fwd_kernel", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), L))
         rows.append(("to_qkv", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(h, wqkv, out_qkv, dt), 2.0 * R * 3 * I * D, R * (D + 3 * I) * es, L))
     rows.append(("attention forward", "attn_fwd_res_kernel", lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt), att, R * 4 * I * es, L))
     fused_proj = fused_mlp and ops.attn_out_mlp_fused_supported(R, D, I, M, dt)
-    if fused_proj:
+    if fused_proj and fused_qkv and L > 1:
+        # blocks 0 .. L-2: one launch from the attention output to the next block's qkv; the last block stops at `out`
+        rows.append(("to_out + norm + MLP + residuals + next block's norm + to_qkv (fused)", "mlp_kernel<false, .., NEXT>",
+                     lambda: ops.attn_out_mlp_next_fwd(o, wo, bD, x32, gam, bD, w1, bM, w2, bD, gam, bD, wqkv, dt, want_g=True),
+                     mlp_flops + 2.0 * R * D * I + 2.0 * R * 3 * I * D, R * (I * es + 12 * D + (2 * D + 2 * M + 3 * I) * es), L - 1))
+        rows.append(("to_out + residual + norm + net.0 + GELU + net.3 + residual (fused, last block)", "mlp_kernel<false>",
+                     lambda: ops.attn_out_mlp_fwd(o, wo, bD, x32, gam, bD, w1, bM, w2, bD, dt, want_g=True),
+                     mlp_flops + 2.0 * R * D * I, R * (I * es + 12 * D + (D + 2 * M) * es), 1))
+    elif fused_proj:
         rows.append(("to_out + residual + norm + net.0 + GELU + net.3 + residual (fused)", "mlp_kernel<false>",
                      lambda: ops.attn_out_mlp_fwd(o, wo, bD, x32, gam, bD, w1, bM, w2, bD, dt, want_g=True),
                      mlp_flops + 2.0 * R * D * I, R * (I * es + 12 * D + (D + 2 * M) * es), L))

@@ -221,3 +221,29 @@ def test_attn_out_mlp_fwd(ops, rows):
                                           M, rt.BF16, rt.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(xm_b[:rows], xmid) and bool((xm_b[rows:] == 7.0).all()) and torch.equal(out_b, out)
+
+
+@pytest.mark.parametrize("rows", [96, 321 * 3, 1000, 20544])
+def test_attn_out_mlp_next_fwd(ops, rows):
+    """... + the next block's LayerNorm and to_qkv appended: every output must carry the bits of the separate
+    launches (attn_out_mlp_fwd, then ln_gemm_fwd on its `out`)."""
+    M, N3 = 768, 576
+    x = rnd("aon/x", (rows, D), 1.5)
+    o = rnd("aon/o", (rows, D), 1.0).bfloat16()
+    woc, bo = rnd("aon/wo", (D, D), D ** -0.5).bfloat16(), rnd("aon/bo", (D,), 0.1)
+    ln_w, ln_b, w1, b1, w2, b2 = params("aon", M)
+    w1c, w2c = w1.bfloat16(), w2.bfloat16()
+    n_lw, n_lb = rnd("aon/nlw", (D,), 0.3) + 1.0, rnd("aon/nlb", (D,), 0.2)
+    wq = rnd("aon/wq", (N3, D), D ** -0.5).bfloat16()
+    got = ops.attn_out_mlp_next_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, n_lw, n_lb, wq, "bf16", want_g=True)
+    ref = ops.attn_out_mlp_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, "bf16", want_g=True)
+    qkv, nh, nmean, nrstd = ops.ln_gemm_fwd(ref[0], n_lw, n_lb, wq, "bf16")
+    torch.cuda.synchronize()
+    for a, b in zip(got[:7], ref):
+        assert torch.equal(a, b)
+    assert torch.equal(got[7], nh) and torch.equal(got[10], qkv)
+    assert rel(got[8], nmean) < 1e-6 and rel(got[9], nrstd) < 1e-6
+    # repeatable
+    again = ops.attn_out_mlp_next_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, n_lw, n_lb, wq, "bf16", want_g=True)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)

@@ -61,6 +61,7 @@ def main():
         "lnqkv_fwd": lambda: ops.ln_gemm_fwd(x32, bD, bD, w["qkv"], dt),
         "lnqkv_bwd": lambda: ops.ln_gemm_bwd(qkv, w["qkv_t"], x32, mean, rstd, bD, x32, dt),
         "proj_mlp_fwd": lambda: ops.attn_out_mlp_fwd(o, w["qkv"][:D].contiguous(), bD, x32, bD, bD, w["w1"], bM, w["w2"], bD, dt, want_g=True),
+        "proj_mlp_next_fwd": lambda: ops.attn_out_mlp_next_fwd(o, w["qkv"][:D].contiguous(), bD, x32, bD, bD, w["w1"], bM, w["w2"], bD, bD, bD, w["qkv"], dt, want_g=True),
         "mlp_fwd_g": lambda: ops.mlp_fwd(x32, bD, bD, w["w1"], bM, w["w2"], bD, dt, want_g=True),
         "proj": lambda: ops.gemm_nt(o, w["qkv"][:D].contiguous(), out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32),
         "tiny": lambda: ops.layernorm_fwd(x32[:128], bD, bD, dt),
