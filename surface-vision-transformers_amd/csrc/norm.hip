@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void ln_finalize_multi_kernel(LnFinalizeBatch 
   const int per = (nblocks + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
   float s = 0.f;
+#pragma unroll 4
   for (int b = b0; b < b1; ++b) s += e.partials[(size_t)b * 2 * D + c];
   if (b1 > b0) unsafeAtomicAdd(c < D ? e.dgamma + c : e.dbeta + (c - D), s);
 }
@@ -294,7 +295,7 @@ int layernorm_finalize_multi(const LnFinalizeEntry* entries, int count, int64_t 
     LnFinalizeBatch b;
     const int n = std::min(LN_FINALIZE_MAX, count - i0);
     for (int i = 0; i < n; ++i) b.e[i] = entries[i0 + i];
-    hipLaunchKernelGGL(ln_finalize_multi_kernel, dim3(cdiv(2 * D, 256), std::min(grid, 16), n), dim3(256), 0, s, b, grid, D);
+    hipLaunchKernelGGL(ln_finalize_multi_kernel, dim3(cdiv(2 * D, 256), std::min(grid, 64), n), dim3(256), 0, s, b, grid, D);
     SITK_LAUNCH_CHECK("layernorm_finalize_multi");
   }
   return SITK_OK;
