@@ -68,12 +68,15 @@ struct LayerActs {
   char *h1, *qkv, *o, *h2, *u, *g;
 };
 struct Scratch {
-  char *du, *dh, *d_o, *dqkv;
-  char* g;  // gelu(u) of the layer in flight, recomputed by the fused MLP backward for the weight gradient
+  // Operands of the weight gradients that backward produces (du, dqkv, the compute-dtype residual gradients) exist
+  // once per layer when the weight gradients of a whole backward slice run as ONE launch at its end (wg_batch).
+  std::vector<char*> du, dqkv, dxAc, dxBc;
+  std::vector<char*> g;  // gelu(u), only when the fused forward does not save it
+  char *dh, *d_o;
+  bool wg_batch;
   float *delta, *ping, *pong;
   // backward: residual-gradient ping-pong (fp32 dxB besides the caller's dx) and compute-dtype copies
   float* dxB;
-  char *dxAc, *dxBc;
   float* ln_partials;
   size_t ln_partial_floats;
   char* wgrad_ws;
@@ -122,24 +125,36 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
   L.acts_bytes = off;
   off = 0;
   auto stake = [&](size_t bytes) { char* p = scratch ? scratch + off : nullptr; off += align_up(bytes, 256); return p; };
-  L.scratch.du = stake(R * M * es);
-  L.scratch.g = mlp_fused(c) ? stake(R * M * es) : nullptr;
+  sitk_wgrad_desc wg4[4] = {};
+  {
+    const int dims[4][2] = {{(int)D, (int)M}, {(int)M, (int)D}, {(int)D, (int)I}, {3 * (int)I, (int)D}};
+    for (int i = 0; i < 4; ++i) {
+      wg4[i].M = (int)R; wg4[i].N = dims[i][0]; wg4[i].K = dims[i][1]; wg4[i].lddy = dims[i][0]; wg4[i].ldx = dims[i][1];
+    }
+  }
+  L.scratch.wg_batch = sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype) > 0 && 4 * c.depth <= 48;
+  const int nslot = L.scratch.wg_batch ? c.depth : 1;
+  L.scratch.du.resize(nslot); L.scratch.g.resize(nslot); L.scratch.dqkv.resize(nslot);
+  L.scratch.dxAc.resize(nslot); L.scratch.dxBc.resize(nslot);
+  for (int i = 0; i < nslot; ++i) {
+    L.scratch.du[i] = stake(R * M * es);
+    L.scratch.g[i] = (mlp_fused(c) && !g_in_fwd()) ? stake(R * M * es) : nullptr;
+    L.scratch.dqkv[i] = stake(R * 3 * I * es);
+    L.scratch.dxAc[i] = stake(R * D * es);
+    L.scratch.dxBc[i] = stake(R * D * es);
+  }
   L.scratch.dh = stake(R * D * es);
   L.scratch.d_o = stake(R * I * es);
-  L.scratch.dqkv = stake(R * 3 * I * es);
   L.scratch.delta = (float*)stake((size_t)c.B * c.heads * c.N * 4);
   L.scratch.ping = (float*)stake(R * D * 4);
   L.scratch.pong = (float*)stake(R * D * 4);
   L.scratch.dxB = (float*)stake(R * D * 4);
-  L.scratch.dxAc = stake(R * D * es);
-  L.scratch.dxBc = stake(R * D * es);
   {  // slab of the large-tile weight-gradient path (0 bytes when the shapes are not eligible)
-    sitk_wgrad_desc wg[4] = {};
-    const int dims[4][2] = {{(int)D, (int)M}, {(int)M, (int)D}, {(int)D, (int)I}, {3 * (int)I, (int)D}};
-    for (int i = 0; i < 4; ++i) {
-      wg[i].M = (int)R; wg[i].N = dims[i][0]; wg[i].K = dims[i][1]; wg[i].lddy = dims[i][0]; wg[i].ldx = dims[i][1];
-    }
-    L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg, 4, c.dtype);
+    std::vector<sitk_wgrad_desc> wg(4 * nslot);
+    for (int i = 0; i < 4 * nslot; ++i) wg[i] = wg4[i % 4];
+    L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg.data(), 4 * nslot, c.dtype);
+    if (L.scratch.wgrad_ws_bytes < sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype))     // a one-layer slice splits 12 ways
+      L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype);
     L.scratch.wgrad_ws = stake(L.scratch.wgrad_ws_bytes);
   }
   L.scratch.ln_partial_floats = sitk_layernorm_bwd_partial_floats((int64_t)R, (int)D);
@@ -309,51 +324,70 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   std::vector<LnFinalizeEntry> ln_entries;
   ln_entries.reserve(2 * (layer_end - layer_begin));
-  SITK_TRY(sitk_cast_rows(dx, D, S.dxAc, D, R, D, dt, stream));
+  // slot of a layer's weight-gradient operands: its own when the slice's weight gradients are batched, else shared
+  auto slot = [&](int l) { return S.wg_batch ? l : 0; };
+  std::vector<sitk_wgrad_desc> wg_all;
+  wg_all.reserve(4 * (layer_end - layer_begin));
+  SITK_TRY(sitk_cast_rows(dx, D, S.dxAc[slot(layer_end - 1)], D, R, D, dt, stream));
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const LayerActs& a = L.layers[l];
     const float* xl = l == 0 ? x_in : a.x_in;
+    const int sl = slot(l);
+    // where LN1' leaves the compute-dtype copy of dx for the MLP backward of layer l - 1 (never this layer's own
+    // slot while its weight gradients are still pending; layer 0 of a batched slice needs no copy at all)
+    char* dxc_next = l > 0 ? S.dxAc[slot(l - 1)] : (S.wg_batch ? nullptr : S.dxAc[0]);
+    char* dxAc = S.dxAc[sl];
+    char* dxBc = S.dxBc[sl];
+    char* du = S.du[sl];
+    char* dqkv = S.dqkv[sl];
     // ---- MLP branch: x_out = xmid + W2 gelu(W1 LN2(xmid) + b1) + b2 ----
     float* part2 = S.ln_partials + (size_t)(2 * l + 1) * S.ln_partial_floats;
     const void* gact = a.g;
     if (mlp_fused(c)) {
-      SITK_TRY(sitk_mlp_bwd(dx, S.dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, S.du, a.g ? nullptr : S.g, S.dxB, S.dxBc,
+      SITK_TRY(sitk_mlp_bwd(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, a.g ? nullptr : S.g[sl], S.dxB, dxBc,
                             part2, R, D, M, dt, stream));
       ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, (int)(sitk_mlp_bwd_partial_floats(R) / (2 * D))});
-      gact = a.g ? a.g : S.g;
+      gact = a.g ? a.g : S.g[sl];
     } else {
-      sitk_gemm_desc d1 = gemm_desc(R, M, D, S.dxAc, D, 0, a.w2_t, SITK_EPI_DGELU, S.du, M, 0);
+      sitk_gemm_desc d1 = gemm_desc(R, M, D, dxAc, D, 0, a.w2_t, SITK_EPI_DGELU, du, M, 0);
       d1.aux = a.u; d1.ldaux = M;
       SITK_TRY(sitk_gemm_nt(&d1, dt, stream));
-      sitk_gemm_desc d2 = gemm_desc(R, D, M, S.du, M, 0, a.w1_t, SITK_EPI_STORE, S.dh, D, 0);
+      sitk_gemm_desc d2 = gemm_desc(R, D, M, du, M, 0, a.w1_t, SITK_EPI_STORE, S.dh, D, 0);
       SITK_TRY(sitk_gemm_nt(&d2, dt, stream));
-      SITK_TRY(layernorm_bwd_deferred(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, S.dxB, S.dxBc, part2, R, D, dt, hs));
+      SITK_TRY(layernorm_bwd_deferred(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, S.dxB, dxBc, part2, R, D, dt, hs));
       ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, 0});
     }
     // ---- attention branch: xmid = x + Wo attn(Wqkv LN1(x)) + bo ----
-    sitk_gemm_desc d3 = gemm_desc(R, I, D, S.dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
+    sitk_gemm_desc d3 = gemm_desc(R, I, D, dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
     SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
-    SITK_TRY(sitk_attention_bwd(a.qkv, a.o, S.d_o, a.lse, S.delta, S.dqkv, c.B, c.N, c.heads, scale, dt, stream));
+    SITK_TRY(sitk_attention_bwd(a.qkv, a.o, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, scale, dt, stream));
     // ---- the four weight (+ bias) gradients of the layer, one launch ----
     sitk_wgrad_desc wg[4] = {
-        wgrad_desc(R, D, M, S.dxAc, 0, gact, G[l].w2, G[l].b2),
-        wgrad_desc(R, M, D, S.du, 0, a.h2, G[l].w1, G[l].b1),
-        wgrad_desc(R, D, I, S.dxBc, 0, a.o, G[l].wo, G[l].bo),
-        wgrad_desc(R, 3 * I, D, S.dqkv, 0, a.h1, G[l].wqkv, nullptr),
+        wgrad_desc(R, D, M, dxAc, 0, gact, G[l].w2, G[l].b2),
+        wgrad_desc(R, M, D, du, 0, a.h2, G[l].w1, G[l].b1),
+        wgrad_desc(R, D, I, dxBc, 0, a.o, G[l].wo, G[l].bo),
+        wgrad_desc(R, 3 * I, D, dqkv, 0, a.h1, G[l].wqkv, nullptr),
     };
-    SITK_TRY(sitk_gemm_wgrad_group_ws(wg, 4, dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
+    if (S.wg_batch) wg_all.insert(wg_all.end(), wg, wg + 4);       // launched once, after the slice's last layer
+    else SITK_TRY(sitk_gemm_wgrad_group_ws(wg, 4, dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
     float* part1 = S.ln_partials + (size_t)(2 * l) * S.ln_partial_floats;
     if (qkv_fused(c)) {
-      SITK_TRY(sitk_ln_gemm_bwd(S.dqkv, a.wqkv_t, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, part1, R, D, 3 * I, dt,
+      SITK_TRY(sitk_ln_gemm_bwd(dqkv, a.wqkv_t, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, dxc_next, part1, R, D, 3 * I, dt,
                                 stream));
       ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, (int)(sitk_ln_gemm_bwd_partial_floats(R) / (2 * D))});
     } else {
-      sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, S.dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
+      sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
       SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
-      SITK_TRY(layernorm_bwd_deferred(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, S.dxAc, part1, R, D, dt, hs));
+      SITK_TRY(layernorm_bwd_deferred(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, dxc_next, part1, R, D, dt, hs));
       ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, 0});
     }
   }
+  // The weight (+ bias) gradients of every layer of the slice in ONE launch: nothing downstream of a layer reads
+  // its parameter gradients, and with 21 tiles per layer a whole slice brings enough tiles to give each workgroup
+  // a long token run (12 layers: 252 tiles = one tile over ALL tokens per workgroup -- no token split, one slab
+  // write and one reduction per step instead of twelve).  The operands stayed in their per-layer slots.
+  if (S.wg_batch && !wg_all.empty())
+    SITK_TRY(sitk_gemm_wgrad_group_ws(wg_all.data(), (int)wg_all.size(), dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
   // every LayerNorm parameter gradient of the slice in one reduction launch
   return layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs);
 }

@@ -23,7 +23,10 @@
 
 namespace sitk {
 
-constexpr int WB_MAX_PROBLEMS = 4;
+// One launch takes up to 48 problems (the 4 Linears of up to 12 encoder layers: 3.8 KB of kernel arguments).  With
+// all 252 tiles of a 12-layer backward in one launch every workgroup owns a whole tile over ALL tokens: no token
+// split, so one slab write + one reduction launch per step instead of twelve of each (see sitk_encoder_bwd).
+constexpr int WB_MAX_PROBLEMS = 48;
 constexpr int WB_TILE_ELEMS = 128 * 192;
 struct WbProblem {
   const bf16* P;   // 128-column side operand (M, ldp)
@@ -62,9 +65,8 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   const int wt = wave & 1, wh = wave >> 1;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   int pi = 0;
-#pragma unroll
-  for (int i = 1; i < WB_MAX_PROBLEMS; ++i)
-    if (i < grp.count && bid >= grp.p[i].block_begin) pi = i;
+  for (int i = 1; i < grp.count; ++i)
+    if (bid >= grp.p[i].block_begin) pi = i;
   const WbProblem P = grp.p[pi];
   const int local = bid - P.block_begin;
   const int split = local / P.tiles, tile = local % P.tiles;
@@ -240,13 +242,9 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
 __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, const float* __restrict__ slab, int total_tiles) {
   const int gt = blockIdx.y;  // global tile index over all problems
   int pi = 0, tbase = 0;
-  bool found = false;
-#pragma unroll
-  for (int i = 0; i < WB_MAX_PROBLEMS; ++i) {
-    if (!found && i < grp.count) {
-      if (gt < tbase + grp.p[i].tiles) { pi = i; found = true; }
-      else tbase += grp.p[i].tiles;
-    }
+  for (int i = 0; i < grp.count; ++i) {
+    if (gt < tbase + grp.p[i].tiles) { pi = i; break; }
+    tbase += grp.p[i].tiles;
   }
   const WbProblem P = grp.p[pi];
   const int tile = gt - tbase;
@@ -324,7 +322,10 @@ extern "C" int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int
                                         sitk_stream_t stream) {
   SITK_REQUIRE(d != nullptr && count >= 1 && count <= WB_MAX_PROBLEMS, "gemm_wgrad_group_ws: 1..%d problems", WB_MAX_PROBLEMS);
   const size_t need = sitk_gemm_wgrad_group_ws_bytes(d, count, dtype);
-  if (need == 0 || ws == nullptr || ws_bytes < need) return sitk_gemm_wgrad_group(d, count, dtype, stream);  // generic tiles
+  if (need == 0 || ws == nullptr || ws_bytes < need) {       // generic tiles, 4 problems per launch
+    for (int i0 = 0; i0 < count; i0 += 4) SITK_TRY(sitk_gemm_wgrad_group(d + i0, std::min(4, count - i0), dtype, stream));
+    return SITK_OK;
+  }
   for (int i = 0; i < count; ++i)
     SITK_REQUIRE(d[i].dY && d[i].X && d[i].dW, "gemm_wgrad_group_ws: null operand in problem %d", i);
   WbGroup g;
