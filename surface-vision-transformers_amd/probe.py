@@ -124,8 +124,21 @@ def layer_kernels(eng):
     rows.append(("d to_out", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(dxc, wo_t, out_o, dt), 2.0 * R * D * I, R * (D + I) * es, L))
     rows.append(("attention backward", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
                  lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt), 2.5 * att, R * 8 * I * es, L))
-    rows.append(("weight gradients of the layer", "wgrad_big_kernel + wgrad_big_reduce_kernel",
-                 lambda: ops.gemm_wgrad_group(probs, dt, workspace=ws), wg_flops, R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L))
+    # the weight gradients of a whole backward slice run as one launch (csrc/encoder.hip): all L layers on one GPU
+    if 4 * L <= 48 and nbytes > 0:      # distinct operand tensors per layer, as in the real step (1.4 GB for tiny)
+        probs_all = list(probs)
+        for _ in range(L - 1):
+            u_l, gg_l, h_l, o_l, qkv_l, dxc_l = (t.clone() for t in (u, gg, h, o, qkv, dxc))
+            probs_all += [dict(dY=dxc_l, X=gg_l, dW=dW["w2"], db=dbD), dict(dY=u_l, X=h_l, dW=dW["w1"], db=dbM),
+                          dict(dY=dxc_l, X=o_l, dW=dW["o"], db=dbD2), dict(dY=qkv_l, X=h_l, dW=dW["qkv"])]
+    else:
+        probs_all = probs
+    nl = len(probs_all) // 4
+    nb_all = ops.rt.lib.sitk_gemm_wgrad_group_ws_bytes(*_desc_array(probs_all), ops.rt.dtype_code(dt))
+    ws_all = torch.empty(max(nb_all, nbytes, 16), dtype=torch.uint8, device=dev)
+    rows.append((f"weight gradients of {nl} layer(s), one launch", "wgrad_big_kernel + wgrad_big_reduce_kernel",
+                 lambda: ops.gemm_wgrad_group(probs_all, dt, workspace=ws_all), wg_flops * nl,
+                 nl * R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L // nl))
     if fused_qkv:
         rows.append(("d to_qkv + norm backward (fused)", "ln_gemm_bwd_kernel",
                      lambda: ops.ln_gemm_bwd(qkv, wqkv_t, x32, mean, rstd, gam, dx32, dt), 2.0 * R * 3 * I * D,

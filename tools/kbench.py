@@ -48,6 +48,9 @@ def main():
         "wgrad_layer": lambda: ops.gemm_wgrad_group([
             dict(dY=dxT, X=u, dW=dW["w2"], db=bD), dict(dY=u, X=h, dW=dW["w1"], db=bM),
             dict(dY=dxT, X=o, dW=dW["o"], db=bD), dict(dY=qkv, X=h, dW=dW["qkv"])], dt, workspace=WS),
+        "wgrad_12layers": lambda: ops.gemm_wgrad_group([
+            dict(dY=dxT, X=u, dW=dW["w2"], db=bD), dict(dY=u, X=h, dW=dW["w1"], db=bM),
+            dict(dY=dxT, X=o, dW=dW["o"], db=bD), dict(dY=qkv, X=h, dW=dW["qkv"])] * 12, dt, workspace=WS),
         "gemm_qkv": lambda: ops.gemm_nt(h, w["qkv"], out_qkv, dt),
         "gemm_fc1": lambda: ops.gemm_nt(h, w["w1"], out_u, dt, epilogue=ops.EPI_BIAS_GELU, bias=bM, out2=out_g),
         "gemm_fc2": lambda: ops.gemm_nt(u, w["w2"], out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32),
@@ -69,7 +72,7 @@ def main():
         "ln_bwd": lambda: ops.layernorm_bwd(h, x32, mean, rstd, bD, x32, bD.clone(), bD.clone(), dt, dx=out_x),
     }
     global WS
-    WS = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    WS = torch.empty(128 << 20, dtype=torch.uint8, device=dev)
     fn = fns[a.kernel]
     for _ in range(3):
         fn()
