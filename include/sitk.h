@@ -36,7 +36,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 5
+#define SITK_ABI_VERSION 6
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -231,6 +231,17 @@ int sitk_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H
 /* dqkv (B*N, 3*H*64) `dtype` <- gradients of q, k, v.  delta (B,H,N) fp32 is scratch.          */
 int sitk_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                        void* dqkv, int B, int N, int H, float scale, int dtype, sitk_stream_t stream);
+/* Attention backward with the to_out backward folded in (vit_pytorch.vit.Attention.to_out[0], key
+ * `layers.i.0.fn.to_out.0.weight`, utils/utils.py:26): instead of reading d_o, the query-side kernel forms
+ *   d_o = dxmid @ Wo        dxmid (B*N, D) `dtype` = gradient of the block's attention-branch output,
+ *                           wo_t (H*64, D) `dtype` = Wo^T (sitk_stage_weight's transposed copy)
+ * per 16-query tile from a 24 KB LDS copy of the head's slice of Wo^T, uses it in registers and WRITES it to d_o
+ * (B*N, H*64) for the key-side kernel.  Replaces one GEMM launch per block.  bf16, N <= 384, D == 192
+ * (`_supported` tells; anything else: sitk_gemm_nt + sitk_attention_bwd).                                        */
+int sitk_attention_bwd_proj_supported(int N, int D, int dtype);
+int sitk_attention_bwd_proj(const void* qkv, const void* o, const void* dxmid, const void* wo_t, void* d_o,
+                            const float* lse, float* delta, void* dqkv, int B, int N, int H, int D, float scale,
+                            int dtype, sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole encoder = vit_pytorch.vit.Transformer(dim, depth, heads, dim_head=64, mlp_dim, dropout=0)

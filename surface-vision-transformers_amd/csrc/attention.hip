@@ -402,16 +402,19 @@ SITK_DEV LaneOffs lane_offs_bf16(int lane) {
   for (int dt = 0; dt < 4; ++dt) o.tr[dt] = attn_res_off(r, (16 * dt + 4 * (lane & 3)) * 2);
   return o;
 }
+// NT: 16-row blocks of the tile that hold rows (4 = whole tile; the last tile of N = 64 k + 1 tokens holds one)
+template <int NT = 4>
 SITK_DEV void row_mma_o(f32x4 (&s)[4], const char* tile, const u32x4 (&frag)[2], const LaneOffs& o) {
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
       s[t] = Mma<bf16>::mma(*reinterpret_cast<const u32x4*>(tile + o.row[ks] + t * 2048), frag[ks], s[t]);
 }
+template <int NS2 = 2>
 SITK_DEV void tr_mma_o(f32x4 (&acc)[4], const f32x4 (&p)[4], const char* tile, const LaneOffs& o) {
 #pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
+  for (int s2 = 0; s2 < NS2; ++s2) {
     bf16x8 pb;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { pb[e] = (bf16)p[2 * s2][e]; pb[e + 4] = (bf16)p[2 * s2 + 1][e]; }
@@ -444,6 +447,16 @@ SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, 
   }
 }
 
+// the last tile of a sequence holds `rows` in 1..63 rows: run f with the number of 16-row blocks to compute (1, 2 or 4;
+// N = 321 = 5 * 64 + 1 and N = 81 = 64 + 17 are the reference's shapes: without this a sixth / a quarter of the score
+// work of every kernel is spent on padding)
+template <typename F>
+SITK_DEV void tail_dispatch(int rows, F&& f) {
+  if (rows <= 16) f(std::integral_constant<int, 1>{});
+  else if (rows <= 32) f(std::integral_constant<int, 2>{});
+  else f(std::integral_constant<int, 4>{});
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
                                                            float* __restrict__ lse, int N, int H, float scale) {
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
   const size_t ld = (size_t)3 * I;
   const T* base = qkv + (size_t)b * N * ld;
   char* sK = smem;
-  char* sV = smem + nkt * 8192;
+  char* sV = smem + (RES_MAX_N / 64) * 8192;   // fixed distance: one address register serves both tiles
   dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
   dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -473,17 +486,19 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nfull = N >> 6;   // key tiles without padding: no masking instructions in their body
+    // masked = 0: full key tile; masked = NT > 0: the last, partly filled tile, NT of its 16-key blocks computed
     auto kv_tile = [&](int t, auto masked) {
+      constexpr int MK = decltype(masked)::value, NT = MK ? MK : 4, NS2 = (NT + 1) / 2;
       f32x4 s[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      row_mma_o(s, sK + t * 8192, qf, lo);
+      row_mma_o<NT>(s, sK + t * 8192, qf, lo);
       float mx = -1e30f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          if constexpr (decltype(masked)::value) {
+          if constexpr (MK != 0) {
             if (t * 64 + 16 * i + 4 * fq + jj >= N) s[i][jj] = -INFINITY;
           }
           mx = fmaxf(mx, s[i][jj]);
@@ -491,9 +506,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
       mx = xor_max4(mx) * c;                       // c > 0: max commutes with the scale
       const float mn = fmaxf(m, mx);
       const float alpha = fast_exp2(m - mn);
+      // (scalar forms on purpose: the whole-vector v_pk_fma / v_pk_add forms the backward kernels use measured 0.8 us
+      //  SLOWER here -- the kernel is bound by the dependent chain of one tile, not by VALU issue slots)
       float ps = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const float pv = fast_exp2(fmaf(s[i][jj], c, -mn));
@@ -504,10 +521,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
       m = mn;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
-      tr_mma_o(oacc, s, sV + t * 8192, lo);
+      tr_mma_o<NS2>(oacc, s, sV + t * 8192, lo);     // s[i >= NT] = 0
     };
-    for (int t = 0; t < nfull; ++t) kv_tile(t, std::false_type{});
-    if (nfull < nkt) kv_tile(nfull, std::true_type{});
+    for (int t = 0; t < nfull; ++t) kv_tile(t, std::integral_constant<int, 0>{});
+    if (nfull < nkt) tail_dispatch(N - 64 * nfull, [&](auto nt) { kv_tile(nfull, nt); });
     const float lt = xor_sum4(l);
     const float inv = 1.0f / lt;
     if (q < N) {
@@ -519,72 +536,132 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
   }
 }
 
-template <int WAVES>
+// FOLD (D = 192): the gradient of the attention output is computed here instead of by a GEMM launch of its own:
+//   dO[q, 64 h + c] = sum_j dxmid[q, j] * Wo[j, 64 h + c]      (to_out backward, utils/utils.py:26 layout: wo_t = Wo^T, (I, D))
+// The head's 64 rows of wo_t (24 KB) sit in LDS next to K and V; per 16-query tile the product is taken TRANSPOSED
+// (A = wo_t rows, B = the lane's own dxmid row, 24 MFMAs), with the A rows of block ct taken in the order
+// c = 32 (ct >> 1) + 8 (m >> 2) + 4 (ct & 1) + (m & 3): the accumulators of blocks 2 ks and 2 ks + 1 then ARE the
+// lane's 16-byte fragment ks of its dO row (columns 32 ks + 8 fq .. + 8) -- no shuffle -- and go to `d_o_out` for the
+// key-side kernel in the same form.
+constexpr int FOLD_D = 192, FOLD_KS = FOLD_D / 32;
+template <int WAVES, bool FOLD = false>
 __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
                                                               const bf16* __restrict__ d_o, const float* __restrict__ lse,
                                                               float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
-                                                              int H, float scale) {
+                                                              int H, float scale, const bf16* __restrict__ dxmid = nullptr,
+                                                              const bf16* __restrict__ wo_t = nullptr,
+                                                              bf16* __restrict__ d_o_out = nullptr) {
   using T = bf16;
-  __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192];
+  __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192 + (FOLD ? 64 * FOLD_D * 2 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int h = blockIdx.x % H, b = blockIdx.x / H, I = H * 64, nkt = (N + 63) / 64;
+  // FOLD: the H workgroups of one sample all read that sample's dxmid rows -- keep them on one XCD (one L2)
+  const int bid = FOLD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int h = bid % H, b = bid / H, I = H * 64, nkt = (N + 63) / 64;
   const size_t ld = (size_t)3 * I;
   const T* base = qkv + (size_t)b * N * ld;
   char* sK = smem;
-  char* sV = smem + nkt * 8192;
+  char* sV = smem + (RES_MAX_N / 64) * 8192;   // fixed distance: one address register serves both tiles
   dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
   dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
+  char* sW = smem + 2 * (RES_MAX_N / 64) * 8192;   // FOLD: [k-step panel 0..5][64 rows][64 B], 16-B slots XOR (row >> 2) & 3
+  if constexpr (FOLD) {
+    for (int pc = wave; pc < 4 * FOLD_KS; pc += WAVES) {     // one piece = 16 rows x 64 B of one panel
+      const int panel = pc >> 2, row = (pc & 3) * 16 + (lane >> 2), kq = (lane & 3) ^ ((row >> 2) & 3);
+      const bf16* g = wo_t + (size_t)(h * 64 + row) * FOLD_D + panel * 32 + kq * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(sW + pc * 1024), 16, 0, 0);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_bf16(lane);
+  // FOLD: A-fragment offsets of blocks ct = 0 / 1 (+ 2048 for ct = 2 / 3, + 4096 per k-step): row c(ct, m), chunk fq
+  int wofs[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int crow = 8 * (fr >> 2) + 4 * ct + (fr & 3);
+    wofs[ct] = crow * 64 + ((fq ^ ((crow >> 2) & 3)) << 4);
+  }
   for (int qt = wave; qt * 16 < N; qt += WAVES) {
     const int q = qt * 16 + fr, qc = min(q, N - 1);
     u32x4 qf[2], dof[2];
     float dpart = 0.f;
+    if constexpr (FOLD) {
+      u32x4 dxf[FOLD_KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int eo = ks * 32 + fq * 8;
-      qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
-      const T* dop = d_o + ((size_t)b * N + qc) * I + h * 64 + eo;
-      const T* op = o + ((size_t)b * N + qc) * I + h * 64 + eo;
-      dof[ks] = *reinterpret_cast<const u32x4*>(dop);
+      for (int ks = 0; ks < FOLD_KS; ++ks)
+        dxf[ks] = *reinterpret_cast<const u32x4*>(dxmid + ((size_t)b * N + qc) * FOLD_D + ks * 32 + fq * 8);
+      f32x4 acc[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dpart += (float)dop[e] * (float)op[e];
+      for (int ct = 0; ct < 4; ++ct) {
+        acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < FOLD_KS; ++ks)
+          acc[ct] = Mma<bf16>::mma(*reinterpret_cast<const u32x4*>(sW + wofs[ct & 1] + (ct >> 1) * 2048 + ks * 4096),
+                                   dxf[ks], acc[ct]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pk[e] = (bf16)acc[2 * ks][e]; pk[e + 4] = (bf16)acc[2 * ks + 1][e]; }
+        dof[ks] = __builtin_bit_cast(u32x4, pk);
+        const int eo = ks * 32 + fq * 8;
+        qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + ((size_t)b * N + qc) * I + h * 64 + eo);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dpart += (float)pk[e] * (float)ov[e];
+        if (q < N) *reinterpret_cast<u32x4*>(d_o_out + ((size_t)b * N + q) * I + h * 64 + eo) = dof[ks];
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int eo = ks * 32 + fq * 8;
+        qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
+        const T* dop = d_o + ((size_t)b * N + qc) * I + h * 64 + eo;
+        const T* op = o + ((size_t)b * N + qc) * I + h * 64 + eo;
+        dof[ks] = *reinterpret_cast<const u32x4*>(dop);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dpart += (float)dop[e] * (float)op[e];
+      }
     }
     const float dl = xor_sum4(dpart);
     const size_t ridx = ((size_t)b * H + h) * N + qc;
     if (q < N && fq == 0) delta[ridx] = dl;
-    const float Lq = lse[ridx] * kLog2e;
+    const float Lq = lse[ridx] * kLog2e, ndl = -dl;
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nfull = N >> 6;
     auto kv_tile = [&](int t, auto masked) {
+      constexpr int MK = decltype(masked)::value, NT = MK ? MK : 4, NS2 = (NT + 1) / 2;
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      row_mma_o(s, sK + t * 8192, qf, lo);
-      row_mma_o(dp, sV + t * 8192, dof, lo);
+      row_mma_o<NT>(s, sK + t * 8192, qf, lo);
+      row_mma_o<NT>(dp, sV + t * 8192, dof, lo);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NT; ++i) {
+        f32x4 x = s[i] * c - Lq;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          float pv = fast_exp2(fmaf(s[i][jj], c, -Lq));
-          if constexpr (decltype(masked)::value) {
-            if (t * 64 + 16 * i + 4 * fq + jj >= N) pv = 0.f;
+          x[jj] = fast_exp2(x[jj]);
+          if constexpr (MK != 0) {
+            if (t * 64 + 16 * i + 4 * fq + jj >= N) x[jj] = 0.f;
           }
-          s[i][jj] = pv * (dp[i][jj] - dl) * scale;
         }
-      tr_mma_o(dq, s, sK + t * 8192, lo);
+        s[i] = x * (dp[i] + ndl);                      // dS / scale: the scale is applied once, to dQ
+      }
+      tr_mma_o<NS2>(dq, s, sK + t * 8192, lo);        // s[i >= NT] = 0
     };
-    for (int t = 0; t < nfull; ++t) kv_tile(t, std::false_type{});
-    if (nfull < nkt) kv_tile(nfull, std::true_type{});
+    for (int t = 0; t < nfull; ++t) kv_tile(t, std::integral_constant<int, 0>{});
+    if (nfull < nkt) tail_dispatch(N - 64 * nfull, [&](auto nt) { kv_tile(nfull, nt); });
     if (q < N) {
       T* row = dqkv + ((size_t)b * N + q) * ld + h * 64;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt + 4 * fq, dq[dt]);
+      for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt + 4 * fq, dq[dt] * scale);
     }
   }
 }
@@ -600,16 +677,17 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16
   const int h = blockIdx.x % H, b = blockIdx.x / H, I = H * 64, nqt = (N + 63) / 64;
   const size_t ld = (size_t)3 * I;
   const T* base = qkv + (size_t)b * N * ld;
-  char* sQ = smem;
-  char* sDO = smem + nqt * 8192;
-  float* sL = reinterpret_cast<float*>(smem + 2 * (RES_MAX_N / 64) * 8192);
+  // row statistics FIRST: every LDS read of the sweep then is `address register + 16-bit immediate`
+  float* sL = reinterpret_cast<float*>(smem);
   float* sD = sL + RES_MAX_N;
+  char* sQ = smem + 2 * RES_MAX_N * 4;
+  char* sDO = sQ + (RES_MAX_N / 64) * 8192;    // fixed distance: one address register serves both tiles
   dma_rows_bf16(sQ, base + h * 64, ld, N, nqt, wave, lane, WAVES);
   dma_rows_bf16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, nqt, wave, lane, WAVES);
   for (int r = tid; r < nqt * 64; r += WAVES * 64) {
     const size_t ridx = ((size_t)b * H + h) * N + min(r, N - 1);
-    sL[r] = r < N ? lse[ridx] * kLog2e : INFINITY;     // exp2(x - inf) = 0 for padded query rows
-    sD[r] = r < N ? delta[ridx] : 0.f;
+    sL[r] = r < N ? -lse[ridx] * kLog2e : -INFINITY;   // negated (added below); exp2(x - inf) = 0 for padded query rows
+    sD[r] = r < N ? -delta[ridx] : 0.f;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -627,31 +705,35 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (int t = 0; t < nqt; ++t) {
+    const int nfull = N >> 6;
+    // nt = 0: full query tile; nt > 0: the last, partly filled tile (its padded rows have L = inf, so p = 0 there)
+    auto q_tile = [&](int t, auto nt) {
+      constexpr int NT = decltype(nt)::value ? decltype(nt)::value : 4, NS2 = (NT + 1) / 2;
       f32x4 s[4], dp[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      row_mma_o(s, sQ + t * 8192, kf, lo);
-      row_mma_o(dp, sDO + t * 8192, vf, lo);
+      row_mma_o<NT>(s, sQ + t * 8192, kf, lo);
+      row_mma_o<NT>(dp, sDO + t * 8192, vf, lo);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NT; ++i) {
         const f32x4 Lr = *reinterpret_cast<const f32x4*>(sL + t * 64 + 16 * i + 4 * fq);
         const f32x4 Dr = *reinterpret_cast<const f32x4*>(sD + t * 64 + 16 * i + 4 * fq);
+        f32x4 x = s[i] * c + Lr;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const float pv = fast_exp2(fmaf(s[i][jj], c, -Lr[jj]));
-          s[i][jj] = pv;
-          dp[i][jj] = pv * (dp[i][jj] - Dr[jj]) * scale;
-        }
+        for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(x[jj]);
+        s[i] = x;
+        dp[i] = x * (dp[i] + Dr);                     // dS / scale: the scale is applied once, to dK
       }
-      tr_mma_o(dv, s, sDO + t * 8192, lo);
-      tr_mma_o(dk, dp, sQ + t * 8192, lo);
-    }
+      tr_mma_o<NS2>(dv, s, sDO + t * 8192, lo);       // s, dp [i >= NT] = 0
+      tr_mma_o<NS2>(dk, dp, sQ + t * 8192, lo);
+    };
+    for (int t = 0; t < nfull; ++t) q_tile(t, std::integral_constant<int, 0>{});
+    if (nfull < nqt) tail_dispatch(N - 64 * nfull, [&](auto nt) { q_tile(nfull, nt); });
     if (key < N) {
       T* row = dqkv + ((size_t)b * N + key) * ld + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        store4(row + I + 16 * dt + 4 * fq, dk[dt]);
+        store4(row + I + 16 * dt + 4 * fq, dk[dt] * scale);
         store4(row + 2 * I + 16 * dt + 4 * fq, dv[dt]);
       }
     }
@@ -671,6 +753,20 @@ static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, fl
   hipLaunchKernelGGL((attn_fwd_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
                      reinterpret_cast<T*>(o), lse, N, H, scale);
   return check_launch("attention_fwd");
+}
+
+static bool bwd_proj_supported(int N, int D, int dtype) { return dtype == SITK_BF16 && N <= RES_MAX_N && D == FOLD_D; }
+
+static int run_bwd_proj(const void* qkv, const void* o, const void* dxmid, const void* wo_t, void* d_o, const float* lse,
+                        float* delta, void* dqkv, int B, int N, int H, float scale, hipStream_t s) {
+  hipLaunchKernelGGL((attn_bwd_dq_res_kernel<16, true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
+                     reinterpret_cast<const bf16*>(o), (const bf16*)nullptr, lse, delta, reinterpret_cast<bf16*>(dqkv), N, H,
+                     scale, reinterpret_cast<const bf16*>(dxmid), reinterpret_cast<const bf16*>(wo_t),
+                     reinterpret_cast<bf16*>(d_o));
+  SITK_LAUNCH_CHECK("attention_bwd_proj_dq_res");
+  hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
+                     reinterpret_cast<const bf16*>(d_o), lse, delta, reinterpret_cast<bf16*>(dqkv), N, H, scale);
+  return check_launch("attention_bwd_dkv_res");
 }
 
 template <typename T>
@@ -721,4 +817,17 @@ extern "C" int sitk_attention_bwd(const void* qkv, const void* o, const void* d_
   if (dtype == SITK_F32) return run_bwd<float>(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, s);
   set_error("attention_bwd: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
+}
+
+extern "C" int sitk_attention_bwd_proj_supported(int N, int D, int dtype) { return sitk::bwd_proj_supported(N, D, dtype) ? 1 : 0; }
+
+extern "C" int sitk_attention_bwd_proj(const void* qkv, const void* o, const void* dxmid, const void* wo_t, void* d_o,
+                                       const float* lse, float* delta, void* dqkv, int B, int N, int H, int D, float scale,
+                                       int dtype, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(qkv && o && dxmid && wo_t && d_o && lse && delta && dqkv, "attention_bwd_proj: null pointer");
+  SITK_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attention_bwd_proj: bad shape B=%d N=%d H=%d", B, N, H);
+  SITK_REQUIRE(bwd_proj_supported(N, D, dtype), "attention_bwd_proj: unsupported N=%d D=%d dtype=%d (bf16, N <= %d, D == %d)", N,
+               D, dtype, RES_MAX_N, FOLD_D);
+  return run_bwd_proj(qkv, o, dxmid, wo_t, d_o, lse, delta, dqkv, B, N, H, scale, reinterpret_cast<hipStream_t>(stream));
 }

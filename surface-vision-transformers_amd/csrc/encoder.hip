@@ -358,9 +358,14 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
       ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, 0});
     }
     // ---- attention branch: xmid = x + Wo attn(Wqkv LN1(x)) + bo ----
-    sitk_gemm_desc d3 = gemm_desc(R, I, D, dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
-    SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
-    SITK_TRY(sitk_attention_bwd(a.qkv, a.o, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, scale, dt, stream));
+    if (sitk_attention_bwd_proj_supported(c.N, D, dt)) {     // d_o = dx_mid Wo inside the query-side kernel
+      SITK_TRY(sitk_attention_bwd_proj(a.qkv, a.o, dxBc, a.wo_t, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale, dt,
+                                       stream));
+    } else {
+      sitk_gemm_desc d3 = gemm_desc(R, I, D, dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
+      SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
+      SITK_TRY(sitk_attention_bwd(a.qkv, a.o, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, scale, dt, stream));
+    }
     // ---- the four weight (+ bias) gradients of the layer, one launch ----
     sitk_wgrad_desc wg[4] = {
         wgrad_desc(R, D, M, dxAc, 0, gact, G[l].w2, G[l].b2),

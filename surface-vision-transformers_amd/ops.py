@@ -318,6 +318,23 @@ def attention_bwd(qkv, o, d_o, lse, B, N, H, scale, dtype):
     return dqkv
 
 
+def attention_bwd_proj_supported(N, D, dtype):
+    return bool(rt.lib.sitk_attention_bwd_proj_supported(N, D, rt.dtype_code(dtype)))
+
+
+def attention_bwd_proj(qkv, o, dxmid, wo_t, lse, B, N, H, scale, dtype):
+    """attention backward with d_o = dxmid @ Wo formed inside the query-side kernel; returns (dqkv, d_o)."""
+    code = rt.dtype_code(dtype)
+    D = dxmid.shape[1]
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    d_o = torch.empty_like(o)
+    rt.check(rt.lib.sitk_attention_bwd_proj(qkv.data_ptr(), o.data_ptr(), dxmid.data_ptr(), wo_t.data_ptr(), d_o.data_ptr(),
+                                            lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N, H, D, scale, code,
+                                            rt.stream_ptr()))
+    return dqkv, d_o
+
+
 # ---- encoder ---------------------------------------------------------------------------------------
 def encoder_cfg(B, N, dim, depth, heads, mlp_dim, dtype):
     return rt.EncoderCfg(B, N, dim, depth, heads, mlp_dim, rt.dtype_code(dtype))

@@ -121,9 +121,14 @@ def layer_kernels(eng):
         rows.append(("layernorm_bwd (2)", "layernorm_bwd_kernel",
                      lambda: ops.layernorm_bwd(h, x32, mean, rstd, gam, dx32, dbD, dbD2, dt, dx=out_x, dx_c=out_xc, partials=part),
                      0, R * D * (2 * es + 12), L))
-    rows.append(("d to_out", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(dxc, wo_t, out_o, dt), 2.0 * R * D * I, R * (D + I) * es, L))
-    rows.append(("attention backward", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
-                 lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt), 2.5 * att, R * 8 * I * es, L))
+    if ops.attention_bwd_proj_supported(N, D, dt):     # d to_out folded into the query-side kernel (csrc/encoder.hip)
+        rows.append(("d to_out + attention backward (fused)", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
+                     lambda: ops.attention_bwd_proj(qkv, o_att, dxc, wo_t, lse, B, N, H, 0.125, dt),
+                     2.5 * att + 2.0 * R * D * I, R * (8 * I + D) * es, L))
+    else:
+        rows.append(("d to_out", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(dxc, wo_t, out_o, dt), 2.0 * R * D * I, R * (D + I) * es, L))
+        rows.append(("attention backward", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
+                     lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt), 2.5 * att, R * 8 * I * es, L))
     # the weight gradients of a whole backward slice run as one launch (csrc/encoder.hip): all L layers on one GPU
     if 4 * L <= 48 and nbytes > 0:      # distinct operand tensors per layer, as in the real step (1.4 GB for tiny)
         probs_all = list(probs)

@@ -10,11 +10,12 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsitk.so")
+# SITK_LIB: A/B timing of two builds of the same ABI (tools/kbench.py); the default is the in-tree build
+LIB_PATH = os.environ.get("SITK_LIB") or os.path.join(_HERE, "libsitk.so")
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class SitkError(RuntimeError):
@@ -84,6 +85,8 @@ _SIGS = {
     "sitk_ln_gemm_bwd": (C.c_int, [_P] * 10 + [_L, _I, _I, _I, _P]),
     "sitk_attention_fwd": (C.c_int, [_P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "sitk_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
+    "sitk_attention_bwd_proj_supported": (C.c_int, [_I, _I, _I]),
+    "sitk_attention_bwd_proj": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "sitk_encoder_acts_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "sitk_encoder_scratch_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "sitk_encoder_fwd": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), _P, _P, _P, _Z, _P, _Z, _I, _P]),

@@ -292,7 +292,8 @@ def _attn_ref(qkv, B, N, H, scale):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,N,H", [(2, 321, 3), (1, 81, 6), (2, 64, 1), (1, 130, 2), (1, 1281, 2)])
+@pytest.mark.parametrize("B,N,H", [(2, 321, 3), (1, 81, 6), (2, 64, 1), (1, 130, 2), (1, 1281, 2), (1, 100, 2), (1, 96, 1),
+                                   (1, 80, 1), (1, 384, 1), (1, 17, 1)])
 def test_attention_fwd_bwd(ops, dtype, B, N, H):
     td = tdt(dtype)
     qkv = rnd("at/qkv", (B * N, 3 * H * 64), 1.0).to(td)
@@ -310,6 +311,25 @@ def test_attention_fwd_bwd(ops, dtype, B, N, H):
     for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
         e = rel(dqkv[:, sl], qr.grad[:, sl])
         assert e < (5e-5 if dtype == "f32" else 2e-2), (name, e)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 321, 3), (1, 81, 3), (3, 64, 2), (1, 100, 1)])
+def test_attention_bwd_with_to_out_backward_folded(ops, B, N, H):
+    """sitk_attention_bwd_proj == sitk_gemm_nt (d_o = dx_mid Wo) + sitk_attention_bwd, and writes that d_o."""
+    dtype, td, D, I = "bf16", torch.bfloat16, 192, H * 64
+    assert ops.attention_bwd_proj_supported(N, D, dtype) and not ops.attention_bwd_proj_supported(N, 384, dtype)
+    qkv = rnd("atp/qkv", (B * N, 3 * I), 1.0).to(td)
+    dxmid = rnd("atp/dx", (B * N, D), 1.0).to(td)
+    wo = rnd("atp/wo", (D, I), 0.1).to(td)                     # to_out.0.weight (dim, inner)
+    wo_t = wo.t().contiguous()
+    o, lse = ops.attention_fwd(qkv, B, N, H, 0.125, dtype)
+    d_o_ref = torch.empty_like(o)
+    ops.gemm_nt(dxmid, wo_t, d_o_ref, dtype)
+    assert rel(d_o_ref, dxmid.float() @ wo.float()) < 1e-2
+    dqkv_ref = ops.attention_bwd(qkv, o, d_o_ref, lse, B, N, H, 0.125, dtype)
+    dqkv, d_o = ops.attention_bwd_proj(qkv, o, dxmid, wo_t, lse, B, N, H, 0.125, dtype)
+    assert rel(d_o, d_o_ref) < 2e-3                            # same product, different summation order, bf16 rounding
+    assert rel(dqkv, dqkv_ref) < 4e-3
 
 
 def test_attention_large_scores_online_softmax(ops):

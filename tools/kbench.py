@@ -1,7 +1,7 @@
 """Micro-benchmark of single hot-path kernels at the headline shapes (for rocprofv3 --pmc runs).
 
     python tools/kbench.py <kernel> [--reps 20] [--batch 64]
-kernels: wgrad_w1 wgrad_w2 wgrad_qkv wgrad_layer gemm_qkv gemm_fc1 gemm_fc2 gemm_dfc2 gemm_dfc1 attn_fwd attn_bwd ln_fwd ln_bwd mlp_fwd mlp_fwd_nosave mlp_bwd lnqkv_fwd lnqkv_bwd
+kernels: wgrad_w1 wgrad_w2 wgrad_qkv wgrad_layer gemm_qkv gemm_fc1 gemm_fc2 gemm_dfc2 gemm_dfc1 attn_fwd attn_bwd attn_bwd_do attn_bwd_proj ln_fwd ln_bwd mlp_fwd mlp_fwd_nosave mlp_bwd lnqkv_fwd lnqkv_bwd
 """
 import argparse
 import os
@@ -40,6 +40,7 @@ def main():
     dW = {k: torch.zeros(s, dtype=f32, device=dev) for k, s in dict(qkv=(3 * I, D), o=(D, I), w1=(M, D), w2=(D, M)).items()}
     out_qkv, out_u, out_g, out_h, out_x = torch.empty_like(qkv), torch.empty_like(u), torch.empty_like(u), torch.empty_like(h), torch.empty_like(x32)
     o_att, lse = ops.attention_fwd(qkv, B, N, H, 0.125, dt)
+    wo_t, out_o = rn(I, D), torch.empty_like(o)
     mean, rstd = torch.zeros(R, device=dev), torch.ones(R, device=dev)
     fns = {
         "wgrad_w1": lambda: ops.gemm_wgrad(u, h, dW["w1"], dt, db=bM),
@@ -58,6 +59,8 @@ def main():
         "gemm_dfc1": lambda: ops.gemm_nt(u, w["w1_t"], out_h, dt),
         "attn_fwd": lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt),
         "attn_bwd": lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt),
+        "attn_bwd_do": lambda: (ops.gemm_nt(dxT, wo_t, out_o, dt), ops.attention_bwd(qkv, o_att, out_o, lse, B, N, H, 0.125, dt)),
+        "attn_bwd_proj": lambda: ops.attention_bwd_proj(qkv, o_att, dxT, wo_t, lse, B, N, H, 0.125, dt),
         "mlp_fwd": lambda: ops.mlp_fwd(x32, bD, bD, w["w1"], bM, w["w2"], bD, dt),
         "mlp_fwd_nosave": lambda: ops.mlp_fwd(x32, bD, bD, w["w1"], bM, w["w2"], bD, dt, save=False),
         "mlp_bwd": lambda: ops.mlp_bwd(x32, dxT, x32, mean, rstd, bD, w["w2_t"], w["w1_t"], u, dt),
