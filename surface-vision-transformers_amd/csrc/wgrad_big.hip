@@ -56,6 +56,10 @@ __device__ u32x4 g_zero_page_wb[4];
 SITK_DEV void mma_acc(f32x4& acc, u32x4 a, u32x4 b) {
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
+// the same, pinned in program order (the stage loop interleaves it with asm LDS reads and DMA issues by hand)
+SITK_DEV void mma_acc_v(f32x4& acc, u32x4 a, u32x4 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
 
 __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __restrict__ slab) {
   constexpr int STG = 5 * 8192;  // panels: P0 P1 Q0 Q1 Q2, each 64 rows x 128 B
@@ -97,15 +101,30 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
     pdst[i] = (isP ? 0 : 2 * 8192) + q * 1024;
   }
   const int rows_total = mend - mbeg;
-  auto issue = [&](int st_idx, int stage) {
-    char* sb = smem + stage * STG;
-    const int left = rows_total - st_idx * 64;               // rows of this split still ahead (uniform)
+  // running source pointers: stages are issued strictly in order, one 64-row step each.  The zero page's address is
+  // held in an opaque register pair (left to the compiler it is rebuilt with s_getpc + exec masking per piece).
+  const char* zp = zero;
+  asm volatile("" : "+v"(zp));
+  const char* pcur[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      const bf16* src = prow[i] < left ? pbase[i] + (size_t)st_idx * pstep[i] : zerop;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(sb + pdst[i]), 16, 0, 0);
-    }
+  for (int i = 0; i < 10; ++i) pcur[i] = reinterpret_cast<const char*>(pbase[i]);
+  // bytes per 64-row step, uniform per side (lanes on columns outside the matrix walk a pointer they never use)
+  const int pincP = __builtin_amdgcn_readfirstlane(64 * P.ldp * (int)sizeof(bf16));
+  const int pincQ = __builtin_amdgcn_readfirstlane(64 * P.ldq * (int)sizeof(bf16));
+  int left = rows_total;                                      // rows of this split from the next stage to issue on
+  // one piece of the next stage to issue (rows past the split and columns outside the matrix read the zero page)
+  auto issue_piece = [&](int i, char* sb) {
+    const char* src = prow[i] < left ? pcur[i] : zp;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sb + pdst[i]), 16, 0, 0);
+    pcur[i] += i < 4 ? pincP : pincQ;
+    asm volatile("" : "+v"(pcur[i]));      // keep it a running pointer (hipcc otherwise rebuilds base + k * step per piece)
+  };
+  auto issue = [&](int stage) {
+    char* sb = smem + stage * STG;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) issue_piece(i, sb);
+    left -= 64;
   };
 
   // transposed-read addresses: rows wt*32 + 8g + q (+4), column block i of a panel at 32*(i ^ key) + 8*(lane&3)
@@ -135,65 +154,76 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   }
 
   const int nstage = (mend - mbeg + 63) / 64;
+  // Software pipeline (one wave per SIMD, so nothing else hides a stall): while the 48 MFMAs of stage s run, the wave
+  // reads the fragments of stage s + 1 into the other register set and issues the DMA pieces of stage s + 3 -- one
+  // transposed read pair after every third MFMA, one DMA piece after every fourth.  Measured before this: stage time =
+  // reads + DMA issue + MFMAs in sequence (removing the MFMAs saved exactly their own 103 us, tools/README.md).
+  // A stage is ALWAYS issued and always read (past the end: zero page into a slot nobody reads, stale LDS into registers
+  // nobody uses), so the loop has no conditions and the wait in front of every stage is the constant vmcnt(10).
+  struct Frags {
+    u32x2 pl[4], ph[4], ql[12], qh[12];
+  };
+  Frags fa, fb;
+  // read pair r of a stage: r < 4 -> P fragment r (panel wh), r >= 4 -> Q fragment r - 4 (panels 2..4)
+  auto read_pair = [&](Frags& f, int r, uint32_t so) {
+    if (r < 4) {
+      const uint32_t a = toff[r] + so + wh * 8192;
+      asm volatile(SITK_WB_TR2("%0", "%1", "%2", 0, 512) : "=&v"(f.pl[r]), "=&v"(f.ph[r]) : "v"(a));
+    } else {
+      const int j = r - 4;
+      const uint32_t a = toff[j & 3] + so;
+      if (j < 4) asm volatile(SITK_WB_TR2("%0", "%1", "%2", 16384, 16896) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
+      else if (j < 8) asm volatile(SITK_WB_TR2("%0", "%1", "%2", 24576, 25088) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
+      else asm volatile(SITK_WB_TR2("%0", "%1", "%2", 32768, 33280) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
+    }
+  };
+  for (int i = 0; i < NSTG - 1; ++i) issue(i);
+  asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int i = 0; i < NSTG - 1; ++i)
-    if (i < nstage) issue(i, i);
+  for (int r = 0; r < 16; ++r) read_pair(fa, r, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // The stage loop exists in three instantiations (no bias / dY on the P side / dY on the Q side), chosen once per
   // workgroup: with the bias MFMAs under a run-time condition inside ONE loop, hipcc carried the 12 bias tiles
   // through VGPR copies of their AGPRs in every stage (441 v_accvgpr moves per 64 MFMAs).
+  auto stage_body = [&](Frags& cur, Frags& nxt, int s, auto bp, auto bq) {
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          // stage s + 1 has landed (s + 2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    char* sb = smem + ((s + NSTG - 1) % NSTG) * STG;           // slot of stage s - 1: every wave has its fragments
+    const uint32_t so = ((s + 1) % NSTG) * STG;
+    u32x4 fp[4], fqv[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fp[i] = u32x4{cur.pl[i][0], cur.pl[i][1], cur.ph[i][0], cur.ph[i][1]};
+#pragma unroll
+    for (int j = 0; j < 12; ++j) fqv[j] = u32x4{cur.ql[j][0], cur.ql[j][1], cur.qh[j][0], cur.qh[j][1]};
+#pragma unroll
+    for (int m = 0; m < 48; ++m) {
+      mma_acc_v(acc[m / 12][m % 12], fp[m / 12], fqv[m % 12]);
+      if (m % 3 == 0) read_pair(nxt, m / 3, so);
+      if (m % 4 == 3 && m / 4 < 10) issue_piece(m / 4, sb);
+    }
+    left -= 64;
+    if constexpr (decltype(bp)::value) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mma_acc_v(accb[i], fp[i], ones);
+    }
+    if constexpr (decltype(bq)::value) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) mma_acc_v(accb[j], ones, fqv[j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
   auto stages = [&](auto bp, auto bq) {
-    for (int s = 0; s < nstage; ++s) {
-      const int rem = min(NSTG - 2, nstage - 1 - s);
-      if (rem >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else if (rem == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (s + NSTG - 1 < nstage) issue(s + NSTG - 1, (s + NSTG - 1) % NSTG);
-      const uint32_t so = (s % NSTG) * STG;
-      const uint32_t b0 = toff[0] + so, b1 = toff[1] + so, b2 = toff[2] + so, b3 = toff[3] + so;
-      const uint32_t a0 = b0 + wh * 8192, a1 = b1 + wh * 8192, a2 = b2 + wh * 8192, a3 = b3 + wh * 8192;
-      u32x2 pl[4], ph[4], ql[12], qh[12];
-      asm volatile(
-          SITK_WB_TR2("%0", "%1", "%16", 0, 512) SITK_WB_TR2("%2", "%3", "%17", 0, 512)
-          SITK_WB_TR2("%4", "%5", "%18", 0, 512) SITK_WB_TR2("%6", "%7", "%19", 0, 512)
-          SITK_WB_TR2("%8", "%9", "%20", 16384, 16896) SITK_WB_TR2("%10", "%11", "%21", 16384, 16896)
-          SITK_WB_TR2("%12", "%13", "%22", 16384, 16896) SITK_WB_TR2("%14", "%15", "%23", 16384, 16896)
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(pl[0]), "=&v"(ph[0]), "=&v"(pl[1]), "=&v"(ph[1]), "=&v"(pl[2]), "=&v"(ph[2]), "=&v"(pl[3]), "=&v"(ph[3]),
-            "=&v"(ql[0]), "=&v"(qh[0]), "=&v"(ql[1]), "=&v"(qh[1]), "=&v"(ql[2]), "=&v"(qh[2]), "=&v"(ql[3]), "=&v"(qh[3])
-          : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
-      asm volatile(
-          SITK_WB_TR2("%0", "%1", "%16", 24576, 25088) SITK_WB_TR2("%2", "%3", "%17", 24576, 25088)
-          SITK_WB_TR2("%4", "%5", "%18", 24576, 25088) SITK_WB_TR2("%6", "%7", "%19", 24576, 25088)
-          SITK_WB_TR2("%8", "%9", "%16", 32768, 33280) SITK_WB_TR2("%10", "%11", "%17", 32768, 33280)
-          SITK_WB_TR2("%12", "%13", "%18", 32768, 33280) SITK_WB_TR2("%14", "%15", "%19", 32768, 33280)
-          "s_waitcnt lgkmcnt(0)"
-          : "=&v"(ql[4]), "=&v"(qh[4]), "=&v"(ql[5]), "=&v"(qh[5]), "=&v"(ql[6]), "=&v"(qh[6]), "=&v"(ql[7]), "=&v"(qh[7]),
-            "=&v"(ql[8]), "=&v"(qh[8]), "=&v"(ql[9]), "=&v"(qh[9]), "=&v"(ql[10]), "=&v"(qh[10]), "=&v"(ql[11]), "=&v"(qh[11])
-          : "v"(b0), "v"(b1), "v"(b2), "v"(b3));
-      __builtin_amdgcn_sched_barrier(0);
-      u32x4 fp[4], fqv[12];
-  #pragma unroll
-      for (int i = 0; i < 4; ++i) fp[i] = u32x4{pl[i][0], pl[i][1], ph[i][0], ph[i][1]};
-  #pragma unroll
-      for (int j = 0; j < 12; ++j) fqv[j] = u32x4{ql[j][0], ql[j][1], qh[j][0], qh[j][1]};
-  #pragma unroll
-      for (int i = 0; i < 4; ++i)
-  #pragma unroll
-        for (int j = 0; j < 12; ++j) mma_acc(acc[i][j], fp[i], fqv[j]);
-      if constexpr (decltype(bp)::value) {
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) mma_acc(accb[i], fp[i], ones);
-      }
-      if constexpr (decltype(bq)::value) {
-  #pragma unroll
-        for (int j = 0; j < 12; ++j) mma_acc(accb[j], ones, fqv[j]);
-      }
+    // stages in pairs (the two fragment sets swap roles); an odd count runs one all-zero padding stage
+    for (int s = 0; s < nstage; s += 2) {
+      stage_body(fa, fb, s, bp, bq);
+      stage_body(fb, fa, s + 1, bp, bq);
     }
   };
   if (biasP) stages(std::true_type{}, std::false_type{});
   else if (biasQ) stages(std::false_type{}, std::true_type{});
   else stages(std::false_type{}, std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the padding stages issued past the end
   __builtin_amdgcn_s_barrier();   // every wave is done with the ring: reuse it for the token-half reduction
 
   // acc[i][j][jj] <-> P column (row of the tile) wh*64 + 16i + 4fq + jj, Q column 16j + fr
