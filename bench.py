@@ -116,6 +116,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # Every kernel of the main chain is ONE wave of workgroups that each own a CU's LDS (214 of the 256 CUs, 192 in
+        # attention): the all-reduce that overlaps backward has to fit in the CUs they leave idle, or each overlapped
+        # kernel needs a second wave.  One RCCL channel = one workgroup; the 22 MB of gradients do not need more.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
 
