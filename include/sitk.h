@@ -286,6 +286,16 @@ int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* param
                      const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
                      size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,
                      sitk_stream_t stream);
+/* The same with the patch embedding's weight gradient riding along (models/sit.py:50, `to_patch_embedding.1`): when
+ * the slice ends at layer 0, `embed` (dW[n][k] += sum_m dY[m][n] X[m][k] with dY = the encoder's input gradient in the
+ * compute dtype, row-mapped onto the patch rows) joins the slice's ONE weight-gradient launch instead of being a launch
+ * of its own.  embed->dY is ignored on entry: the call writes the compute-dtype copy of d(x_in) to `dx_c` (B*N, dim)
+ * and points the problem at it.  Returns SITK_OK with *embed_done = 1 when the problem was taken (bf16, large-tile
+ * path), 0 when the caller still has to run sitk_gemm_wgrad itself (then dx_c is not written).                      */
+int sitk_encoder_bwd_embed(const sitk_encoder_cfg* cfg, const sitk_layer_params* params,
+                           const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
+                           size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,
+                           const sitk_wgrad_desc* embed, void* dx_c, int* embed_done, sitk_stream_t stream);
 
 /* Row 0 of every sample of the residual stream: x[b, 0, :] = cls_token + pos_embedding[0, :]
  * (models/sit.py:70-73; rows 1..P come from the patch-embedding GEMM's BIAS_RES epilogue).      */

@@ -155,6 +155,7 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
     L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg.data(), 4 * nslot, c.dtype);
     if (L.scratch.wgrad_ws_bytes < sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype))     // a one-layer slice splits 12 ways
       L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype);
+    if (L.scratch.wgrad_ws_bytes) L.scratch.wgrad_ws_bytes += (size_t)64 * 128 * 192 * 4;   // + the patch embedding's tiles (sitk_encoder_bwd_embed)
     L.scratch.wgrad_ws = stake(L.scratch.wgrad_ws_bytes);
   }
   L.scratch.ln_partial_floats = sitk_layernorm_bwd_partial_floats((int64_t)R, (int)D);
@@ -306,6 +307,15 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
 extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
                                 const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
                                 size_t scratch_bytes, int layer_begin, int layer_end, sitk_stream_t stream) {
+  return sitk_encoder_bwd_embed(cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, nullptr,
+                                nullptr, nullptr, stream);
+}
+
+extern "C" int sitk_encoder_bwd_embed(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
+                                      const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
+                                      size_t scratch_bytes, int layer_begin, int layer_end, const sitk_wgrad_desc* embed,
+                                      void* dx_c, int* embed_done, sitk_stream_t stream) {
+  if (embed_done) *embed_done = 0;
   SITK_TRY(check_cfg(cfg));
   SITK_REQUIRE(P && G && x_in && dx && acts && scratch, "encoder_bwd: null pointer");
   const sitk_encoder_cfg& c = *cfg;
@@ -326,6 +336,15 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   ln_entries.reserve(2 * (layer_end - layer_begin));
   // slot of a layer's weight-gradient operands: its own when the slice's weight gradients are batched, else shared
   auto slot = [&](int l) { return S.wg_batch ? l : 0; };
+  // the patch embedding's weight gradient joins this slice's launch when the slice ends at layer 0, its shape takes the
+  // large-tile path and the slab has room for its tiles (sized for them in make_layout)
+  sitk_wgrad_desc emb = {};
+  bool take_embed = false;
+  if (embed && dx_c && embed_done && layer_begin == 0 && S.wg_batch) {
+    emb = *embed;
+    emb.dY = dx_c; emb.lddy = D; emb.dy_is_f32 = 0;
+    take_embed = sitk_gemm_wgrad_group_ws_bytes(&emb, 1, dt) > 0;
+  }
   std::vector<sitk_wgrad_desc> wg_all;
   wg_all.reserve(4 * (layer_end - layer_begin));
   SITK_TRY(sitk_cast_rows(dx, D, S.dxAc[slot(layer_end - 1)], D, R, D, dt, stream));
@@ -335,7 +354,7 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     const int sl = slot(l);
     // where LN1' leaves the compute-dtype copy of dx for the MLP backward of layer l - 1 (never this layer's own
     // slot while its weight gradients are still pending; layer 0 of a batched slice needs no copy at all)
-    char* dxc_next = l > 0 ? S.dxAc[slot(l - 1)] : (S.wg_batch ? nullptr : S.dxAc[0]);
+    char* dxc_next = l > 0 ? S.dxAc[slot(l - 1)] : (take_embed ? (char*)dx_c : (S.wg_batch ? nullptr : S.dxAc[0]));
     char* dxAc = S.dxAc[sl];
     char* dxBc = S.dxBc[sl];
     char* du = S.du[sl];
@@ -391,6 +410,12 @@ extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   // its parameter gradients, and with 21 tiles per layer a whole slice brings enough tiles to give each workgroup
   // a long token run (12 layers: 252 tiles = one tile over ALL tokens per workgroup -- no token split, one slab
   // write and one reduction per step instead of twelve).  The operands stayed in their per-layer slots.
+  if (take_embed) {
+    wg_all.push_back(emb);
+    take_embed = sitk_gemm_wgrad_group_ws_bytes(wg_all.data(), (int)wg_all.size(), dt) <= S.wgrad_ws_bytes;
+    if (!take_embed) wg_all.pop_back();          // (cannot happen with make_layout's sizing; the caller then runs it)
+    else *embed_done = 1;
+  }
   if (S.wg_batch && !wg_all.empty())
     SITK_TRY(sitk_gemm_wgrad_group_ws(wg_all.data(), (int)wg_all.size(), dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
   // every LayerNorm parameter gradient of the slice in one reduction launch

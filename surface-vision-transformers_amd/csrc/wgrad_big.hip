@@ -23,10 +23,11 @@
 
 namespace sitk {
 
-// One launch takes up to 48 problems (the 4 Linears of up to 12 encoder layers: 3.8 KB of kernel arguments).  With
+// One launch takes up to 52 problems (the 4 Linears of up to 12 encoder layers + the patch embedding: 5.4 KB of
+// kernel arguments).  With
 // all 252 tiles of a 12-layer backward in one launch every workgroup owns a whole tile over ALL tokens: no token
 // split, so one slab write + one reduction launch per step instead of twelve of each (see sitk_encoder_bwd).
-constexpr int WB_MAX_PROBLEMS = 48;
+constexpr int WB_MAX_PROBLEMS = 52;   // 12 layers x 4 + the patch embedding (+ spare)
 constexpr int WB_TILE_ELEMS = 128 * 192;
 struct WbProblem {
   const bf16* P;   // 128-column side operand (M, ldp)
@@ -37,6 +38,9 @@ struct WbProblem {
   int swapped;     // 0: P = dY (rows n), Q = X (cols k); 1: P = X (cols k), Q = dY (rows n)
   float* db;       // bias gradient of the dY side or null
   int M, tiles_q, tiles, block_begin, splits, chunk;
+  // row map of each side (sitk_rowmap; group 0 = identity).  group % 64 == 0, so a 64-row stage never straddles two
+  // groups and the running DMA pointer only takes (stride - group) extra rows when a stage starts a new group.
+  int pgroup, pstride, poffset, qgroup, qstride, qoffset;
 };
 struct WbGroup {
   WbProblem p[WB_MAX_PROBLEMS];
@@ -95,7 +99,9 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
     const int col = (isP ? p0 : q0) + panel * 64 + ((lane & 7) ^ (key << 1)) * 8;
     const bool colok = col < (isP ? P.cp : P.cq);
     const int ld = isP ? P.ldp : P.ldq;
-    pbase[i] = colok ? (isP ? P.P : P.Q) + (size_t)(mbeg + row) * ld + col : zerop;
+    const int grp_i = isP ? P.pgroup : P.qgroup, lrow = mbeg + row;
+    const int frow = grp_i ? (lrow / grp_i) * (isP ? P.pstride : P.qstride) + (isP ? P.poffset : P.qoffset) + lrow % grp_i : lrow;
+    pbase[i] = colok ? (isP ? P.P : P.Q) + (size_t)frow * ld + col : zerop;
     pstep[i] = colok ? (size_t)64 * ld : 0;
     prow[i] = colok ? row : (1 << 30);                       // invalid columns never leave the zero page
     pdst[i] = (isP ? 0 : 2 * 8192) + q * 1024;
@@ -112,16 +118,30 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   const int pincP = __builtin_amdgcn_readfirstlane(64 * P.ldp * (int)sizeof(bf16));
   const int pincQ = __builtin_amdgcn_readfirstlane(64 * P.ldq * (int)sizeof(bf16));
   int left = rows_total;                                      // rows of this split from the next stage to issue on
+  // row-mapped sides: position of the NEXT stage to issue inside its group, and the extra step at a group boundary
+  int gposP = P.pgroup ? mbeg % P.pgroup : 0, gposQ = P.qgroup ? mbeg % P.qgroup : 0;
+  const int extraP = P.pgroup ? (P.pstride - P.pgroup) * P.ldp * (int)sizeof(bf16) : 0;
+  const int extraQ = P.qgroup ? (P.qstride - P.qgroup) * P.ldq * (int)sizeof(bf16) : 0;
+  int incP = pincP, incQ = pincQ;                             // byte step from the stage being issued to the next one
+  auto next_stage_steps = [&]() __attribute__((always_inline)) {                             // call once per issued stage, before its pieces
+    gposP += 64;
+    gposQ += 64;
+    incP = pincP;
+    incQ = pincQ;
+    if (P.pgroup && gposP >= P.pgroup) { gposP = 0; incP += extraP; }
+    if (P.qgroup && gposQ >= P.qgroup) { gposQ = 0; incQ += extraQ; }
+  };
   // one piece of the next stage to issue (rows past the split and columns outside the matrix read the zero page)
-  auto issue_piece = [&](int i, char* sb) {
+  auto issue_piece = [&](int i, char* sb) __attribute__((always_inline)) {
     const char* src = prow[i] < left ? pcur[i] : zp;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sb + pdst[i]), 16, 0, 0);
-    pcur[i] += i < 4 ? pincP : pincQ;
+    pcur[i] += i < 4 ? incP : incQ;
     asm volatile("" : "+v"(pcur[i]));      // keep it a running pointer (hipcc otherwise rebuilds base + k * step per piece)
   };
-  auto issue = [&](int stage) {
+  auto issue = [&](int stage) __attribute__((always_inline)) {
     char* sb = smem + stage * STG;
+    next_stage_steps();
 #pragma unroll
     for (int i = 0; i < 10; ++i) issue_piece(i, sb);
     left -= 64;
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   };
   Frags fa, fb;
   // read pair r of a stage: r < 4 -> P fragment r (panel wh), r >= 4 -> Q fragment r - 4 (panels 2..4)
-  auto read_pair = [&](Frags& f, int r, uint32_t so) {
+  auto read_pair = [&](Frags& f, int r, uint32_t so) __attribute__((always_inline)) {
     if (r < 4) {
       const uint32_t a = toff[r] + so + wh * 8192;
       asm volatile(SITK_WB_TR2("%0", "%1", "%2", 0, 512) : "=&v"(f.pl[r]), "=&v"(f.ph[r]) : "v"(a));
@@ -186,11 +206,12 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   // The stage loop exists in three instantiations (no bias / dY on the P side / dY on the Q side), chosen once per
   // workgroup: with the bias MFMAs under a run-time condition inside ONE loop, hipcc carried the 12 bias tiles
   // through VGPR copies of their AGPRs in every stage (441 v_accvgpr moves per 64 MFMAs).
-  auto stage_body = [&](Frags& cur, Frags& nxt, int s, auto bp, auto bq) {
+  auto stage_body = [&](Frags& cur, Frags& nxt, int s, auto bp, auto bq) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          // stage s + 1 has landed (s + 2 may be in flight)
     __builtin_amdgcn_s_barrier();
     char* sb = smem + ((s + NSTG - 1) % NSTG) * STG;           // slot of stage s - 1: every wave has its fragments
     const uint32_t so = ((s + 1) % NSTG) * STG;
+    next_stage_steps();
     u32x4 fp[4], fqv[12];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fp[i] = u32x4{cur.pl[i][0], cur.pl[i][1], cur.ph[i][0], cur.ph[i][1]};
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
-  auto stages = [&](auto bp, auto bq) {
+  auto stages = [&](auto bp, auto bq) __attribute__((always_inline)) {
     // stages in pairs (the two fragment sets swap roles); an odd count runs one all-zero padding stage
     for (int s = 0; s < nstage; s += 2) {
       stage_body(fa, fb, s, bp, bq);
@@ -279,27 +300,42 @@ __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, cons
   const WbProblem P = grp.p[pi];
   const int tile = gt - tbase;
   const int p0 = (tile / P.tiles_q) * 128, q0 = (tile % P.tiles_q) * 192;
-  const int e4 = (blockIdx.x * 256 + threadIdx.x) * 4;   // element index within the 128 x 192 tile
-  if (e4 >= WB_TILE_ELEMS) return;
-  const int r = e4 / 192, c = e4 % 192;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int sp = 0; sp < P.splits; ++sp)
-    s += *reinterpret_cast<const f32x4*>(slab + (size_t)(P.block_begin + sp * P.tiles + tile) * WB_TILE_ELEMS + e4);
-  const int pc = p0 + r;
-  if (pc >= P.cp) return;
+  const int t = blockIdx.x * 256 + threadIdx.x;          // 6144 threads per 128 x 192 tile, 4 elements each
+  if (t * 4 >= WB_TILE_ELEMS) return;
+  const size_t sbase = (size_t)(P.block_begin + tile) * WB_TILE_ELEMS, sstep = (size_t)P.tiles * WB_TILE_ELEMS;
+  if (!P.swapped) {                                       // dW rows = P columns: 4 consecutive Q columns per thread
+    const int e4 = t * 4, r = e4 / 192, c = e4 % 192;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < P.splits; ++sp) s += *reinterpret_cast<const f32x4*>(slab + sbase + sp * sstep + e4);
+    const int pc = p0 + r;
+    if (pc >= P.cp) return;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int qc = q0 + c + e;
-    if (qc < P.cq) {
-      float* dst = P.swapped ? P.dW + (size_t)qc * P.lddw + pc : P.dW + (size_t)pc * P.lddw + qc;
-      *dst += s[e];
+    for (int e = 0; e < 4; ++e) {
+      const int qc = q0 + c + e;
+      if (qc < P.cq) P.dW[(size_t)pc * P.lddw + qc] += s[e];
+    }
+  } else {                                                // dW rows = Q columns: 4 consecutive P columns per thread, so
+    const int c = t % 192, r0 = (t / 192) * 4;            // that the transposed write is 16 bytes per thread too
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < P.splits; ++sp)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += slab[sbase + sp * sstep + (size_t)(r0 + e) * 192 + c];
+    const int qc = q0 + c, pc = p0 + r0;
+    if (qc >= P.cq) return;
+    float* dst = P.dW + (size_t)qc * P.lddw + pc;
+    if (pc + 3 < P.cp && (P.lddw & 3) == 0) {
+      *reinterpret_cast<f32x4*>(dst) += s;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (pc + e < P.cp) dst[e] += s[e];
     }
   }
 }
 
 static bool wb_eligible(const sitk_wgrad_desc& d) {
   const bool align = d.N % 8 == 0 && d.K % 8 == 0 && d.lddy % 8 == 0 && d.ldx % 8 == 0;
-  const bool plain = d.dymap.group == 0 && d.xmap.group == 0 && !d.dy_is_f32;
+  const bool plain = (d.dymap.group == 0 || d.dymap.group % 64 == 0) && d.xmap.group == 0 && !d.dy_is_f32;
   return align && plain && d.M >= 2048 && (d.K % 192 == 0 || d.N % 192 == 0);
 }
 
@@ -307,7 +343,12 @@ static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks,
   tiles_total = 0;
   for (int i = 0; i < count; ++i) {
     WbProblem& p = g.p[i];
-    const bool normal = d[i].K % 192 == 0;   // Q side = X columns (k)
+    // Q side (192-column tiles) = X columns (k) or dY columns (n): whichever orientation needs fewer 128 x 192 tiles
+    // (net.3 of dim 192: dY 192 x X 768 is 2 x 4 tiles with dY on the 128 side, half of them half empty, but 6 x 1
+    // the other way round)
+    const int tiles_normal = d[i].K % 192 == 0 ? cdiv(d[i].N, 128) * (d[i].K / 192) : (1 << 30);
+    const int tiles_swapped = d[i].N % 192 == 0 ? cdiv(d[i].K, 128) * (d[i].N / 192) : (1 << 30);
+    const bool normal = tiles_normal <= tiles_swapped;
     p.swapped = normal ? 0 : 1;
     p.P = reinterpret_cast<const bf16*>(normal ? d[i].dY : d[i].X);
     p.Q = reinterpret_cast<const bf16*>(normal ? d[i].X : d[i].dY);
@@ -316,6 +357,12 @@ static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks,
     p.cp = normal ? d[i].N : d[i].K;
     p.cq = normal ? d[i].K : d[i].N;
     p.dW = d[i].dW; p.lddw = d[i].lddw; p.db = d[i].db; p.M = d[i].M;
+    p.pgroup = p.pstride = p.poffset = p.qgroup = p.qstride = p.qoffset = 0;
+    if (d[i].dymap.group) {                                   // the row-mapped operand is dY: P side when normal
+      (normal ? p.pgroup : p.qgroup) = d[i].dymap.group;
+      (normal ? p.pstride : p.qstride) = d[i].dymap.stride;
+      (normal ? p.poffset : p.qoffset) = d[i].dymap.offset;
+    }
     p.tiles_q = p.cq / 192;
     p.tiles = cdiv(p.cp, 128) * p.tiles_q;
     tiles_total += p.tiles;

@@ -113,6 +113,8 @@ class TrainEngine:
         self.xL = torch.empty((B * N, D), dtype=f32, device=dev)
         self.dx = torch.empty((B * N, D), dtype=f32, device=dev)
         self.dW_embed = torch.zeros((D, ld), dtype=f32, device=dev)
+        self.dx_c = torch.empty((B * N, D), dtype=self.tdt, device=dev)     # compute-dtype d(x_0) for the embedding's dW
+        self._embed_wgrad_done = False
         self.loss = torch.zeros((1,), dtype=f32, device=dev)
         if task == "regression":
             self.target = torch.zeros((B, self.ncls), dtype=f32, device=dev)
@@ -192,7 +194,8 @@ class TrainEngine:
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
         lin = sit.to_patch_embedding[1]
         g = self.fp.g
-        ops.gemm_wgrad(self.dx, tokens, self.dW_embed, dt, db=g(lin.bias), M=B * P, N=D, K=ld, dymap=(P, N, 1))
+        if not self._embed_wgrad_done:
+            ops.gemm_wgrad(self.dx, tokens, self.dW_embed, dt, db=g(lin.bias), M=B * P, N=D, K=ld, dymap=(P, N, 1))
         g(lin.weight).copy_(self.dW_embed[:, :K])
         gpos = g(sit.pos_embedding).view(-1)[:N * D]
         ops.colsum_f32(self.dx.view(B, N * D), gpos)
@@ -246,6 +249,13 @@ class TrainEngine:
         ops.gemm_nt(self.dout, self.wo_t, self.dx, dt, M=B * P, N=D, K=K, omap=(P, N, 1))
 
     def _backward_slice(self, lb, le):
+        if lb == 0 and self.dx_c is not None:
+            # the slice that ends at layer 0 also carries the patch embedding's weight gradient (one launch for all)
+            lin = self.sit.to_patch_embedding[1]
+            self._embed_wgrad_done = ops.encoder_bwd_embed(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch,
+                                                           lb, le, self.tokens, self.dW_embed, self.fp.g(lin.bias), self.dx_c,
+                                                           self.P)
+            return
         ops.encoder_bwd(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, layer_begin=lb, layer_end=le)
 
     def _finish_backward(self):

@@ -123,7 +123,7 @@ def gemm_wgrad(dY, X, dW, dtype, db=None, M=None, N=None, K=None, dymap=None, xm
 
 
 def gemm_wgrad_group(problems, dtype, workspace=None):
-    """problems: list (<= 4) of dicts(dY, X, dW, db=None): all weight gradients in ONE launch.
+    """problems: list of dicts(dY, X, dW, db=None[, dymap=(group, stride, offset), M, K]): all weight gradients in ONE launch.
     workspace: None (64x64 tiles + atomics), a uint8 tensor, or "auto" (allocate what the large-tile
     slab path asks for)."""
     code = rt.dtype_code(dtype)
@@ -131,8 +131,8 @@ def gemm_wgrad_group(problems, dtype, workspace=None):
     for d, p in zip(arr, problems):
         dY, X, dW, db = p["dY"], p["X"], p["dW"], p.get("db")
         rt.require_cuda(dY, X, dW, db)
-        d.M, d.N, d.K = dY.shape[0], dW.shape[0], dW.shape[1]
-        d.dY, d.lddy, d.dy_is_f32, d.dymap = dY.data_ptr(), dY.stride(0), int(dY.dtype == torch.float32), _rowmap(None)
+        d.M, d.N, d.K = p.get("M", dY.shape[0]), dW.shape[0], p.get("K", dW.shape[1])
+        d.dY, d.lddy, d.dy_is_f32, d.dymap = dY.data_ptr(), dY.stride(0), int(dY.dtype == torch.float32), _rowmap(p.get("dymap"))
         d.X, d.ldx, d.xmap = X.data_ptr(), X.stride(0), _rowmap(None)
         d.dW, d.lddw, d.db = dW.data_ptr(), dW.stride(0), rt.ptr(db)
     if workspace == "auto":
@@ -371,6 +371,21 @@ def encoder_bwd(cfg, params, grads, x_in, dx, acts, scratch, layer_begin=0, laye
                                      acts.numel(), scratch.data_ptr(), scratch.numel(), layer_begin, layer_end,
                                      rt.stream_ptr()))
     return dx
+
+
+def encoder_bwd_embed(cfg, params, grads, x_in, dx, acts, scratch, layer_begin, layer_end, tokens, dW, db, dx_c, P):
+    """encoder_bwd with the patch embedding's weight gradient (dW (D, ld) fp32 += d(x_in)[rows 1..P]^T tokens, db) taken
+    into the slice's one weight-gradient launch.  Returns True when it was (else the caller runs gemm_wgrad)."""
+    d = rt.WgradDesc()
+    d.M, d.N, d.K = tokens.shape[0], dW.shape[0], dW.shape[1]
+    d.dY, d.lddy, d.dy_is_f32, d.dymap = 0, dW.shape[0], 0, _rowmap((P, P + 1, 1))
+    d.X, d.ldx, d.xmap = tokens.data_ptr(), tokens.stride(0), _rowmap(None)
+    d.dW, d.lddw, d.db = dW.data_ptr(), dW.stride(0), rt.ptr(db)
+    done = C.c_int(0)
+    rt.check(rt.lib.sitk_encoder_bwd_embed(C.byref(cfg), params, grads, x_in.data_ptr(), dx.data_ptr(), acts.data_ptr(),
+                                           acts.numel(), scratch.data_ptr(), scratch.numel(), layer_begin, layer_end,
+                                           C.byref(d), dx_c.data_ptr(), C.byref(done), rt.stream_ptr()))
+    return bool(done.value)
 
 
 def embed_cls_rows(x, cls_token, pos, B, N, D):

@@ -264,6 +264,25 @@ def test_wgrad_large_tile_slab_path_integer_exact(ops, D, M, H):
             assert torch.equal(p["db"], rb)
 
 
+def test_wgrad_large_tile_row_mapped_dy_integer_exact(ops):
+    """The patch-embedding weight gradient in the large-tile path: dY = rows 1..P of every sample of a (B, P + 1, D)
+    gradient (row map group P, stride P + 1, offset 1), X = (B P, ld) tokens with K = 612 of ld = 616 columns used,
+    next to a plain problem; token splits that start inside a group."""
+    B, P, D, K, ld = 8, 320, 192, 612, 616
+    dx = ints("wgm/dx", (B * (P + 1), D), -2, 3).to(torch.bfloat16)
+    tok = ints("wgm/tok", (B * P, ld), -2, 3).to(torch.bfloat16)
+    tok[:, K:] = 0
+    dW = torch.zeros((D, ld), device=DEV)
+    db = torch.zeros((D,), device=DEV)
+    dY2, X2 = ints("wgm/dY2", (B * P, 768), -2, 3).to(torch.bfloat16), ints("wgm/X2", (B * P, D), -2, 3).to(torch.bfloat16)
+    dW2 = torch.zeros((768, D), device=DEV)
+    ops.gemm_wgrad_group([dict(dY=dx, X=tok, dW=dW, db=db, dymap=(P, P + 1, 1), M=B * P),
+                          dict(dY=dY2, X=X2, dW=dW2)], "bf16", workspace="auto")
+    dxp = dx.float().view(B, P + 1, D)[:, 1:].reshape(B * P, D)
+    assert torch.equal(dW, dxp.t() @ tok.float()) and torch.equal(db, dxp.sum(0))
+    assert torch.equal(dW2, dY2.float().t() @ X2.float())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_group_matches_single_launches(ops, dtype):
     td = tdt(dtype)
