@@ -54,6 +54,50 @@ __global__ __launch_bounds__(256) void stage_weights_kernel(StageArgs a) {
   }
 }
 
+// bf16, rows % 4 == 0 and cols % 4 == 0 (every encoder Linear): 64 x 64 tiles, 16-byte loads, 8-byte stores in both
+// orientations (the 32 x 32 scalar kernel above took 21.6 us for the 48 matrices of SiT-tiny: 2-byte stores)
+__global__ __launch_bounds__(256) void stage_weights_vec_kernel(StageArgs a) {
+  __shared__ float tile[64][65];
+  int mi = 0;
+  const int bid = blockIdx.x;
+  while (mi + 1 < a.count && bid >= a.m[mi + 1].tile_begin) ++mi;
+  const StageMat& M = a.m[mi];
+  const int t = bid - M.tile_begin;
+  const int r0 = (t / M.tiles_c) * 64, c0 = (t % M.tiles_c) * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  bf16* dc = reinterpret_cast<bf16*>(M.dst_c);
+  bf16* dt = reinterpret_cast<bf16*>(M.dst_t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 16 * i, c = c0 + 4 * tx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < M.rows && c < M.cols) {
+      v = *reinterpret_cast<const f32x4*>(M.src + (size_t)r * M.cols + c);
+      if (dc) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+        *reinterpret_cast<bf16x4*>(dc + (size_t)r * M.cols + c) = o;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[ty + 16 * i][4 * tx + e] = v[e];
+  }
+  __syncthreads();
+  if (dt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 16 * i, r = r0 + 4 * tx;
+      if (c < M.cols && r < M.rows) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)tile[4 * tx + e][ty + 16 * i];
+        *reinterpret_cast<bf16x4*>(dt + (size_t)c * M.rows + r) = o;
+      }
+    }
+  }
+}
+
 template <typename T>
 static int launch_stage(const StageArgs& a, int total_tiles, hipStream_t s) {
   hipLaunchKernelGGL((stage_weights_kernel<T>), dim3(total_tiles), dim3(256), 0, s, a);
@@ -193,9 +237,17 @@ static int stage_all(const sitk_encoder_cfg& c, const sitk_layer_params* P, cons
   StageArgs a;
   a.count = 0;
   int tiles = 0;
+  const bool vec = !f32 && D % 4 == 0 && I % 4 == 0 && M % 4 == 0;   // 64 x 64 tiles, vector accesses
+  const int ts = vec ? 64 : 32;
   auto flush = [&]() -> int {
     if (a.count == 0) return SITK_OK;
-    const int e = f32 ? launch_stage<float>(a, tiles, s) : launch_stage<bf16>(a, tiles, s);
+    int e;
+    if (vec) {
+      hipLaunchKernelGGL(stage_weights_vec_kernel, dim3(tiles), dim3(256), 0, s, a);
+      e = check_launch("stage_weights_vec");
+    } else {
+      e = f32 ? launch_stage<float>(a, tiles, s) : launch_stage<bf16>(a, tiles, s);
+    }
     a.count = 0;
     tiles = 0;
     return e;
@@ -203,8 +255,8 @@ static int stage_all(const sitk_encoder_cfg& c, const sitk_layer_params* P, cons
   auto add = [&](const float* src, void* dc, void* dt, int rows, int cols) {
     StageMat& m = a.m[a.count++];
     m.src = src; m.dst_c = f32 ? nullptr : dc; m.dst_t = dt; m.rows = rows; m.cols = cols;
-    m.tile_begin = tiles; m.tiles_c = cdiv(cols, 32);
-    tiles += cdiv(rows, 32) * m.tiles_c;
+    m.tile_begin = tiles; m.tiles_c = cdiv(cols, ts);
+    tiles += cdiv(rows, ts) * m.tiles_c;
   };
   for (int l = 0; l < c.depth; ++l) {
     if (a.count + 4 > STAGE_MAX_MAT) SITK_TRY(flush());
