@@ -29,7 +29,7 @@ _ALIGN = 64  # floats (256 B): every parameter view is 16-byte aligned with room
 class FlatParams:
     """Flat fp32 storage for parameters / gradients / optimizer state of a module."""
 
-    def __init__(self, module, device):
+    def __init__(self, module, device, grad_extra=0):
         self.params = []
         seen = set()
         for p in module.parameters():
@@ -42,7 +42,11 @@ class FlatParams:
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.total = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        # grad_extra floats behind the gradients: per-step accumulators (loss, padded embedding gradient, ...) that are
+        # zeroed together with the gradients by ONE fill (`grad_all.zero_()`); never part of an all-reduce range
+        self.grad_all = torch.zeros(off + grad_extra, dtype=torch.float32, device=device)
+        self.grad = self.grad_all[:off]
+        self._extra_used = 0
         for p in self.params:
             o, n = self.offsets[id(p)]
             view = self.flat[o:o + n].view(p.shape)
@@ -53,6 +57,16 @@ class FlatParams:
     def g(self, p):
         o, n = self.offsets[id(p)]
         return self.grad[o:o + n].view(p.shape)
+
+    def extra(self, shape):
+        """A zero-initialised fp32 accumulator carved from the tail of the gradient buffer."""
+        n = 1
+        for d in shape:
+            n *= d
+        o = self.total + self._extra_used
+        self._extra_used += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+        assert o + n <= self.grad_all.numel(), "FlatParams: grad_extra too small"
+        return self.grad_all[o:o + n].view(shape)
 
     def offset(self, p):
         return self.offsets[id(p)][0]
@@ -97,7 +111,7 @@ class TrainEngine:
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self.nsteps = 0
 
-        self.fp = FlatParams(self.module, self.device)
+        self.fp = FlatParams(self.module, self.device, grad_extra=self.D * self.ld + 4 * _ALIGN + self.D)
         dev, f32 = self.device, torch.float32
         B, P, N, D, K, ld = self.B, self.P, self.N, self.D, self.K, self.ld
         self.cfg = ops.encoder_cfg(B, N, D, tr.depth, tr.heads, tr.mlp_dim, self.dtype)
@@ -112,10 +126,10 @@ class TrainEngine:
         self.x0 = torch.empty((B * N, D), dtype=f32, device=dev)
         self.xL = torch.empty((B * N, D), dtype=f32, device=dev)
         self.dx = torch.empty((B * N, D), dtype=f32, device=dev)
-        self.dW_embed = torch.zeros((D, ld), dtype=f32, device=dev)
+        self.dW_embed = self.fp.extra((D, ld))          # per-step accumulators live behind the gradients: one fill zeroes all
         self.dx_c = torch.empty((B * N, D), dtype=self.tdt, device=dev)     # compute-dtype d(x_0) for the embedding's dW
         self._embed_wgrad_done = False
-        self.loss = torch.zeros((1,), dtype=f32, device=dev)
+        self.loss = self.fp.extra((1,))
         if task == "regression":
             self.target = torch.zeros((B, self.ncls), dtype=f32, device=dev)
             self.logits = torch.empty((B, self.ncls), dtype=f32, device=dev)
@@ -132,7 +146,7 @@ class TrainEngine:
             self.dout = torch.empty((B * P, K), dtype=f32, device=dev)
             self.masked = torch.zeros((B * P,), dtype=torch.uint8, device=dev)
             self.replaced_full = torch.zeros((B, N), dtype=torch.uint8, device=dev)
-            self.rsum = torch.zeros((1, D), dtype=f32, device=dev)
+            self.rsum = self.fp.extra((1, D))
             self.dmt = torch.zeros((1, K), dtype=f32, device=dev)
         if optimizer == "sgd":
             self.state = [torch.zeros_like(self.fp.flat)] if momentum != 0 else [None]
@@ -159,9 +173,7 @@ class TrainEngine:
         sit, L, s = self.sit, rt.lib, self._s()
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
         lin = sit.to_patch_embedding[1]
-        self.fp.grad.zero_()
-        self.loss.zero_()
-        self.dW_embed.zero_()
+        self.fp.grad_all.zero_()                        # gradients + loss + padded embedding gradient
         if self.layout == "surface":
             rt.check(L.sitk_gather_tokens(self.inp.data_ptr(), self.table.data_ptr(), self.tokens.data_ptr(), B, 40962,
                                           self.Cc, P, self.V, ld, dt, s))
@@ -204,10 +216,7 @@ class TrainEngine:
     def _forward_mpp(self):
         ssl, sit, L, s = self.ssl, self.sit, rt.lib, self._s()
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
-        self.fp.grad.zero_()
-        self.loss.zero_()
-        self.dW_embed.zero_()
-        self.rsum.zero_()
+        self.fp.grad_all.zero_()                        # gradients + loss + padded embedding gradient + rsum
         if self.layout == "surface":
             rt.check(L.sitk_gather_tokens(self.inp.data_ptr(), self.table.data_ptr(), self.tok32.data_ptr(), B, 40962,
                                           self.Cc, P, self.V, K, rt.F32, s))
