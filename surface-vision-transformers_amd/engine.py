@@ -318,7 +318,11 @@ class TrainEngine:
             self._graphs = {}
         if idx not in self._graphs:
             fn()                                   # eager warm-up (also validates arguments)
-            torch.cuda.current_stream().synchronize()
+            # nothing else may touch the device while a stream captures (capture_error_mode "global"): a collective of an
+            # earlier segment still copying on another thread / stream makes the capture fail now and then (gloo does).
+            for w in self._pending:
+                w.wait()
+            torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
                 fn()
