@@ -324,7 +324,9 @@ class TrainEngine:
                 w.wait()
             torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
+            # thread_local: calls made by OTHER threads (the process group's watchdog polling its events) must not
+            # invalidate this thread's capture
+            with torch.cuda.graph(gr, capture_error_mode="thread_local"):
                 fn()
             self._graphs[idx] = gr
             return                                 # the eager run above already did this step's work
