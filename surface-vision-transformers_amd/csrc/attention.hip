@@ -26,6 +26,23 @@ struct AttnGeom {
   static constexpr int TILE_BYTES = 64 * RB;
 };
 
+// Swizzle of the bf16 attention tiles (tiled and sequence-resident kernels).  The transposed reads below take 4-row blocks that are FOUR rows apart
+// in the two 16-lane groups of a half wave (rows 4 fq + q: the accumulator layout of the probabilities), for which
+// the generic key of common.h (row bits 1 and 3, built for blocks eight rows apart) leaves rows r and r + 4 on the
+// same banks: a 2-way conflict on every ds_read_b64_tr_b16 (SQ_LDS_BANK_CONFLICT = 27 % of the LDS cycles of the
+// backward kernels, profiles/r01_pmc_attention_bwd.txt).  Row bits 1 and 2 give the 8 rows of a half-wave read 8
+// distinct (parity, window) slots and keep the 16-row ds_read_b128 pattern conflict-free.
+SITK_DEV int attn_res_key(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 1); }
+SITK_DEV int attn_res_off(int row, int byte_in_row) { return row * 128 + (byte_in_row ^ (attn_res_key(row) << 5)); }
+
+// byte offset of (row, byte) inside one 64-row x 128-byte panel: bf16 panels use the attention swizzle above, the f32
+// panels (ds_read_b32 transposed reads, a different access pattern) the generic one of common.h
+template <typename T>
+SITK_DEV int tile_off(int row, int byte_in_row) {
+  if constexpr (sizeof(T) == 2) return attn_res_off(row, byte_in_row);
+  else return lds_off(row, byte_in_row);
+}
+
 // stage 64 rows x 64 elements (row r <- src + r*ld, zero when row0 + r >= nrows) into an LDS tile
 template <typename T>
 SITK_DEV void stage_tile(char* tile, const T* __restrict__ src, size_t ld, int row0, int nrows, int tid) {
@@ -35,13 +52,13 @@ SITK_DEV void stage_tile(char* tile, const T* __restrict__ src, size_t ld, int r
     const int c = tid + 256 * i, row = c / G::CPR, cc = c % G::CPR;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (row0 + row < nrows) v = *reinterpret_cast<const u32x4*>(src + (size_t)(row0 + row) * ld + cc * G::EPV);
-    *reinterpret_cast<u32x4*>(tile + ((cc * 16) / 128) * (64 * 128) + lds_off(row, (cc * 16) % 128)) = v;
+    *reinterpret_cast<u32x4*>(tile + ((cc * 16) / 128) * (64 * 128) + tile_off<T>(row, (cc * 16) % 128)) = v;
   }
 }
 
 template <typename T>
 SITK_DEV u32x4 row_frag(const char* tile, int row, int ks, int fq) {
-  return *reinterpret_cast<const u32x4*>(tile + (ks >> 1) * (64 * 128) + lds_off(row, (ks & 1) * 64 + fq * 16));
+  return *reinterpret_cast<const u32x4*>(tile + (ks >> 1) * (64 * 128) + tile_off<T>(row, (ks & 1) * 64 + fq * 16));
 }
 
 // s[t] += tile rows (16t + i) . frag       (frag: this lane's 16-byte chunks of its own row)
@@ -72,9 +89,9 @@ struct TrMma<bf16> {
       for (int dt = 0; dt < 4; ++dt) {
         const int row = 32 * s2 + 4 * g + q, cb = (16 * dt + 4 * pp) * 2;
         const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) i16x4*)(tile + lds_off(row, cb)));
+            (__attribute__((address_space(3))) i16x4*)(tile + attn_res_off(row, cb)));
         const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) i16x4*)(tile + lds_off(row + 16, cb)));
+            (__attribute__((address_space(3))) i16x4*)(tile + attn_res_off(row + 16, cb)));
         u32x4 vf;
         vf[0] = __builtin_bit_cast(u32x2, lo)[0];
         vf[1] = __builtin_bit_cast(u32x2, lo)[1];
@@ -379,15 +396,6 @@ __device__ u32x4 g_zero_page_attn[4];
 // Per-lane byte offsets into a 64-row bf16 tile, computed ONCE per kernel: with them every fragment
 // read is `tile + lane offset + compile-time immediate` (the XOR swizzle of lds_off() depends only on
 // lane bits here; recomputing it per read cost more VALU than the softmax itself).
-// Swizzle of the sequence-resident tiles.  The transposed reads below take 4-row blocks that are FOUR rows apart
-// in the two 16-lane groups of a half wave (rows 4 fq + q: the accumulator layout of the probabilities), for which
-// the generic key of common.h (row bits 1 and 3, built for blocks eight rows apart) leaves rows r and r + 4 on the
-// same banks: a 2-way conflict on every ds_read_b64_tr_b16 (SQ_LDS_BANK_CONFLICT = 27 % of the LDS cycles of the
-// backward kernels, profiles/r01_pmc_attention_bwd.txt).  Row bits 1 and 2 give the 8 rows of a half-wave read 8
-// distinct (parity, window) slots and keep the 16-row ds_read_b128 pattern conflict-free.
-SITK_DEV int attn_res_key(int row) { return ((row >> 1) & 1) | (((row >> 2) & 1) << 1); }
-SITK_DEV int attn_res_off(int row, int byte_in_row) { return row * 128 + (byte_in_row ^ (attn_res_key(row) << 5)); }
-
 struct LaneOffs {
   int row[2];  // row-read (ds_read_b128) offset of k-step ks for row (lane&15):  + t * 2048 per 16-row block
   int tr[4];   // transposed-read offset of column block dt for row 4*(lane>>4) + ((lane>>2)&3): + s2*4096, + 2048 (second half)
