@@ -315,6 +315,13 @@ int sitk_head_bwd(const float* x, const float* ln_w, const float* ln_b, const fl
  * mean |p-t|; dpred = d loss / d pred.  loss must be zeroed by the caller.                      */
 int sitk_loss_fwd_bwd(const float* pred, const float* target, float* loss, float* dpred, int n, int l1,
                       sitk_stream_t stream);
+/* head_fwd + loss_fwd_bwd + head_bwd in ONE launch (the regression step between the encoder's forward and backward,
+ * tools/train.py:245-248,288-290): logits (B, n_classes) out, loss += mean loss (MSE, or L1 when l1), dx (B*N, D) out
+ * = d(loss)/d(x_out) for every row, parameter gradients accumulated.  One workgroup per sample.                   */
+int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
+                           const float* target, float* logits, float* loss, float* dx, float* d_ln_w, float* d_ln_b,
+                           float* d_w, float* d_b, int B, int N, int D, int n_classes, int pool_mean, int l1,
+                           sitk_stream_t stream);
 
 /* column sums: out[c] += sum_r in[r][c]  (d_pos_embedding / d_cls_token over the batch) */
 int sitk_colsum_f32(const float* in, int64_t rows, int cols, int ld, float* out, sitk_stream_t stream);

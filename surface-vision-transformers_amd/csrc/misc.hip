@@ -136,6 +136,86 @@ __global__ __launch_bounds__(256) void head_spread_kernel(float* __restrict__ dx
   }
 }
 
+// Pool + head + loss + their backward in ONE launch (the regression step of tools/train.py:245-248,288-290 between the
+// encoder's forward and backward): one workgroup of 4 waves per sample.  Wave 0 does what head_fwd, loss and head_bwd do
+// for its sample -- the loss gradient of a sample depends on no other sample, only the scalar loss is a sum (one atomic
+// per sample) -- then all four waves write the sample's rows 1..N-1 of dx (zeros, or copies of row 0 for mean pooling).
+// Replaces 4 dependent launches (head_fwd, loss, head_bwd, head_spread) of ~5-9 us each.
+__global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
+                                                              const float* __restrict__ ln_b, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, const float* __restrict__ target,
+                                                              float* __restrict__ logits, float* __restrict__ loss,
+                                                              float* __restrict__ dx, float* __restrict__ d_ln_w,
+                                                              float* __restrict__ d_ln_b, float* __restrict__ d_w,
+                                                              float* __restrict__ d_b, int B, int N, int D, int n_classes,
+                                                              int pool_mean, int l1) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave == 0) {
+    float v[HEAD_NV], dh[HEAD_NV];
+    head_pool(x, b, N, D, pool_mean, lane, v);
+    float mu, rs;
+    head_stats(v, D, lane, mu, rs);
+#pragma unroll
+    for (int i = 0; i < HEAD_NV; ++i) { v[i] = (v[i] - mu) * rs; dh[i] = 0.f; }  // xhat
+    const float inv = 1.0f / (float)(B * n_classes);
+    float lsum = 0.f;
+    for (int c = 0; c < n_classes; ++c) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < HEAD_NV; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) sacc += (v[i] * ln_w[d] + ln_b[d]) * w[(size_t)c * D + d];
+      }
+      const float logit = wave_sum(sacc) + bias[c];
+      const float df = logit - target[(size_t)b * n_classes + c];
+      const float dl = l1 ? (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv : 2.f * df * inv;
+      lsum += l1 ? fabsf(df) : df * df;
+      if (lane == 0) {
+        logits[(size_t)b * n_classes + c] = logit;
+        unsafeAtomicAdd(d_b + c, dl);
+      }
+#pragma unroll
+      for (int i = 0; i < HEAD_NV; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) {
+          dh[i] += dl * w[(size_t)c * D + d];
+          unsafeAtomicAdd(d_w + (size_t)c * D + d, dl * (v[i] * ln_w[d] + ln_b[d]));
+        }
+      }
+    }
+    if (lane == 0) unsafeAtomicAdd(loss, lsum * inv);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < HEAD_NV; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) {
+        unsafeAtomicAdd(d_ln_w + d, dh[i] * v[i]);
+        unsafeAtomicAdd(d_ln_b + d, dh[i]);
+        dh[i] *= ln_w[d];
+        s1 += dh[i];
+        s2 += dh[i] * v[i];
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+    const float post = pool_mean ? 1.0f / (float)N : 1.0f;
+#pragma unroll
+    for (int i = 0; i < HEAD_NV; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) dx[(size_t)b * N * D + d] = rs * (dh[i] - s1 - v[i] * s2) * post;
+    }
+  }
+  if (pool_mean) __syncthreads();                        // row 0 is copied below (same workgroup: visible after the barrier)
+  const int nvec = D >> 2;
+  float* dxb = dx + (size_t)b * N * D;
+  for (int i = threadIdx.x; i < (N - 1) * nvec; i += 256) {
+    const int c = i % nvec, n = i / nvec + 1;
+    f32x4 val = {0.f, 0.f, 0.f, 0.f};
+    if (pool_mean) val = load4(dxb + 4 * c);
+    store4(dxb + (size_t)n * D + 4 * c, val);
+  }
+}
+
 // x[b, 0, :] = cls + pos[0, :]   (models/sit.py:70-73: cls token row of the residual stream)
 __global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, int B, int N, int D) {
@@ -298,6 +378,19 @@ extern "C" int sitk_embed_cls_rows(float* x, const float* cls_token, const float
   hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for((int64_t)B * D / 4, 256, 1024)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, cls_token, pos, B, N, D);
   return check_launch("embed_cls_rows");
+}
+
+extern "C" int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
+                                      const float* target, float* logits, float* loss, float* dx, float* d_ln_w,
+                                      float* d_ln_b, float* d_w, float* d_b, int B, int N, int D, int n_classes,
+                                      int pool_mean, int l1, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x && ln_w && ln_b && w && b && target && logits && loss && dx && d_ln_w && d_ln_b && d_w && d_b,
+               "head_loss_fwd_bwd: null pointer");
+  SITK_REQUIRE(B > 0 && N > 0 && D > 0 && D <= HEAD_MAXD && D % 4 == 0 && n_classes > 0, "head_loss_fwd_bwd: bad shape");
+  hipLaunchKernelGGL(head_loss_fused_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ln_w, ln_b, w, b,
+                     target, logits, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1);
+  return check_launch("head_loss_fwd_bwd");
 }
 
 extern "C" int sitk_loss_fwd_bwd(const float* pred, const float* target, float* loss, float* dpred, int n, int l1,

@@ -182,14 +182,13 @@ class TrainEngine:
         self._embed_forward(self.tokens)
         ops.encoder_fwd(self.cfg, self.Pa, self.x0, self.xL, self.acts, self.scratch, save=True)
         ln, fc = sit.mlp_head[0], sit.mlp_head[1]
-        rt.check(L.sitk_head_fwd(self.xL.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), fc.weight.data_ptr(),
-                                 fc.bias.data_ptr(), self.logits.data_ptr(), B, N, D, self.ncls, self.pool_mean, s))
-        rt.check(L.sitk_loss_fwd_bwd(self.logits.data_ptr(), self.target.data_ptr(), self.loss.data_ptr(),
-                                     self.dlogits.data_ptr(), B * self.ncls, int(self.loss_kind == "l1"), s))
         g = self.fp.g
-        rt.check(L.sitk_head_bwd(self.xL.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), fc.weight.data_ptr(),
-                                 self.dlogits.data_ptr(), self.dx.data_ptr(), g(ln.weight).data_ptr(), g(ln.bias).data_ptr(),
-                                 g(fc.weight).data_ptr(), g(fc.bias).data_ptr(), B, N, D, self.ncls, self.pool_mean, s))
+        # pool + head + loss + their backward: one launch (dx = d(loss)/d(x_L) for every row comes out of it)
+        rt.check(L.sitk_head_loss_fwd_bwd(self.xL.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), fc.weight.data_ptr(),
+                                          fc.bias.data_ptr(), self.target.data_ptr(), self.logits.data_ptr(),
+                                          self.loss.data_ptr(), self.dx.data_ptr(), g(ln.weight).data_ptr(),
+                                          g(ln.bias).data_ptr(), g(fc.weight).data_ptr(), g(fc.bias).data_ptr(), B, N, D,
+                                          self.ncls, self.pool_mean, int(self.loss_kind == "l1"), s))
 
     def _embed_forward(self, tokens):
         sit, L, s = self.sit, rt.lib, self._s()

@@ -410,6 +410,17 @@ def head_bwd(x, ln_w, ln_b, w, dlogits, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, p
     return dx
 
 
+def head_loss_fwd_bwd(x, ln_w, ln_b, w, b, target, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, pool_mean, l1=False):
+    """pool + head + loss and their backward in one launch; returns logits (B, n_classes)."""
+    ncls = w.shape[0]
+    logits = torch.empty((B, ncls), dtype=torch.float32, device=x.device)
+    rt.check(rt.lib.sitk_head_loss_fwd_bwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                           target.data_ptr(), logits.data_ptr(), loss.data_ptr(), dx.data_ptr(),
+                                           d_ln_w.data_ptr(), d_ln_b.data_ptr(), d_w.data_ptr(), d_b.data_ptr(), B, N, D, ncls,
+                                           int(pool_mean), int(l1), rt.stream_ptr()))
+    return logits
+
+
 def loss_fwd_bwd(pred, target, loss, dpred, l1=False):
     rt.check(rt.lib.sitk_loss_fwd_bwd(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), dpred.data_ptr(),
                                       pred.numel(), int(l1), rt.stream_ptr()))

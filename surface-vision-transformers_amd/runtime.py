@@ -97,6 +97,7 @@ _SIGS = {
     "sitk_embed_cls_rows": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "sitk_head_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sitk_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sitk_head_loss_fwd_bwd": (C.c_int, [_P] * 13 + [_I] * 6 + [_P]),
     "sitk_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "sitk_colsum_f32": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "sitk_mpp_corrupt": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -440,6 +440,29 @@ def test_head_fwd_bwd(ops, pool_mean, ncls):
         assert rel(g, r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("pool_mean,ncls,l1", [(False, 1, 0), (True, 1, 0), (False, 3, 1), (True, 2, 1)])
+def test_head_loss_fused_matches_autograd(ops, pool_mean, ncls, l1):
+    """sitk_head_loss_fwd_bwd (one launch) == pool + LayerNorm + Linear + MSE/L1 loss and their autograd backward."""
+    B, N, D = 6, 81, 192
+    x = rnd("hl/x", (B, N, D))
+    lw, lb = 1 + 0.1 * rnd("hl/lw", (D,)), 0.1 * rnd("hl/lb", (D,))
+    w, b = rnd("hl/w", (ncls, D), 0.1), rnd("hl/b", (ncls,), 0.1)
+    tgt = rnd("hl/t", (B, ncls))
+    xr, lwr, lbr, wr, br = [t.clone().requires_grad_(True) for t in (x, lw, lb, w, b)]
+    pooled = xr.mean(1) if pool_mean else xr[:, 0]
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(pooled, (D,), lwr, lbr, 1e-5), wr, br)
+    lref = torch.nn.functional.l1_loss(ref, tgt) if l1 else torch.nn.functional.mse_loss(ref, tgt)
+    lref.backward()
+    loss = torch.zeros(1, device=DEV)
+    dx = torch.full((B * N, D), 7.0, device=DEV)
+    grads = [torch.zeros_like(t) for t in (lw, lb, w, b)]
+    logits = ops.head_loss_fwd_bwd(x.reshape(B * N, D), lw, lb, w, b, tgt, loss, dx, *grads, B, N, D, pool_mean, l1=bool(l1))
+    assert rel(logits, ref) < 1e-5 and abs(float(loss) - float(lref)) < 1e-5 * max(1.0, abs(float(lref)))
+    assert rel(dx.reshape(B, N, D), xr.grad) < 1e-5
+    for g, r in zip(grads, (lwr, lbr, wr, br)):
+        assert rel(g, r.grad) < 1e-5
+
+
 @pytest.mark.parametrize("l1", [0, 1])
 def test_loss(ops, l1):
     p, t = rnd("ls/p", (64,)), rnd("ls/t", (64,))
