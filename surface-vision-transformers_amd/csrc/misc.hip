@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __res
                                                               float* __restrict__ d_ln_b, float* __restrict__ d_w,
                                                               float* __restrict__ d_b, int B, int N, int D, int n_classes,
                                                               int pool_mean, int l1) {
+  // grid (B, S): slice y of sample b writes its share of the rows 1..N-1; slice 0 also does the head itself.  Mean pooling
+  // copies row 0, which slice 0 produces: S = 1 then (chosen by the launcher).
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave == 0) {
+  if (wave == 0 && blockIdx.y == 0) {
     float v[HEAD_NV], dh[HEAD_NV];
     head_pool(x, b, N, D, pool_mean, lane, v);
     float mu, rs;
@@ -208,7 +210,9 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __res
   if (pool_mean) __syncthreads();                        // row 0 is copied below (same workgroup: visible after the barrier)
   const int nvec = D >> 2;
   float* dxb = dx + (size_t)b * N * D;
-  for (int i = threadIdx.x; i < (N - 1) * nvec; i += 256) {
+  const int per = ((N - 1) * nvec + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int i_end = min((N - 1) * nvec, ((int)blockIdx.y + 1) * per);
+  for (int i = (int)blockIdx.y * per + threadIdx.x; i < i_end; i += 256) {
     const int c = i % nvec, n = i / nvec + 1;
     f32x4 val = {0.f, 0.f, 0.f, 0.f};
     if (pool_mean) val = load4(dxb + 4 * c);
@@ -388,7 +392,8 @@ extern "C" int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const f
   SITK_REQUIRE(x && ln_w && ln_b && w && b && target && logits && loss && dx && d_ln_w && d_ln_b && d_w && d_b,
                "head_loss_fwd_bwd: null pointer");
   SITK_REQUIRE(B > 0 && N > 0 && D > 0 && D <= HEAD_MAXD && D % 4 == 0 && n_classes > 0, "head_loss_fwd_bwd: bad shape");
-  hipLaunchKernelGGL(head_loss_fused_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ln_w, ln_b, w, b,
+  const int slices = pool_mean ? 1 : std::max(1, std::min(8, 512 / B));      // fill the chip with the row writes
+  hipLaunchKernelGGL(head_loss_fused_kernel, dim3(B, slices), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ln_w, ln_b, w, b,
                      target, logits, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1);
   return check_launch("head_loss_fwd_bwd");
 }
