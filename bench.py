@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N > 1 (gloo: rehearsal of the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,8 +112,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1 and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but {ndev} GPU(s) visible (RCCL needs one GPU per rank)")
+    local_dev = local_rank % max(ndev, 1)              # gloo rehearsal: several ranks may share a GPU
+    torch.cuda.set_device(local_dev)
+    dev = torch.device(f"cuda:{local_dev}")
     pg = None
     if world > 1:
         import torch.distributed as dist
@@ -120,7 +126,10 @@ def main():
         # attention): the all-reduce that overlaps backward has to fit in the CUs they leave idle, or each overlapped
         # kernel needs a second wave.  One RCCL channel = one workgroup; the 22 MB of gradients do not need more.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         pg = dist.group.WORLD
 
     import sitk  # noqa: F401
