@@ -259,17 +259,52 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
         for (int jj = 0; jj < 4; ++jj) red[(16 * i + 4 * fq + jj) * 192 + 16 * j + fr] = acc[i][j][jj];
   }
   __syncthreads();
-  if (wt == 0) {
-    float* out = slab + (size_t)bid * WB_TILE_ELEMS + wh * (64 * 192);
+  if (wt == 0) {                                      // the whole 128 x 192 tile, both token halves, now in LDS
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 12; ++j)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int e = (16 * i + 4 * fq + jj) * 192 + 16 * j + fr;
-          out[e] = acc[i][j][jj] + red[e];
-        }
+        for (int jj = 0; jj < 4; ++jj) red[(16 * i + 4 * fq + jj) * 192 + 16 * j + fr] += acc[i][j][jj];
+  }
+  __syncthreads();
+  // Write-out by all 256 threads in 16-byte pieces.  A tile that covers ALL tokens of its problem (splits == 1: the 12-layer
+  // launch of one GPU) is added straight into dW; token-split tiles go to the slab and are summed by the reduce kernel.
+  const float* til = reinterpret_cast<const float*>(smem);
+  const bool vec_ok = (P.lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(P.dW) & 15) == 0;
+  if (P.splits > 1) {
+    float* out = slab + (size_t)bid * WB_TILE_ELEMS;
+    for (int e4 = tid * 4; e4 < WB_TILE_ELEMS; e4 += 1024) *reinterpret_cast<f32x4*>(out + e4) = *reinterpret_cast<const f32x4*>(til + e4);
+  } else if (!P.swapped) {                            // dW rows = P columns
+    for (int e4 = tid * 4; e4 < WB_TILE_ELEMS; e4 += 1024) {
+      const int r = e4 / 192, c = e4 % 192, pc = p0 + r, qc = q0 + c;
+      if (pc >= P.cp || qc >= P.cq) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(til + e4);
+      float* dst = P.dW + (size_t)pc * P.lddw + qc;
+      if (qc + 3 < P.cq && vec_ok) {
+        *reinterpret_cast<f32x4*>(dst) += v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (qc + e < P.cq) dst[e] += v[e];
+      }
+    }
+  } else {                                            // dW rows = Q columns: 4 consecutive P columns per thread
+    for (int t = tid; t < WB_TILE_ELEMS / 4; t += 256) {
+      const int c = t % 192, r0 = (t / 192) * 4, qc = q0 + c, pc = p0 + r0;
+      if (qc >= P.cq || pc >= P.cp) continue;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = til[(r0 + e) * 192 + c];
+      float* dst = P.dW + (size_t)qc * P.lddw + pc;
+      if (pc + 3 < P.cp && vec_ok) {
+        *reinterpret_cast<f32x4*>(dst) += v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (pc + e < P.cp) dst[e] += v[e];
+      }
+    }
   }
   if (biasP && fr == 0) {   // column sums of dY blocks on the P side: accb[i][jj] <-> n = p0 + wh*64 + 16i + 4fq + jj
 #pragma unroll
@@ -298,6 +333,7 @@ __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, cons
     tbase += grp.p[i].tiles;
   }
   const WbProblem P = grp.p[pi];
+  if (P.splits == 1) return;                              // written by the tile's own workgroup
   const int tile = gt - tbase;
   const int p0 = (tile / P.tiles_q) * 128, q0 = (tile % P.tiles_q) * 192;
   const int t = blockIdx.x * 256 + threadIdx.x;          // 6144 threads per 128 x 192 tile, 4 elements each
@@ -411,6 +447,9 @@ extern "C" int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(wgrad_big_kernel, dim3(blocks), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
   SITK_LAUNCH_CHECK("wgrad_big");
+  bool any_split = false;
+  for (int i = 0; i < count; ++i) any_split |= g.p[i].splits > 1;
+  if (!any_split) return SITK_OK;                          // every tile covered all its tokens and went straight to dW
   hipLaunchKernelGGL(wgrad_big_reduce_kernel, dim3(WB_TILE_ELEMS / 4 / 256, tiles), dim3(256), 0, s, g,
                      reinterpret_cast<const float*>(ws), tiles);
   return check_launch("wgrad_big_reduce");
