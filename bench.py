@@ -5,7 +5,11 @@ of synthetic surfaces already resident in HBM:
     gather (B,40962,4) -> patch embedding -> 12-layer encoder -> head -> MSE -> full backward
     -> [RCCL gradient all-reduce, N > 1] -> fused SGD(momentum 0.9) update
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: either already under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (one rank per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or typed bare -- then this process starts exactly that
+launcher as a CHILD process (before anything touches the GPU), relays its output and exits with its return code.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     : the dominant kernel (by time share in profiles/) timed live with HIP events on the launch
@@ -16,6 +20,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -45,21 +50,30 @@ def step_gflop_per_sample(dim, depth, heads, mlp_dim, P, K, n_classes=1, mpp=Fal
     return (fwd + 2 * (fwd - embed) + embed) / 1e9
 
 
-def cpu_baseline(seconds=15.0):
-    """BASELINE configs[0]: SiT-tiny, 320 patches, B = 4, fp32, MSE, SGD(momentum 0.9) on the host."""
-    import numpy as np
-    from oracle import sit_oracle
+def host_cores():
+    """CPU threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants a 16-CPU share; 256 torch threads on it made the first bench run of round 1 time out inside
+    the CPU baseline before it printed anything)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         pass
-    try:  # cgroup CPU quota (the GPU box exposes 256 logical CPUs but grants a 16-CPU share)
+    try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             cores = max(1, min(cores, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
+    return cores
+
+
+def cpu_baseline(seconds=15.0):
+    """BASELINE configs[0]: SiT-tiny, 320 patches, B = 4, fp32, MSE, SGD(momentum 0.9) on the host.  Bounded: stops after
+    `seconds` (3 timed steps at least) and in any case after 4 x `seconds`."""
+    import numpy as np
+    from oracle import sit_oracle
+    cores = host_cores()
     torch.set_num_threads(cores)
     B = 4
     model = sit_oracle.SiT(**MODELS["tiny"], num_patches=320, num_vertices=153, num_channels=4)
@@ -68,7 +82,8 @@ def cpu_baseline(seconds=15.0):
     x = torch.randn((B, 4, 320, 153), generator=g)
     y = torch.randn((B,), generator=g)
     times = []
-    t_end = time.perf_counter() + seconds
+    t_start = time.perf_counter()
+    t_end = t_start + seconds
     it = 0
     while True:
         t0 = time.perf_counter()
@@ -80,12 +95,23 @@ def cpu_baseline(seconds=15.0):
         if it >= 2:
             times.append(dt)
         it += 1
-        if (time.perf_counter() > t_end and len(times) >= 3) or len(times) >= 200:
+        now = time.perf_counter()
+        if (now > t_end and len(times) >= 3) or len(times) >= 200 or (now > t_start + 4 * seconds and times):
             break
     med = float(np.median(times))
     return {"value": B / med, "unit": "surfaces/s", "cores": cores, "kind": "port",
             "sample": f"oracle/sit_oracle.py SiT-tiny 320x153x4, B=4 fp32 fwd+bwd+SGD, median of {len(times)} steps "
                       f"({med * 1e3:.1f} ms/step), torch {torch.__version__} CPU"}
+
+
+def self_launch_command(n, argv):
+    """`python bench.py --gpus N` typed bare: the one-rank-per-GPU launcher to start as a child process."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -105,12 +131,12 @@ def main():
                     help="process-group backend for N > 1 (gloo: rehearsal of the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(subprocess.call(self_launch_command(args.gpus, sys.argv[1:])))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with python -m torch.distributed.run --nproc-per-node N")
         args.gpus = world
     ndev = torch.cuda.device_count()
     if args.backend == "nccl" and world > 1 and local_rank >= ndev:
@@ -142,6 +168,7 @@ def main():
     mk = MODELS[args.model]
     torch.manual_seed(1234)                       # identical initial weights on every rank
     model = SiT(**mk, num_patches=P, num_vertices=V, num_channels=4, compute_dtype=args.dtype)
+    model.allow_synthetic_table = True            # 1280 patches: synthetic table on synthetic surfaces (said in config.workload)
     if args.task == "mpp":
         model = masked_patch_pretraining(model, mk["dim"], K, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
                                          channels=4, num_vertices=V)
@@ -179,7 +206,7 @@ def main():
         "value": round(value, 1), "unit": "surfaces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"SiT-{args.model} {P} patches x {V} vertices x 4 channels, B={B}/GPU, {args.task}: "
+        "config": {"workload": f"SiT-{args.model} {P} patches{' (synthetic table)' if P == 1280 else ''} x {V} vertices x 4 channels, B={B}/GPU, {args.task}: "
                                f"gather(B,40962,4) + fwd + {'masked MSE' if args.task == 'mpp' else 'MSE'} + bwd + "
                                f"SGD(m=0.9), bf16 MFMA / fp32 accumulate" if args.dtype == "bf16" else
                                f"SiT-{args.model} {P}x{V}x4 B={B}/GPU {args.task} f32 MFMA",

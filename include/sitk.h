@@ -36,7 +36,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 6
+#define SITK_ABI_VERSION 7
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -63,6 +63,14 @@ int sitk_gather_tokens(const float* x_bvc, const uint16_t* table_pv, void* token
 int sitk_gather_tokens_norm(const float* x_bvc, const uint16_t* table_pv, const float* mean, const float* stdv,
                             void* tokens, int B, int n_vertices, int C, int P, int V, int ld, int dtype,
                             sitk_stream_t stream);
+
+/* Batch assembly from a data set that stays resident in HBM (replaces the DataLoader of tools/train.py:97-113 and
+ * the per-step H2D copy of tools/train.py:282-283): batch row b is sample sample_idx[b] of x_all (S, n_vertices, C)
+ * fp32; mean / stdv as above (both null: no normalisation).  targets_all (S, n_targets) fp32 (or null): the labels of
+ * the selected samples are written to target_out (B, n_targets).  Only the B int32 indices move per step.        */
+int sitk_gather_tokens_idx(const float* x_all, const int32_t* sample_idx, const uint16_t* table_pv, const float* mean,
+                           const float* stdv, void* tokens, const float* targets_all, float* target_out, int n_targets,
+                           int B, int n_vertices, int C, int P, int V, int ld, int dtype, sitk_stream_t stream);
 
 /* Drop-in layout of the reference: x_bcpv (B, C, P, V) fp32 (models/sit.py:47-49) -> tokens as above. */
 int sitk_patchify(const float* x_bcpv, void* tokens, int B, int C, int P, int V, int ld, int dtype,
@@ -115,8 +123,11 @@ typedef struct {
 
 int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream);
 
-/* Weight gradient: dW[n][k] += sum_m dY[m][n] X[m][k]   (fp32 accumulate with float atomics
- * across token chunks), optionally db[n] += sum_m dY[m][n].
+/* Weight gradient: dW[n][k] += sum_m dY[m][n] X[m][k], optionally db[n] += sum_m dY[m][n]; fp32 accumulation.
+ * sitk_gemm_wgrad / _group (64 x 64 tiles, any shape): token chunks are summed into dW with float atomics (the result
+ * depends on arrival order in the last bits).  sitk_gemm_wgrad_group_ws on eligible shapes (the encoder's): 128 x 192
+ * tiles, no float atomics -- a tile that covers all tokens is added straight into dW, token-split tiles go through a
+ * slab in the workspace and a fixed-order reduction.
  *   dY (M, N): `dtype` or fp32 (dy_is_f32); X (M, K) `dtype`; row maps as above.               */
 typedef struct {
   int M, N, K;
@@ -243,6 +254,14 @@ int sitk_attention_bwd_proj(const void* qkv, const void* o, const void* dxmid, c
                             const float* lse, float* delta, void* dqkv, int B, int N, int H, int D, float scale,
                             int dtype, sitk_stream_t stream);
 
+/* One kernel of the backward pair by itself (profiling / bench.py's per-kernel roofline rows): phases bit 0 = the
+ * query-side kernel (dQ, delta, and d_o_out when wo_t != NULL), bit 1 = the key-side kernel (dK, dV; needs the delta
+ * -- and d_o_out -- a query-side launch left behind).  wo_t == NULL: d_o_in is the attention output's gradient
+ * (sitk_attention_bwd); else dxmid / wo_t / d_o_out as in sitk_attention_bwd_proj.  phases = 3 equals those calls.   */
+int sitk_attention_bwd_phases(const void* qkv, const void* o, const void* d_o_in, const void* dxmid, const void* wo_t,
+                              void* d_o_out, const float* lse, float* delta, void* dqkv, int B, int N, int H, int D,
+                              float scale, int dtype, int phases, sitk_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole encoder = vit_pytorch.vit.Transformer(dim, depth, heads, dim_head=64, mlp_dim, dropout=0)
  * as constructed at models/sit.py:57 and called at models/sit.py:76 / models/mpp.py:128:
@@ -325,6 +344,10 @@ int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b,
 
 /* column sums: out[c] += sum_r in[r][c]  (d_pos_embedding / d_cls_token over the batch) */
 int sitk_colsum_f32(const float* in, int64_t rows, int cols, int ld, float* out, sitk_stream_t stream);
+/* the same, with the first cols2 sums also added to out2 (models/sit.py:70-73: d cls_token = the token-0 part of
+ * d pos_embedding) */
+int sitk_colsum_f32_dup(const float* in, int64_t rows, int cols, int ld, float* out, float* out2, int cols2,
+                        sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Masked patch pre-training, models/mpp.py:85-112 and :132.
@@ -350,6 +373,20 @@ int sitk_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t 
 int sitk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, int step,
                    float grad_scale, sitk_stream_t stream);
+
+/* The same optimizers with their step-dependent scalars in DEVICE memory, so that a captured hipGraph follows the
+ * learning-rate schedulers of tools/pretrain.py:42-50 (StepLR, ReduceLROnPlateau, warm-up) and Adam's step count
+ * (tools/train.py:228-241): state = 4 doubles {lr, beta1^t, beta2^t, t}; the caller initialises {lr, 1, 1, 0} and rewrites
+ * state[0] to change the learning rate.  sitk_adam_step_dev advances t and the two powers before it uses them.
+ * zero_grad = 1 folds the next step's optimizer.zero_grad() (tools/train.py:288) into this pass: every consumed gradient
+ * and the n_extra accumulator floats stored behind them (grad + n) are overwritten with zeros; the accumulator with
+ * index keep_idx (the step's loss; < 0: none) is copied to keep_dst first.                                              */
+int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state, float momentum,
+                      float weight_decay, int nesterov, float grad_scale, int zero_grad, int64_t n_extra,
+                      int64_t keep_idx, float* keep_dst, sitk_stream_t stream);
+int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double* state,
+                       float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, float grad_scale,
+                       int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst, sitk_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -765,13 +765,17 @@ static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, fl
 
 static bool bwd_proj_supported(int N, int D, int dtype) { return dtype == SITK_BF16 && N <= RES_MAX_N && D == FOLD_D; }
 
+// phases: bit 0 = the query-side kernel (dQ, delta[, dO]), bit 1 = the key-side kernel (dK, dV); 3 = the whole backward.
+// (Single phases exist so that a profiler / bench.py can time each kernel of the pair by itself.)
 static int run_bwd_proj(const void* qkv, const void* o, const void* dxmid, const void* wo_t, void* d_o, const float* lse,
-                        float* delta, void* dqkv, int B, int N, int H, float scale, hipStream_t s) {
+                        float* delta, void* dqkv, int B, int N, int H, float scale, hipStream_t s, int phases = 3) {
+  if (phases & 1)
   hipLaunchKernelGGL((attn_bwd_dq_res_kernel<16, true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
                      reinterpret_cast<const bf16*>(o), (const bf16*)nullptr, lse, delta, reinterpret_cast<bf16*>(dqkv), N, H,
                      scale, reinterpret_cast<const bf16*>(dxmid), reinterpret_cast<const bf16*>(wo_t),
                      reinterpret_cast<bf16*>(d_o));
   SITK_LAUNCH_CHECK("attention_bwd_proj_dq_res");
+  if (phases & 2)
   hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
                      reinterpret_cast<const bf16*>(d_o), lse, delta, reinterpret_cast<bf16*>(dqkv), N, H, scale);
   return check_launch("attention_bwd_dkv_res");
@@ -779,23 +783,27 @@ static int run_bwd_proj(const void* qkv, const void* o, const void* dxmid, const
 
 template <typename T>
 static int run_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta, void* dqkv,
-                   int B, int N, int H, float scale, hipStream_t s) {
+                   int B, int N, int H, float scale, hipStream_t s, int phases = 3) {
   if constexpr (sizeof(T) == 2) {
     if (N <= RES_MAX_N) {
+      if (phases & 1)
       hipLaunchKernelGGL(attn_bwd_dq_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
                          reinterpret_cast<const bf16*>(o), reinterpret_cast<const bf16*>(d_o), lse, delta,
                          reinterpret_cast<bf16*>(dqkv), N, H, scale);
       SITK_LAUNCH_CHECK("attention_bwd_dq_res");
+      if (phases & 2)
       hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
                          reinterpret_cast<const bf16*>(d_o), lse, delta, reinterpret_cast<bf16*>(dqkv), N, H, scale);
       return check_launch("attention_bwd_dkv_res");
     }
   }
   dim3 grid(cdiv(N, 64) * H * B);
+  if (phases & 1)
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
                      reinterpret_cast<const T*>(o), reinterpret_cast<const T*>(d_o), lse, delta,
                      reinterpret_cast<T*>(dqkv), N, H, scale);
   SITK_LAUNCH_CHECK("attention_bwd_dq");
+  if (phases & 2)
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<T>), grid, dim3(256), 0, s, reinterpret_cast<const T*>(qkv),
                      reinterpret_cast<const T*>(d_o), lse, delta, reinterpret_cast<T*>(dqkv), N, H, scale);
   return check_launch("attention_bwd_dkv");
@@ -838,4 +846,22 @@ extern "C" int sitk_attention_bwd_proj(const void* qkv, const void* o, const voi
   SITK_REQUIRE(bwd_proj_supported(N, D, dtype), "attention_bwd_proj: unsupported N=%d D=%d dtype=%d (bf16, N <= %d, D == %d)", N,
                D, dtype, RES_MAX_N, FOLD_D);
   return run_bwd_proj(qkv, o, dxmid, wo_t, d_o, lse, delta, dqkv, B, N, H, scale, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int sitk_attention_bwd_phases(const void* qkv, const void* o, const void* d_o_in, const void* dxmid, const void* wo_t,
+                                         void* d_o_out, const float* lse, float* delta, void* dqkv, int B, int N, int H, int D,
+                                         float scale, int dtype, int phases, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(qkv && o && lse && delta && dqkv && phases >= 1 && phases <= 3, "attention_bwd_phases: bad arguments");
+  SITK_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attention_bwd_phases: bad shape B=%d N=%d H=%d", B, N, H);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (wo_t) {
+    SITK_REQUIRE(dxmid && d_o_out && bwd_proj_supported(N, D, dtype), "attention_bwd_phases: projection fold unsupported here");
+    return run_bwd_proj(qkv, o, dxmid, wo_t, d_o_out, lse, delta, dqkv, B, N, H, scale, s, phases);
+  }
+  SITK_REQUIRE(d_o_in, "attention_bwd_phases: null d_o");
+  if (dtype == SITK_BF16) return run_bwd<bf16>(qkv, o, d_o_in, lse, delta, dqkv, B, N, H, scale, s, phases);
+  if (dtype == SITK_F32) return run_bwd<float>(qkv, o, d_o_in, lse, delta, dqkv, B, N, H, scale, s, phases);
+  set_error("attention_bwd_phases: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
 }

@@ -1,7 +1,10 @@
 // sitk encoder: the whole vit_pytorch.vit.Transformer (models/sit.py:57,76; models/mpp.py:128) as
 // one host call per direction.  The host side only sequences kernel launches on the caller's stream
-// (no allocation, no sync): 7 launches per layer forward, 13 backward, plus one weight-staging
-// launch per 12 layers.
+// (no allocation, no sync).  Launches: one weight-staging launch per 12 layers; per layer forward 2 with the fused
+// kernels (attention; to_out + norm + MLP + next block's norm + to_qkv) and 7 on the generic path (norm, to_qkv,
+// attention, to_out, norm, net.0, net.3); per layer backward 4 fused (MLP backward, attention query side + key side,
+// to_qkv backward + norm) and 9 generic, plus ONE weight-gradient launch and ONE LayerNorm-gradient reduction per
+// backward slice.
 #include <algorithm>
 #include <cstdlib>
 #include <vector>

@@ -15,7 +15,16 @@ namespace sitk {
 template <typename T>
 __global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restrict__ x, const uint16_t* __restrict__ table,
                                                             T* __restrict__ tokens, int64_t rows, int n_vertices, int P, int V, int ld,
-                                                            const float* __restrict__ mean, const float* __restrict__ stdv) {
+                                                            const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                            const int32_t* __restrict__ sample_idx = nullptr,
+                                                            const float* __restrict__ targets_all = nullptr,
+                                                            float* __restrict__ target_out = nullptr, int n_targets = 0) {
+  // resident data set (tools/train.py:97-113,282): batch row b is sample sample_idx[b] of x; its n_targets labels ride along
+  if (targets_all && blockIdx.x == 0 && blockIdx.y == 0) {
+    const int64_t B = rows / P;
+    for (int64_t i = threadIdx.x; i < B * n_targets; i += 256)
+      target_out[i] = targets_all[(int64_t)sample_idx[i / n_targets] * n_targets + i % n_targets];
+  }
   const int slots = ld >> 2;  // 4-element slots per token row, the first V carry data, the rest zero pad
   // optional per-channel normalisation (x - mean[c]) / std[c]  (tools/preprocessing.py:72); a true division
   // so that the result is bit-identical to the reference's numpy expression evaluated in fp32
@@ -24,7 +33,7 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restr
   const f32x4 sd = norm ? load4(stdv) : f32x4{1.f, 1.f, 1.f, 1.f};
   for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {  // row = b * P + p
     const int p = (int)(row % P);
-    const int64_t b = row / P;
+    const int64_t b = sample_idx ? (int64_t)sample_idx[row / P] : row / P;
     for (int v = blockIdx.x * 256 + threadIdx.x; v < slots; v += gridDim.x * 256) {
       f32x4 val = {0.f, 0.f, 0.f, 0.f};
       if (v < V) {
@@ -102,11 +111,12 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 
 template <typename T>
 static int run_gather(const float* x, const uint16_t* table, void* tokens, int B, int nv, int P, int V, int ld,
-                      const float* mean, const float* stdv, hipStream_t s) {
+                      const float* mean, const float* stdv, hipStream_t s, const int32_t* sample_idx = nullptr,
+                      const float* targets_all = nullptr, float* target_out = nullptr, int n_targets = 0) {
   const int64_t rows = (int64_t)B * P;
   dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
   hipLaunchKernelGGL((gather_tokens_kernel<T>), grid, dim3(256), 0, s, x, table, reinterpret_cast<T*>(tokens), rows, nv, P, V, ld,
-                     mean, stdv);
+                     mean, stdv, sample_idx, targets_all, target_out, n_targets);
   return check_launch("gather_tokens");
 }
 
@@ -164,6 +174,27 @@ extern "C" int sitk_gather_tokens_norm(const float* x_bvc, const uint16_t* table
   if (dtype == SITK_BF16) return run_gather<bf16>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
   if (dtype == SITK_F32) return run_gather<float>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
   set_error("gather_tokens: bad dtype %d", dtype);
+  return SITK_ERR_INVALID;
+}
+
+extern "C" int sitk_gather_tokens_idx(const float* x_all, const int32_t* sample_idx, const uint16_t* table_pv, const float* mean,
+                                      const float* stdv, void* tokens, const float* targets_all, float* target_out,
+                                      int n_targets, int B, int n_vertices, int C, int P, int V, int ld, int dtype,
+                                      sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x_all && sample_idx && table_pv && tokens, "gather_tokens_idx: null pointer");
+  SITK_REQUIRE((mean == nullptr) == (stdv == nullptr), "gather_tokens_idx: mean and std go together");
+  SITK_REQUIRE((targets_all == nullptr) == (target_out == nullptr) && (!targets_all || n_targets > 0),
+               "gather_tokens_idx: targets_all, target_out and n_targets go together");
+  SITK_REQUIRE(C == 4, "gather_tokens_idx: channels-last gather is specialised for num_channels == 4 (got %d)", C);
+  SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "gather_tokens_idx: bad shape");
+  SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "gather_tokens_idx: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16)
+    return run_gather<bf16>(x_all, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
+  if (dtype == SITK_F32)
+    return run_gather<float>(x_all, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
+  set_error("gather_tokens_idx: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
 template <typename TI>
 __global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ in, int ld, const uint8_t* __restrict__ fa,
                                                      const uint8_t* __restrict__ fb, int64_t rows, int cols,
-                                                     int64_t rows_per_block, float* __restrict__ out) {
+                                                     int64_t rows_per_block, float* __restrict__ out,
+                                                     float* __restrict__ out2 = nullptr, int cols2 = 0) {
   // thread -> 4 consecutive columns; grid.x covers column groups of 1024, grid.y covers row blocks
   const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (c4 >= cols) return;
@@ -191,16 +192,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ in, 
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out + c4 + e, s[e]);
+  if (out2 && c4 < cols2) {      // the first cols2 sums once more (d cls_token = d pos_embedding[0])
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out2 + c4 + e, s[e]);
+  }
 }
 
 template <typename TI>
 static int launch_colsum(const TI* in, int ld, const uint8_t* fa, const uint8_t* fb, int64_t rows, int cols,
-                         float* out, hipStream_t s) {
+                         float* out, hipStream_t s, float* out2 = nullptr, int cols2 = 0) {
   const int gx = cdiv(cols, 1024);
   int64_t gy = std::max<int64_t>(1, std::min<int64_t>(cdiv64(rows, 8), 2048 / gx));
   const int64_t rpb = cdiv64(rows, gy);
   gy = cdiv64(rows, rpb);
-  hipLaunchKernelGGL((colsum_kernel<TI>), dim3(gx, (unsigned)gy), dim3(256), 0, s, in, ld, fa, fb, rows, cols, rpb, out);
+  hipLaunchKernelGGL((colsum_kernel<TI>), dim3(gx, (unsigned)gy), dim3(256), 0, s, in, ld, fa, fb, rows, cols, rpb, out, out2, cols2);
   return check_launch("colsum");
 }
 
@@ -349,6 +354,14 @@ extern "C" int sitk_colsum_f32(const float* in, int64_t rows, int cols, int ld, 
   using namespace sitk;
   SITK_REQUIRE(in && out && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, "colsum: bad arguments");
   return launch_colsum<float>(in, ld, nullptr, nullptr, rows, cols, out, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int sitk_colsum_f32_dup(const float* in, int64_t rows, int cols, int ld, float* out, float* out2, int cols2,
+                                   sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(in && out && out2 && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0 && cols2 > 0 && cols2 % 4 == 0 &&
+               cols2 <= cols, "colsum_dup: bad arguments");
+  return launch_colsum<float>(in, ld, nullptr, nullptr, rows, cols, out, reinterpret_cast<hipStream_t>(stream), out2, cols2);
 }
 
 extern "C" int sitk_masked_colsum(const void* in, int ld, int in_is_f32, int dtype, const uint8_t* flag_a,

@@ -80,11 +80,20 @@ class TrainEngine:
 
     input_layout: 'surface' -> step(x) takes raw channels-last surfaces (B, 40962, C) and gathers the
                   patches on the GPU; 'patched' -> the reference's (B, C, P, V) layout.
+    normalise:    (mean, std) per channel -> (x - mean) / std fused into the gather (tools/preprocessing.py:72);
+                  surface layout only.
+    keep_grads:   True -> the parameters' .grad still hold this step's gradients after step() (the buffers are then
+                  zeroed by a fill at the start of the next step); False (default) -> the optimizer pass zeroes every
+                  gradient it consumes (optimizer.zero_grad() of tools/train.py:288 folded into optimizer.step()).
+
+    The learning rate (and Adam's step count) live in device memory: `set_lr()` takes effect in captured graphs too,
+    so the schedulers of tools/pretrain.py:42-50 can drive the engine.  `load_dataset()` keeps a whole data set
+    resident in HBM; `step(indices=...)` then assembles the batch on the GPU (tools/train.py:97-113,282).
     """
 
     def __init__(self, model, batch_size, *, task="regression", input_layout="surface", loss="mse", optimizer="sgd",
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None, bwd_slices=None, use_graph=True, device=None):
+                 process_group=None, bwd_slices=None, use_graph=True, device=None, normalise=None, keep_grads=False):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -107,6 +116,18 @@ class TrainEngine:
             raise rt.SitkError("TrainEngine: dropout > 0 is not implemented on the fused path")
         self.depth = tr.depth
         self.opt = dict(kind=optimizer, lr=lr, momentum=momentum, wd=weight_decay, nesterov=nesterov, betas=betas, eps=eps)
+        self.keep_grads = keep_grads
+        # {lr, beta1^t, beta2^t, t} in device memory: read by the optimizer kernels, so captured graphs follow set_lr()
+        self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
+        self.norm = None
+        if normalise is not None:
+            if input_layout != "surface":
+                raise rt.SitkError("TrainEngine: normalise= needs input_layout='surface' (it is fused into the gather)")
+            mean, std = (torch.as_tensor(t, dtype=torch.float32).reshape(-1).to(self.device) for t in normalise)
+            assert mean.numel() == self.Cc and std.numel() == self.Cc
+            self.norm = (mean.contiguous(), std.contiguous())
+        self.dataset = None                              # (x_all, targets_all) resident in HBM, see load_dataset()
+        self.idx = torch.zeros((batch_size,), dtype=torch.int32, device=self.device)
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self.nsteps = 0
@@ -129,7 +150,9 @@ class TrainEngine:
         self.dW_embed = self.fp.extra((D, ld))          # per-step accumulators live behind the gradients: one fill zeroes all
         self.dx_c = torch.empty((B * N, D), dtype=self.tdt, device=dev)     # compute-dtype d(x_0) for the embedding's dW
         self._embed_wgrad_done = False
-        self.loss = self.fp.extra((1,))
+        self.loss_acc = self.fp.extra((1,))             # accumulated by the loss kernels; zeroed with the gradients
+        self.loss = torch.zeros((1,), dtype=f32, device=dev) if not keep_grads else self.loss_acc
+        self._loss_extra_idx = (self.loss_acc.data_ptr() - self.fp.grad_all.data_ptr()) // 4 - self.fp.total
         if task == "regression":
             self.target = torch.zeros((B, self.ncls), dtype=f32, device=dev)
             self.logits = torch.empty((B, self.ncls), dtype=f32, device=dev)
@@ -152,7 +175,6 @@ class TrainEngine:
             self.state = [torch.zeros_like(self.fp.flat)] if momentum != 0 else [None]
         elif optimizer in ("adam", "adamw"):
             self.state = [torch.zeros_like(self.fp.flat), torch.zeros_like(self.fp.flat)]
-            use_graph = False  # bias correction is a host scalar that changes every step
         else:
             raise ValueError(optimizer)
 
@@ -175,10 +197,10 @@ class TrainEngine:
         sit, L, s = self.sit, rt.lib, self._s()
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
         lin = sit.to_patch_embedding[1]
-        self.fp.grad_all.zero_()                        # gradients + loss + padded embedding gradient
+        if self.keep_grads:
+            self.fp.grad_all.zero_()                    # gradients + loss + padded embedding gradient
         if self.layout == "surface":
-            rt.check(L.sitk_gather_tokens(self.inp.data_ptr(), self.table.data_ptr(), self.tokens.data_ptr(), B, 40962,
-                                          self.Cc, P, self.V, ld, dt, s))
+            self._gather(self.tokens, ld, dt)
         else:
             rt.check(L.sitk_patchify(self.inp.data_ptr(), self.tokens.data_ptr(), B, self.Cc, P, self.V, ld, dt, s))
         self._embed_forward(self.tokens)
@@ -188,9 +210,28 @@ class TrainEngine:
         # pool + head + loss + their backward: one launch (dx = d(loss)/d(x_L) for every row comes out of it)
         rt.check(L.sitk_head_loss_fwd_bwd(self.xL.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), fc.weight.data_ptr(),
                                           fc.bias.data_ptr(), self.target.data_ptr(), self.logits.data_ptr(),
-                                          self.loss.data_ptr(), self.dx.data_ptr(), g(ln.weight).data_ptr(),
+                                          self.loss_acc.data_ptr(), self.dx.data_ptr(), g(ln.weight).data_ptr(),
                                           g(ln.bias).data_ptr(), g(fc.weight).data_ptr(), g(fc.bias).data_ptr(), B, N, D,
                                           self.ncls, self.pool_mean, int(self.loss_kind == "l1"), s))
+
+    def _gather(self, out, ld, dt):
+        """patch gather of the batch: from the static input buffer, or -- after load_dataset() -- straight from the resident
+        data set through the step's sample indices (their labels ride along); per-channel normalisation fused if set."""
+        L, s = rt.lib, self._s()
+        mean, std = (self.norm[0].data_ptr(), self.norm[1].data_ptr()) if self.norm else (None, None)
+        if self.dataset is not None:
+            x_all, t_all = self.dataset
+            tgt = self.task == "regression" and t_all is not None
+            rt.check(L.sitk_gather_tokens_idx(x_all.data_ptr(), self.idx.data_ptr(), self.table.data_ptr(), mean, std,
+                                              out.data_ptr(), t_all.data_ptr() if tgt else None,
+                                              self.target.data_ptr() if tgt else None, self.ncls if tgt else 0, self.B, 40962,
+                                              self.Cc, self.P, self.V, ld, dt, s))
+        elif self.norm:
+            rt.check(L.sitk_gather_tokens_norm(self.inp.data_ptr(), self.table.data_ptr(), mean, std, out.data_ptr(), self.B,
+                                               40962, self.Cc, self.P, self.V, ld, dt, s))
+        else:
+            rt.check(L.sitk_gather_tokens(self.inp.data_ptr(), self.table.data_ptr(), out.data_ptr(), self.B, 40962, self.Cc,
+                                          self.P, self.V, ld, dt, s))
 
     def _embed_forward(self, tokens):
         sit, L, s = self.sit, rt.lib, self._s()
@@ -211,16 +252,16 @@ class TrainEngine:
             ops.gemm_wgrad(self.dx, tokens, self.dW_embed, dt, db=g(lin.bias), M=B * P, N=D, K=ld, dymap=(P, N, 1))
         g(lin.weight).copy_(self.dW_embed[:, :K])
         gpos = g(sit.pos_embedding).view(-1)[:N * D]
-        ops.colsum_f32(self.dx.view(B, N * D), gpos)
-        g(sit.cls_token).view(-1).copy_(gpos[:D])
+        rt.check(rt.lib.sitk_colsum_f32_dup(self.dx.data_ptr(), B, N * D, N * D, gpos.data_ptr(),
+                                            g(sit.cls_token).data_ptr(), D, self._s()))
 
     def _forward_mpp(self):
         ssl, sit, L, s = self.ssl, self.sit, rt.lib, self._s()
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
-        self.fp.grad_all.zero_()                        # gradients + loss + padded embedding gradient + rsum
+        if self.keep_grads:
+            self.fp.grad_all.zero_()                    # gradients + loss + padded embedding gradient + rsum
         if self.layout == "surface":
-            rt.check(L.sitk_gather_tokens(self.inp.data_ptr(), self.table.data_ptr(), self.tok32.data_ptr(), B, 40962,
-                                          self.Cc, P, self.V, K, rt.F32, s))
+            self._gather(self.tok32, K, rt.F32)
         else:
             rt.check(L.sitk_patchify(self.inp.data_ptr(), self.tok32.data_ptr(), B, self.Cc, P, self.V, K, rt.F32, s))
         # on-device draws (statistically equivalent to models/mpp.py:25-43; the parity path replays
@@ -250,7 +291,7 @@ class TrainEngine:
                                      self.wo_t.shape[1], dt, s))
         ops.gemm_nt(self.xL, self.wo_c, self.out, dt, M=B * P, N=K, K=D, bias=lo.bias.data, amap=(P, N, 1))
         rt.check(L.sitk_mpp_loss_fwd_bwd(self.out.data_ptr(), self.tok32.data_ptr(), self.masked.data_ptr(),
-                                         self.loss.data_ptr(), self.dout.data_ptr(), B * P, K, B * self.n_mask, s))
+                                         self.loss_acc.data_ptr(), self.dout.data_ptr(), B * P, K, B * self.n_mask, s))
         g = self.fp.g
         # d to_original: X = encoder output rows 1..P (fp32 -> compute dtype copy)
         rt.check(L.sitk_cast_rows(self.xL.data_ptr() + 4 * D, N * D, self.enc_out.data_ptr(), P * D, B, P * D, dt, s))
@@ -279,14 +320,26 @@ class TrainEngine:
             ops.gemm_nt(self.rsum, self.we_t, self.dmt, dt, M=1, N=K, K=D)
             self.fp.g(ssl.mask_token).view(-1).copy_(self.dmt.view(-1))
 
+    def set_lr(self, lr):
+        """New learning rate from the next step on (a device-side write: captured graphs read it from memory)."""
+        self.opt["lr"] = float(lr)
+        self.hyper[0:1].fill_(float(lr))
+
     def _optimizer(self):
-        o, fp = self.opt, self.fp
+        o, fp, L, s = self.opt, self.fp, rt.lib, self._s()
         scale = 1.0 / self.world
+        zero = int(not self.keep_grads)
+        n_extra = fp.grad_all.numel() - fp.total if zero else 0
+        keep_dst = self.loss.data_ptr() if zero else None
         if o["kind"] == "sgd":
-            ops.sgd_step(fp.flat, fp.grad, self.state[0], o["lr"], o["momentum"], o["wd"], o["nesterov"], scale)
+            rt.check(L.sitk_sgd_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), rt.ptr(self.state[0]), fp.total,
+                                         self.hyper.data_ptr(), o["momentum"], o["wd"], int(o["nesterov"]), scale, zero,
+                                         n_extra, self._loss_extra_idx, keep_dst, s))
         else:
-            ops.adam_step(fp.flat, fp.grad, self.state[0], self.state[1], o["lr"], o["betas"][0], o["betas"][1], o["eps"],
-                          o["wd"], o["kind"] == "adamw", self.nsteps + 1, scale)
+            rt.check(L.sitk_adam_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), self.state[0].data_ptr(),
+                                          self.state[1].data_ptr(), fp.total, self.hyper.data_ptr(), o["betas"][0],
+                                          o["betas"][1], o["eps"], o["wd"], int(o["kind"] == "adamw"), scale, zero, n_extra,
+                                          self._loss_extra_idx, keep_dst, s))
 
     # ---- segments: [fwd + loss + head/backward slice 0], [slice 1], ..., [finish + optimizer] ------------
     def _segment_fns(self):
@@ -338,10 +391,31 @@ class TrainEngine:
         if target is not None:
             self.target.copy_(target.reshape(self.target.shape), non_blocking=True)
 
-    def step(self, x=None, target=None):
-        """Runs one optimisation step on the batch in the static input buffers (or on x/target if
-        given).  Returns the device tensor holding the loss of this step (no host sync)."""
-        if x is not None:
+    def load_dataset(self, x_all, targets_all=None):
+        """Keep a whole data set resident in HBM: x_all (S, 40962, C) fp32 raw (un-normalised if `normalise` was given)
+        surfaces, targets_all (S, n_classes) labels.  From then on step(indices=...) selects the batch by index inside
+        the gather kernel; per step only the B int32 indices cross PCIe (tools/train.py:97-113,282-283 move the data)."""
+        if self.layout != "surface":
+            raise rt.SitkError("load_dataset: needs input_layout='surface'")
+        x_all = torch.as_tensor(x_all, dtype=torch.float32).to(self.device).contiguous()
+        if x_all.dim() != 3 or x_all.shape[1] != 40962 or x_all.shape[2] != self.Cc:
+            raise rt.SitkError(f"load_dataset: expected (S, 40962, {self.Cc}), got {tuple(x_all.shape)}")
+        t_all = None
+        if targets_all is not None:
+            t_all = torch.as_tensor(targets_all, dtype=torch.float32).to(self.device).reshape(x_all.shape[0], -1).contiguous()
+            assert self.task != "regression" or t_all.shape[1] == self.ncls
+        self.dataset = (x_all, t_all)
+        self._graphs = None                               # the gather node changes: capture again
+
+    def step(self, x=None, target=None, indices=None):
+        """Runs one optimisation step on the batch in the static input buffers (or on x/target if given; or on the
+        samples `indices` (B,) of the resident data set).  Returns the device tensor holding the loss of this step
+        (no host sync)."""
+        if indices is not None:
+            if self.dataset is None:
+                raise rt.SitkError("step(indices=...) needs load_dataset() first")
+            self.idx.copy_(torch.as_tensor(indices, dtype=torch.int32).reshape(-1), non_blocking=True)
+        elif x is not None:
             self.load_batch(x, target)
         segs = self._segment_fns()
         for i, fn in enumerate(segs):

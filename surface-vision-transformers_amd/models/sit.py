@@ -129,6 +129,7 @@ class SiT(nn.Module):
         self.to_latent = nn.Identity()
         self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))
         self._table = None           # numpy (P, V) uint16
+        self.allow_synthetic_table = False   # True: the built-in synthetic 1280 x 45 table loads without a warning
         self._table_dev = {}
 
     # ---- patch table for the raw-surface entry ---------------------------------------------------
@@ -139,7 +140,7 @@ class SiT(nn.Module):
 
     def patch_table(self, device):
         if self._table is None:
-            self._table = tables.load_table(self.num_patches, self.num_vertices)
+            self._table = tables.load_table(self.num_patches, self.num_vertices, allow_synthetic=self.allow_synthetic_table)
         key = str(device)
         if key not in self._table_dev:
             self._table_dev[key] = tables.table_tensor(self._table, device)

@@ -1,29 +1,37 @@
 """Per-kernel timing of the hot path at the live workload's shapes (bench.py's `roofline` object).
 
-Every kernel family of one encoder layer is launched exactly as csrc/encoder.hip launches it (same
-entry point, operand dtypes, epilogue, workspace; the fused LayerNorm+MLP / LayerNorm+to_qkv kernels where
-the shape supports them, the separate kernels otherwise) `reps` times inside a hipGraph, and the replay is
-timed between two HIP events on the replay stream: no host launch gap is included.  The family with
-the largest (average duration x launches per step) is the dominant kernel; its achieved rate =
-algorithmic FLOPs (or bytes) per launch / average duration.  The rocprofv3 --kernel-trace --stats
-summary of the same bench command (profiles/) lists the same kernels by name; an entry that covers two
-kernels (e.g. the weight-gradient kernel and its slab reduction) must equal the sum of their averages.
+Every kernel of one encoder layer is launched exactly as csrc/encoder.hip launches it (same entry point, operand
+dtypes, epilogue, workspace; the fused kernels where the shape supports them, the separate ones otherwise) `reps` times
+inside a hipGraph, and the replay is timed between two HIP events on the replay stream: no host launch gap is included.
+
+Each repetition works on its OWN set of operand and output buffers (one set per layer, as in the real step, where
+every layer's activations are distinct tensors): replaying one launch over the same buffers lets its stores hit lines
+the previous repetition left in the Infinity Cache and reads 20-25 % fast (round 1's table did that).  Rows are single
+kernels (the two kernels of the attention backward are timed one by one through sitk_attention_bwd_phases), so each
+`us` must agree with the same kernel's average in profiles/*step_kernel_stats*.md of the same bench command.
+
+The dominant kernel is the single kernel with the largest (average duration x launches per step).  Its bound is the
+LARGER of its two roofline fractions: algorithmic FLOPs / duration against the dense bf16 MFMA peak, algorithmic bytes
+/ duration against the HBM peak.
 """
 import torch
 
 from . import ops
+from . import runtime as rt
 
 
-def _time(fn, reps):
-    """Average device time of one launch: `reps` launches captured in a hipGraph (so no host launch
-    gap is timed), replayed between two HIP events on the replay stream."""
-    for _ in range(2):
-        fn()
+def _time(fn, nset, reps):
+    """Average device time of one launch: `reps` launches (launch i on buffer set i % nset) captured in a hipGraph,
+    replayed between two HIP events on the replay stream.  Outputs stay alive through the capture so that no two
+    launches share an output buffer through the caching allocator."""
+    for i in range(min(2, nset)):
+        fn(i)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
+    keep = []
     with torch.cuda.graph(graph):
-        for _ in range(reps):
-            fn()
+        for i in range(reps):
+            keep.append(fn(i % nset))
     graph.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,11 +39,36 @@ def _time(fn, reps):
     graph.replay()
     e1.record()
     e1.synchronize()
-    return e0.elapsed_time(e1) / reps * 1e-3   # seconds
+    dt = e0.elapsed_time(e1) / reps * 1e-3   # seconds
+    del keep, graph
+    return dt
 
 
-def layer_kernels(eng):
-    """[(name, rocprof kernel names, fn, flops, algorithmic bytes, launches per step)] for one layer."""
+class _Set:
+    """One layer's worth of operands (random, scaled like activations)."""
+
+    def __init__(self, eng, seed):
+        B, N, D = eng.B, eng.N, eng.D
+        tr = eng.sit.transformer
+        H, M = tr.heads, tr.mlp_dim
+        I, R = H * 64, B * N
+        dev, td, f32 = eng.device, eng.tdt, torch.float32
+        g = torch.Generator(device=dev).manual_seed(seed)
+        rn = lambda *s, dtype=td: (torch.randn(*s, device=dev, generator=g) * 0.5).to(dtype)  # noqa: E731
+        self.h, self.qkv, self.o, self.u, self.gg = rn(R, D), rn(R, 3 * I), rn(R, I), rn(R, M), rn(R, M)
+        self.x32, self.dx32, self.dxc = rn(R, D, dtype=f32), rn(R, D, dtype=f32), rn(R, D)
+        self.wqkv, self.wqkv_t = rn(3 * I, D), rn(D, 3 * I)
+        self.wo, self.wo_t = rn(D, I), rn(I, D)
+        self.w1, self.w1_t, self.w2, self.w2_t = rn(M, D), rn(D, M), rn(D, M), rn(M, D)
+        self.bD, self.bM, self.gam = rn(D, dtype=f32), rn(M, dtype=f32), rn(D, dtype=f32)
+        self.mean, self.rstd = torch.zeros(R, device=dev), torch.ones(R, device=dev)
+        self.o_att, self.lse = ops.attention_fwd(self.qkv, B, N, H, 0.125, eng.dtype)
+        self.delta = torch.zeros_like(self.lse)
+        self.d_o = rn(R, I)
+
+
+def layer_kernels(eng, nset):
+    """[(op, rocprof kernel name, fn(set index), flops, algorithmic bytes, launches per step)] for one layer."""
     B, N, D, dt = eng.B, eng.N, eng.D, eng.dtype
     tr = eng.sit.transformer
     H, M = tr.heads, tr.mlp_dim
@@ -43,121 +76,118 @@ def layer_kernels(eng):
     dev, td = eng.device, eng.tdt
     es = 2 if td == torch.bfloat16 else 4
     L = eng.depth
-    g = torch.Generator(device=dev).manual_seed(7)
-    rn = lambda *s, dtype=td: (torch.randn(*s, device=dev, generator=g) * 0.5).to(dtype)  # noqa: E731
     f32 = torch.float32
-    h, qkv, o, u, gg = rn(R, D), rn(R, 3 * I), rn(R, I), rn(R, M), rn(R, M)
-    x32, dx32, dxc = rn(R, D, dtype=f32), rn(R, D, dtype=f32), rn(R, D)
-    wqkv, wqkv_t = rn(3 * I, D), rn(D, 3 * I)
-    wo, wo_t = rn(D, I), rn(I, D)
-    w1, w1_t, w2, w2_t = rn(M, D), rn(D, M), rn(D, M), rn(M, D)
-    bD, bM = rn(D, dtype=f32), rn(M, dtype=f32)
-    gam = rn(D, dtype=f32)
-    out_qkv, out_o = torch.empty_like(qkv), torch.empty_like(o)
-    out_x, out_xc = torch.empty_like(x32), torch.empty_like(h)
-    out_u, out_g, out_h = torch.empty_like(u), torch.empty_like(u), torch.empty_like(h)
+    S = [_Set(eng, 7 + i) for i in range(nset)]
     dW = {k: torch.zeros(s, dtype=f32, device=dev) for k, s in
           dict(qkv=(3 * I, D), o=(D, I), w1=(M, D), w2=(D, M)).items()}
     dbD, dbD2, dbM = torch.zeros(D, device=dev), torch.zeros(D, device=dev), torch.zeros(M, device=dev)
-    o_att, lse = ops.attention_fwd(qkv, B, N, H, 0.125, dt)
-    mean, rstd = torch.zeros(R, device=dev), torch.ones(R, device=dev)
     part = torch.empty(ops.layernorm_bwd_partial_floats(R, D), device=dev)
-    probs = [dict(dY=dxc, X=gg, dW=dW["w2"], db=dbD), dict(dY=u, X=h, dW=dW["w1"], db=dbM),
-             dict(dY=dxc, X=o, dW=dW["o"], db=dbD2), dict(dY=qkv, X=h, dW=dW["qkv"])]
-    nbytes = ops.rt.lib.sitk_gemm_wgrad_group_ws_bytes(*_desc_array(probs), ops.rt.dtype_code(dt))
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
     att = 4.0 * B * H * N * N * 64
     wg_flops = 2.0 * R * (D * M * 2 + D * I + 3 * I * D)
     mlp_flops = 4.0 * R * D * M
     fused_mlp = ops.mlp_fused_supported(D, M, dt)
     fused_qkv = ops.ln_gemm_fused_supported(D, 3 * I, dt)
-    rows = []
-    # ---- forward ----
-    fused_chain = fused_mlp and fused_qkv and ops.attn_out_mlp_fused_supported(R, D, I, M, dt) and L > 1
-    if fused_qkv:
-        rows.append(("norm + to_qkv (fused)", "ln_gemm_fwd_kernel", lambda: ops.ln_gemm_fwd(x32, gam, bD, wqkv, dt),
-                     2.0 * R * 3 * I * D, R * (4 * D + (D + 3 * I) * es), 1 if fused_chain else L))
-    else:
-        rows.append(("layernorm_fwd", "layernorm_fwd_kernel", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), L))
-        rows.append(("to_qkv", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(h, wqkv, out_qkv, dt), 2.0 * R * 3 * I * D, R * (D + 3 * I) * es, L))
-    rows.append(("attention forward", "attn_fwd_res_kernel", lambda: ops.attention_fwd(qkv, B, N, H, 0.125, dt), att, R * 4 * I * es, L))
     fused_proj = fused_mlp and ops.attn_out_mlp_fused_supported(R, D, I, M, dt)
-    if fused_proj and fused_qkv and L > 1:
+    fused_chain = fused_proj and fused_qkv and L > 1
+    rows = []
+    add = lambda *r: rows.append(r)  # noqa: E731
+
+    def ln_bwd(i):
+        dxc = torch.empty_like(S[i].h)
+        return dxc, ops.layernorm_bwd(S[i].h, S[i].x32, S[i].mean, S[i].rstd, S[i].gam, S[i].dx32, dbD, dbD2, dt,
+                                      dx=torch.empty_like(S[i].x32), dx_c=dxc, partials=part)
+    # ---- forward ----
+    if fused_qkv:
+        add("norm + to_qkv (fused)", "ln_gemm_fwd_kernel", lambda i: ops.ln_gemm_fwd(S[i].x32, S[i].gam, S[i].bD, S[i].wqkv, dt),
+            2.0 * R * 3 * I * D, R * (4 * D + (D + 3 * I) * es), 1 if fused_chain else L)
+    else:
+        add("norm (attention)", "layernorm_fwd_kernel", lambda i: ops.layernorm_fwd(S[i].x32, S[i].gam, S[i].bD, dt), 0, R * D * (4 + es), L)
+        add("to_qkv", "gemm_nt", lambda i: ops.gemm_nt(S[i].h, S[i].wqkv, torch.empty_like(S[i].qkv), dt),
+            2.0 * R * 3 * I * D, R * (D + 3 * I) * es, L)
+    add("attention forward", "attn_fwd", lambda i: ops.attention_fwd(S[i].qkv, B, N, H, 0.125, dt), att, R * 4 * I * es, L)
+    if fused_chain:
         # blocks 0 .. L-2: one launch from the attention output to the next block's qkv; the last block stops at `out`
-        rows.append(("to_out + norm + MLP + residuals + next block's norm + to_qkv (fused)", "mlp_kernel<false, .., NEXT>",
-                     lambda: ops.attn_out_mlp_next_fwd(o, wo, bD, x32, gam, bD, w1, bM, w2, bD, gam, bD, wqkv, dt, want_g=True),
-                     mlp_flops + 2.0 * R * D * I + 2.0 * R * 3 * I * D, R * (I * es + 12 * D + (2 * D + 2 * M + 3 * I) * es), L - 1))
-        rows.append(("to_out + residual + norm + net.0 + GELU + net.3 + residual (fused, last block)", "mlp_kernel<false>",
-                     lambda: ops.attn_out_mlp_fwd(o, wo, bD, x32, gam, bD, w1, bM, w2, bD, dt, want_g=True),
-                     mlp_flops + 2.0 * R * D * I, R * (I * es + 12 * D + (D + 2 * M) * es), 1))
-    elif fused_proj:
-        rows.append(("to_out + residual + norm + net.0 + GELU + net.3 + residual (fused)", "mlp_kernel<false>",
-                     lambda: ops.attn_out_mlp_fwd(o, wo, bD, x32, gam, bD, w1, bM, w2, bD, dt, want_g=True),
-                     mlp_flops + 2.0 * R * D * I, R * (I * es + 12 * D + (D + 2 * M) * es), L))
-    else:
-        rows.append(("to_out + residual", "gemm_nt_wres_kernel",
-                     lambda: ops.gemm_nt(o, wo, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * I, R * (I * es + 8 * D), L))
+        add("to_out + norm + MLP + residuals + next block's norm + to_qkv (fused)", "mlp_kernel<false, .., NEXT>",
+            lambda i: ops.attn_out_mlp_next_fwd(S[i].o, S[i].wo, S[i].bD, S[i].x32, S[i].gam, S[i].bD, S[i].w1, S[i].bM, S[i].w2,
+                                                S[i].bD, S[i].gam, S[i].bD, S[i].wqkv, dt, want_g=True),
+            mlp_flops + 2.0 * R * D * I + 2.0 * R * 3 * I * D, R * (I * es + 12 * D + (2 * D + 2 * M + 3 * I) * es), L - 1)
     if fused_proj:
-        pass
-    elif fused_mlp:
-        rows.append(("norm + net.0 + GELU + net.3 + residual (fused)", "mlp_kernel<false>",
-                     lambda: ops.mlp_fwd(x32, gam, bD, w1, bM, w2, bD, dt, want_g=True), mlp_flops,
-                     R * (8 * D + (D + 2 * M) * es), L))
+        add("to_out + residual + norm + net.0 + GELU + net.3 + residual (fused)", "mlp_kernel<false, .., PROJ>",
+            lambda i: ops.attn_out_mlp_fwd(S[i].o, S[i].wo, S[i].bD, S[i].x32, S[i].gam, S[i].bD, S[i].w1, S[i].bM, S[i].w2, S[i].bD,
+                                           dt, want_g=True),
+            mlp_flops + 2.0 * R * D * I, R * (I * es + 12 * D + (D + 2 * M) * es), 1 if fused_chain else L)
     else:
-        rows.append(("layernorm_fwd (2)", "layernorm_fwd_kernel", lambda: ops.layernorm_fwd(x32, gam, bD, dt), 0, R * D * (4 + es), L))
-        rows.append(("net.0 + GELU", "gemm_nt_wres_kernel",
-                     lambda: ops.gemm_nt(h, w1, out_u, dt, epilogue=ops.EPI_BIAS_GELU, bias=bM, out2=out_g), 2.0 * R * M * D, R * (D + 2 * M) * es, L))
-        rows.append(("net.3 + residual", "gemm_nt_n192_kernel",
-                     lambda: ops.gemm_nt(gg, w2, out_x, dt, epilogue=ops.EPI_BIAS_RES, bias=bD, aux=x32), 2.0 * R * D * M, R * (M * es + 8 * D), L))
+        add("to_out + residual", "gemm_nt", lambda i: ops.gemm_nt(S[i].o, S[i].wo, torch.empty_like(S[i].x32), dt,
+                                                                   epilogue=ops.EPI_BIAS_RES, bias=S[i].bD, aux=S[i].x32),
+            2.0 * R * D * I, R * (I * es + 8 * D), L)
+        if fused_mlp:
+            add("norm + net.0 + GELU + net.3 + residual (fused)", "mlp_kernel<false>",
+                lambda i: ops.mlp_fwd(S[i].x32, S[i].gam, S[i].bD, S[i].w1, S[i].bM, S[i].w2, S[i].bD, dt, want_g=True), mlp_flops,
+                R * (8 * D + (D + 2 * M) * es), L)
+        else:
+            add("norm (MLP)", "layernorm_fwd_kernel", lambda i: ops.layernorm_fwd(S[i].x32, S[i].gam, S[i].bD, dt), 0, R * D * (4 + es), L)
+            def fc1(i):
+                o2 = torch.empty_like(S[i].u)
+                return o2, ops.gemm_nt(S[i].h, S[i].w1, torch.empty_like(S[i].u), dt, epilogue=ops.EPI_BIAS_GELU, bias=S[i].bM, out2=o2)
+            add("net.0 + GELU", "gemm_nt", fc1, 2.0 * R * M * D, R * (D + 2 * M) * es, L)
+            add("net.3 + residual", "gemm_nt", lambda i: ops.gemm_nt(S[i].gg, S[i].w2, torch.empty_like(S[i].x32), dt,
+                                                                      epilogue=ops.EPI_BIAS_RES, bias=S[i].bD, aux=S[i].x32),
+                2.0 * R * D * M, R * (M * es + 8 * D), L)
     # ---- backward ----
     if fused_mlp:
-        rows.append(("d net.3 x GELU' + d net.0 + norm backward (fused)", "mlp_kernel<true>",
-                     lambda: ops.mlp_bwd(dx32, dxc, x32, mean, rstd, gam, w2_t, w1_t, u, dt, want_g=False), mlp_flops,
-                     R * (D * es + 2 * M * es + 12 * D + D * es), L))
+        add("d net.3 x GELU' + d net.0 + norm backward (fused)", "mlp_kernel<true>",
+            lambda i: ops.mlp_bwd(S[i].dx32, S[i].dxc, S[i].x32, S[i].mean, S[i].rstd, S[i].gam, S[i].w2_t, S[i].w1_t, S[i].u, dt,
+                                  want_g=False), mlp_flops, R * (D * es + 2 * M * es + 12 * D + D * es), L)
     else:
-        rows.append(("d net.3 (x GELU')", "gemm_nt_wres_kernel",
-                     lambda: ops.gemm_nt(dxc, w2_t, out_u, dt, epilogue=ops.EPI_DGELU, aux=u), 2.0 * R * D * M, R * (D + 2 * M) * es, L))
-        rows.append(("d net.0", "gemm_nt_n192_kernel", lambda: ops.gemm_nt(u, w1_t, out_h, dt), 2.0 * R * D * M, R * (M + D) * es, L))
-        rows.append(("layernorm_bwd (2)", "layernorm_bwd_kernel",
-                     lambda: ops.layernorm_bwd(h, x32, mean, rstd, gam, dx32, dbD, dbD2, dt, dx=out_x, dx_c=out_xc, partials=part),
-                     0, R * D * (2 * es + 12), L))
-    if ops.attention_bwd_proj_supported(N, D, dt):     # d to_out folded into the query-side kernel (csrc/encoder.hip)
-        rows.append(("d to_out + attention backward (fused)", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
-                     lambda: ops.attention_bwd_proj(qkv, o_att, dxc, wo_t, lse, B, N, H, 0.125, dt),
-                     2.5 * att + 2.0 * R * D * I, R * (8 * I + D) * es, L))
-    else:
-        rows.append(("d to_out", "gemm_nt_wres_kernel", lambda: ops.gemm_nt(dxc, wo_t, out_o, dt), 2.0 * R * D * I, R * (D + I) * es, L))
-        rows.append(("attention backward", "attn_bwd_dq_res_kernel + attn_bwd_dkv_res_kernel",
-                     lambda: ops.attention_bwd(qkv, o_att, o, lse, B, N, H, 0.125, dt), 2.5 * att, R * 8 * I * es, L))
+        add("d net.3 (x GELU')", "gemm_nt", lambda i: ops.gemm_nt(S[i].dxc, S[i].w2_t, torch.empty_like(S[i].u), dt, epilogue=ops.EPI_DGELU,
+                                                                   aux=S[i].u), 2.0 * R * D * M, R * (D + 2 * M) * es, L)
+        add("d net.0", "gemm_nt", lambda i: ops.gemm_nt(S[i].u, S[i].w1_t, torch.empty_like(S[i].h), dt), 2.0 * R * D * M, R * (M + D) * es, L)
+        add("norm backward (MLP)", "layernorm_bwd_kernel", ln_bwd, 0, R * D * (2 * es + 12), L)
+    fold = ops.attention_bwd_proj_supported(N, D, dt)     # d to_out folded into the query-side kernel (csrc/encoder.hip)
+    if not fold:
+        add("d to_out", "gemm_nt", lambda i: ops.gemm_nt(S[i].dxc, S[i].wo_t, torch.empty_like(S[i].o), dt), 2.0 * R * D * I, R * (D + I) * es, L)
+
+    def att_bwd(i, phases):
+        s = S[i]
+        dqkv = torch.empty_like(s.qkv)
+        rt.check(rt.lib.sitk_attention_bwd_phases(
+            s.qkv.data_ptr(), s.o_att.data_ptr(), None if fold else s.d_o.data_ptr(), s.dxc.data_ptr() if fold else None,
+            s.wo_t.data_ptr() if fold else None, s.d_o.data_ptr() if fold else None, s.lse.data_ptr(), s.delta.data_ptr(),
+            dqkv.data_ptr(), B, N, H, D, 0.125, dt, phases, rt.stream_ptr()))
+        return dqkv
+    # algorithmic work (backward = 2 x forward = four products): dP and dQ count for the query side, dV and dK
+    # for the key side; both kernels also recompute S (query side executes 3 products + the folded projection, key side 4)
+    add("attention backward, query side (dQ" + (", d to_out folded in)" if fold else ")"), "attn_bwd_dq",
+        lambda i: att_bwd(i, 1), att + (2.0 * R * D * I if fold else 0.0), R * (5 * I + (D if fold else I)) * es, L)
+    add("attention backward, key side (dK, dV)", "attn_bwd_dkv", lambda i: att_bwd(i, 2), att, R * 6 * I * es, L)
     # the weight gradients of a whole backward slice run as one launch (csrc/encoder.hip): all L layers on one GPU
-    if 4 * L <= 48 and nbytes > 0:      # distinct operand tensors per layer, as in the real step (1.4 GB for tiny)
-        probs_all = list(probs)
-        for _ in range(L - 1):
-            u_l, gg_l, h_l, o_l, qkv_l, dxc_l = (t.clone() for t in (u, gg, h, o, qkv, dxc))
-            probs_all += [dict(dY=dxc_l, X=gg_l, dW=dW["w2"], db=dbD), dict(dY=u_l, X=h_l, dW=dW["w1"], db=dbM),
-                          dict(dY=dxc_l, X=o_l, dW=dW["o"], db=dbD2), dict(dY=qkv_l, X=h_l, dW=dW["qkv"])]
-    else:
-        probs_all = probs
-    nl = len(probs_all) // 4
-    nb_all = ops.rt.lib.sitk_gemm_wgrad_group_ws_bytes(*_desc_array(probs_all), ops.rt.dtype_code(dt))
-    ws_all = torch.empty(max(nb_all, nbytes, 16), dtype=torch.uint8, device=dev)
-    rows.append((f"weight gradients of {nl} layer(s), one launch", "wgrad_big_kernel + wgrad_big_reduce_kernel",
-                 lambda: ops.gemm_wgrad_group(probs_all, dt, workspace=ws_all), wg_flops * nl,
-                 nl * R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L // nl))
+    probs = []
+    nl = L if 4 * L <= 48 else 1
+    for l in range(nl):        # distinct operand tensors per layer, as in the real step
+        s = S[l % nset]
+        u_l, gg_l, h_l, o_l, qkv_l, dxc_l = (t if l < nset else t.clone() for t in (s.u, s.gg, s.h, s.o, s.qkv, s.dxc))
+        probs += [dict(dY=dxc_l, X=gg_l, dW=dW["w2"], db=dbD), dict(dY=u_l, X=h_l, dW=dW["w1"], db=dbM),
+                  dict(dY=dxc_l, X=o_l, dW=dW["o"], db=dbD2), dict(dY=qkv_l, X=h_l, dW=dW["qkv"])]
+    nb_all = rt.lib.sitk_gemm_wgrad_group_ws_bytes(*_desc_array(probs), rt.dtype_code(dt))
+    if nb_all == 0 and nl > 1:          # shapes outside the batched large-tile path: one layer per launch
+        probs, nl = probs[:4], 1
+        nb_all = rt.lib.sitk_gemm_wgrad_group_ws_bytes(*_desc_array(probs), rt.dtype_code(dt))
+    ws_all = torch.empty(max(nb_all, 16), dtype=torch.uint8, device=dev)
+    add(f"weight gradients of {nl} layer(s), one launch", "wgrad_big_kernel" if nb_all else "wgrad_kernel",
+        lambda i: ops.gemm_wgrad_group(probs, dt, workspace=ws_all if nb_all else None), wg_flops * nl,
+        nl * R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L // nl)
     if fused_qkv:
-        rows.append(("d to_qkv + norm backward (fused)", "ln_gemm_bwd_kernel",
-                     lambda: ops.ln_gemm_bwd(qkv, wqkv_t, x32, mean, rstd, gam, dx32, dt), 2.0 * R * 3 * I * D,
-                     R * (3 * I * es + 12 * D + D * es), L))
+        add("d to_qkv + norm backward (fused)", "ln_gemm_bwd_kernel",
+            lambda i: ops.ln_gemm_bwd(S[i].qkv, S[i].wqkv_t, S[i].x32, S[i].mean, S[i].rstd, S[i].gam, S[i].dx32, dt),
+            2.0 * R * 3 * I * D, R * (3 * I * es + 12 * D + D * es), L)
     else:
-        rows.append(("d to_qkv", "gemm_nt_n192_kernel", lambda: ops.gemm_nt(qkv, wqkv_t, out_h, dt), 2.0 * R * 3 * I * D, R * (3 * I + D) * es, L))
-        rows.append(("layernorm_bwd", "layernorm_bwd_kernel",
-                     lambda: ops.layernorm_bwd(h, x32, mean, rstd, gam, dx32, dbD, dbD2, dt, dx=out_x, dx_c=out_xc, partials=part),
-                     0, R * D * (2 * es + 12), L))
+        add("d to_qkv", "gemm_nt", lambda i: ops.gemm_nt(S[i].qkv, S[i].wqkv_t, torch.empty_like(S[i].h), dt), 2.0 * R * 3 * I * D,
+            R * (3 * I + D) * es, L)
+        add("norm backward (attention)", "layernorm_bwd_kernel", ln_bwd, 0, R * D * (2 * es + 12), L)
     return rows
 
 
 def _desc_array(problems):
-    from . import runtime as rt
     arr = (rt.WgradDesc * len(problems))()
     for d, p in zip(arr, problems):
         dY, X, dW = p["dY"], p["X"], p["dW"]
@@ -167,19 +197,26 @@ def _desc_array(problems):
     return arr, len(problems)
 
 
-def dominant_kernel_roofline(eng, peak_tflops, peak_gbs, reps=20):
+def dominant_kernel_roofline(eng, peak_tflops, peak_gbs, reps=None):
+    tr = eng.sit.transformer
+    R, D, M, I = eng.B * eng.N, eng.D, tr.mlp_dim, tr.heads * 64
+    per_set = R * (2 * (2 * D + 4 * I + 2 * M + D + I) + 8 * D) * 2.2     # operands + the outputs kept alive, bytes
+    nset = int(max(2, min(eng.depth, 12, 40e9 // per_set)))
+    reps = reps or nset
     rows = []
-    for name, kernels, fn, flops, nbytes, launches in layer_kernels(eng):
-        t = _time(fn, reps)
-        rows.append(dict(op=name, kernels=kernels, us=round(t * 1e6, 2), launches_per_step=launches,
+    for name, kernel, fn, flops, nbytes, launches in layer_kernels(eng, nset):
+        t = _time(fn, nset, reps)
+        rows.append(dict(op=name, kernel=kernel, us=round(t * 1e6, 2), launches_per_step=launches,
                          tflops=round(flops / t / 1e12, 1), gbs=round(nbytes / t / 1e9, 1),
+                         mfma_frac=round(flops / t / 1e12 / peak_tflops, 4), hbm_frac=round(nbytes / t / 1e9 / peak_gbs, 4),
                          step_share_us=round(t * 1e6 * launches, 1)))
     dom = max(rows, key=lambda r: r["step_share_us"])
     total = sum(r["step_share_us"] for r in rows)
-    mfma_bound = dom["tflops"] > 0
+    mfma_bound = dom["mfma_frac"] >= dom["hbm_frac"]
     ach = dom["tflops"] if mfma_bound else dom["gbs"]
     peak = peak_tflops if mfma_bound else peak_gbs
-    return {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernels"], "op": dom["op"], "achieved": ach,
+    return {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "op": dom["op"], "achieved": ach,
             "peak": peak, "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
             "avg_us": dom["us"], "launches_per_step": dom["launches_per_step"],
-            "encoder_kernel_sum_us": round(total, 1), "kernels": rows}
+            "mfma_frac": dom["mfma_frac"], "hbm_frac": dom["hbm_frac"],
+            "buffer_sets": nset, "encoder_kernel_sum_us": round(total, 1), "kernels": rows}

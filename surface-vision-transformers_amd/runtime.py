@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SITK_LIB") or os.path.join(_HERE, "libsitk.so")
 
 F32, BF16 = 0, 1
 EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class SitkError(RuntimeError):
@@ -61,6 +61,7 @@ _SIGS = {
     "sitk_dtype_size": (C.c_int, [_I]),
     "sitk_gather_tokens": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_gather_tokens_norm": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sitk_gather_tokens_idx": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_patchify": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_cast_rows": (C.c_int, [_P, _I, _P, _I, _L, _I, _I, _P]),
     "sitk_stage_weight": (C.c_int, [_P, _I, _I, _P, _I, _P, _I, _I, _P]),
@@ -87,6 +88,7 @@ _SIGS = {
     "sitk_attention_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P]),
     "sitk_attention_bwd_proj_supported": (C.c_int, [_I, _I, _I]),
     "sitk_attention_bwd_proj": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "sitk_attention_bwd_phases": (C.c_int, [_P] * 9 + [_I, _I, _I, _I, _F, _I, _I, _P]),
     "sitk_encoder_acts_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "sitk_encoder_scratch_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "sitk_encoder_fwd": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), _P, _P, _P, _Z, _P, _Z, _I, _P]),
@@ -100,11 +102,14 @@ _SIGS = {
     "sitk_head_loss_fwd_bwd": (C.c_int, [_P] * 13 + [_I] * 6 + [_P]),
     "sitk_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "sitk_colsum_f32": (C.c_int, [_P, _L, _I, _I, _P, _P]),
+    "sitk_colsum_f32_dup": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P]),
     "sitk_mpp_corrupt": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sitk_mpp_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _P]),
     "sitk_masked_colsum": (C.c_int, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P]),
     "sitk_sgd_step": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _I, _F, _P]),
     "sitk_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _F, _P]),
+    "sitk_sgd_step_dev": (C.c_int, [_P, _P, _P, _L, _P, _F, _F, _I, _F, _I, _L, _L, _P, _P]),
+    "sitk_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _I, _L, _L, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

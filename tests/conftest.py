@@ -17,3 +17,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Dump every parity error the GPU tests measured (tests/parity_bars.py) next to the other run outputs."""
+    try:
+        from tests import parity_bars
+    except ImportError:
+        return
+    if not parity_bars.RECORDS:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_measured.json"), "w") as f:
+        json.dump(dict(sorted(parity_bars.RECORDS.items())), f, indent=1)

@@ -24,7 +24,7 @@ def run_smoke():
     for dtype, tol in (("f32", 1e-3), ("bf16", 5e-2)):
         model = SiT(**kw, compute_dtype=dtype)
         model.load_state_dict(ref.state_dict())
-        eng = engine.TrainEngine(model, 4, input_layout="surface", lr=0.0, momentum=0.0, use_graph=False)
+        eng = engine.TrainEngine(model, 4, input_layout="surface", lr=0.0, momentum=0.0, use_graph=False, keep_grads=True)
         loss = float(eng.step(torch.from_numpy(xs).to(dev), torch.from_numpy(y).to(dev)))
         assert abs(loss - float(lref)) / float(lref) < tol, (dtype, loss, float(lref))
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):

@@ -84,3 +84,21 @@ def test_two_rank_engine_matches_single_process_full_batch(use_graph):
         assert p.exitcode == 0
     err = float((got.double() - want.double()).norm() / want.double().norm())
     assert err < 1e-6, err
+
+
+def test_bench_gpus_2_as_typed_prints_one_json_line():
+    """`python bench.py --gpus 2 ...` with no launcher around it: the script starts torch.distributed.run itself (child
+    process) and rank 0's JSON line comes back through it (gloo transport: one GPU on this box)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline",
+                        "--no-probe", "--steps", "3", "--warmup", "2", "--batch", "4"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0

@@ -155,3 +155,41 @@ def test_timm_weight_import_mapping(sitk_pkg):
     bad["blocks.0.mlp.fc1.weight"] = torch.zeros(mlp + 8, dim)
     with pytest.raises(ValueError):
         load_weights_imagenet(model.state_dict(), bad, depth)
+
+
+def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus 2` typed bare must start `python -m torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2 ...` as a CHILD process (never exec) before anything touches the GPU, and exit with its return code."""
+    import subprocess
+    import sys
+    import bench
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, **kw: calls.append(cmd) or 7)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3", "--backend", "gloo", "--no-probe"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7 and len(calls) == 1
+    cmd = calls[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--backend", "gloo", "--no-probe"]
+    # under the launcher (WORLD_SIZE set) it must NOT launch again
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert "WORLD_SIZE" in os.environ
+
+
+def test_cpu_baseline_thread_count_respects_cgroup_quota():
+    """The CPU baseline must size its thread pool by what the cgroup grants, not by os.cpu_count() (DESIGN.md section 5:
+    256 threads on a 16-CPU share is what timed out round 1's first bench run)."""
+    import bench
+    cores = bench.host_cores()
+    assert 1 <= cores <= (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            assert cores <= max(1, int(int(quota) / int(period)))
+    except OSError:
+        pass

@@ -2,9 +2,10 @@
 against the golden vectors captured from the reference's own Python (tests/golden/*.npz, see
 oracle/make_golden.py) and against the CPU oracle on the same seeded inputs.
 
-Tolerances: f32 compute mode must meet the north-star bar (1e-3 relative) with margin -- we assert
-2e-4 on outputs/loss and 1e-3 on every gradient norm; bf16 mode (the benchmark dtype) is asserted at
-3e-2 on outputs and 5e-2 on gradient norms (one 2^-9 rounding per MFMA operand over up to 12 layers).
+Tolerances (tests/parity_bars.py): f32 compute mode must meet the north-star bar (1e-3 relative) with
+margin -- 2e-4 on outputs/loss and 1e-3 on every gradient; bf16 mode (the benchmark dtype) is held, per case
+and metric, to 2 x the error measured on an MI355X (tests/golden/parity_measured_bf16.json); every check
+prints the measured error and its bar.
 """
 import os
 
@@ -17,9 +18,9 @@ pytestmark = pytest.mark.gpu
 from oracle import detgen, sit_oracle  # noqa: E402
 from oracle.make_golden import MPP_CASES, SIT_CASES, mpp_case_inputs, sit_case_inputs  # noqa: E402
 
+from tests.parity_bars import check  # noqa: E402
+
 DEV = "cuda:0"
-OUT_TOL = {"f32": 2e-4, "bf16": 3e-2}
-GRAD_TOL = {"f32": 1e-3, "bf16": 5e-2}
 
 
 def _load(module, seed):
@@ -53,18 +54,25 @@ def test_sit_matches_reference_golden(sitk_models, golden_dir, name, dtype):
     loss.backward()
     ref_out = g[f"{name}/out"]
     err = float(np.abs(out.detach().cpu().numpy() - ref_out).max() / (np.abs(ref_out).max() + 1e-12))
-    assert err < OUT_TOL[dtype], err
-    assert abs(float(loss) - float(g[f"{name}/loss"])) / float(g[f"{name}/loss"]) < 10 * OUT_TOL[dtype]
-    worst = 0.0
+    check(f"sit/{name}", "out", dtype, err, "out")
+    check(f"sit/{name}", "loss", dtype, abs(float(loss) - float(g[f"{name}/loss"])) / float(g[f"{name}/loss"]), "grad")
+    worst, worst_k, worst_head, worst_hk = 0.0, "", 0.0, ""
     for k, p in model.named_parameters():
         gn = float(g[f"{name}/gnorm/{k}"])
         e = abs(float(p.grad.double().norm()) - gn) / (gn + 1e-12)
-        worst = max(worst, e)
-        assert e < GRAD_TOL[dtype], (k, e)
+        if e > worst:
+            worst, worst_k = e, k
+        # first 8 gradient elements against the reference's, in units of the tensor's RMS gradient
         head = g[f"{name}/ghead/{k}"]
         he = float(np.abs(p.grad.reshape(-1)[:8].cpu().numpy() - head).max()) / (gn / np.sqrt(p.numel()) + 1e-12)
-        assert he < (0.05 if dtype == "f32" else 1.0), (k, he)
-    print(f"{name} {dtype}: out err {err:.2e}, worst grad-norm err {worst:.2e}")
+        if he > worst_head:
+            worst_head, worst_hk = he, k
+    print(f"{name} {dtype}: worst gradient norm {worst_k}, worst gradient head {worst_hk}")
+    check(f"sit/{name}", "gnorm", dtype, worst, "grad")
+    if dtype == "f32":
+        assert worst_head < 0.05, (worst_hk, worst_head)
+    else:
+        check(f"sit/{name}", "ghead", dtype, worst_head, "grad")
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -83,10 +91,10 @@ def test_sit_full_gradient_vs_oracle(sitk_models, dtype):
     lr.backward()
     lo = torch.nn.functional.mse_loss(model(torch.from_numpy(x).to(DEV)).squeeze(), torch.from_numpy(y).to(DEV))
     lo.backward()
-    tol = 1e-3 if dtype == "f32" else 6e-2
-    assert abs(float(lo) - float(lr)) / float(lr) < tol
-    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        assert rel(p.grad, q.grad) < tol, (k, rel(p.grad, q.grad))
+    check("fullgrad/tiny320_d3", "loss", dtype, abs(float(lo) - float(lr)) / float(lr), "grad")
+    worst = max((rel(p.grad, q.grad), k) for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()))
+    print("worst element-wise gradient:", worst)
+    check("fullgrad/tiny320_d3", "grad_rel", dtype, worst[0], "grad")
 
 
 def test_raw_surface_entry_equals_patched_entry(sitk_models):
@@ -118,17 +126,21 @@ def test_mpp_matches_reference_golden(sitk_models, golden_dir, name, dtype):
     rnd = {k.split("/")[-1]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{name}/rnd/")}
     loss, out = ssl(torch.from_numpy(x).to(DEV), randoms=rnd)
     loss.backward()
-    ot, gt = OUT_TOL[dtype], GRAD_TOL[dtype]
-    assert abs(float(loss) - float(g[f"{name}/loss"])) / float(g[f"{name}/loss"]) < 5 * ot
-    assert rel(out.detach()[:, :4, :16], g[f"{name}/out_head"]) < 5 * ot
-    assert abs(float(out.double().abs().sum()) - float(g[f"{name}/out_abs"])) / float(g[f"{name}/out_abs"]) < 5 * ot
+    check(f"mpp/{name}", "loss", dtype, abs(float(loss) - float(g[f"{name}/loss"])) / float(g[f"{name}/loss"]), "grad")
+    check(f"mpp/{name}", "out_head", dtype, rel(out.detach()[:, :4, :16], g[f"{name}/out_head"]), "grad")
+    check(f"mpp/{name}", "out_abs", dtype,
+          abs(float(out.double().abs().sum()) - float(g[f"{name}/out_abs"])) / float(g[f"{name}/out_abs"]), "grad")
+    worst, worst_k = 0.0, ""
     for k, p in ssl.named_parameters():
         gn = float(g[f"{name}/gnorm/{k}"])
         if gn < 0:
             assert p.grad is None
             continue
         e = abs(float(p.grad.double().norm()) - gn) / (gn + 1e-12)
-        assert e < gt, (k, e)
+        if e > worst:
+            worst, worst_k = e, k
+    print(f"{name} {dtype}: worst gradient norm {worst_k}")
+    check(f"mpp/{name}", "gnorm", dtype, worst, "grad")
 
 
 def test_mpp_seeded_draws_have_exact_mask_count(sitk_models):

@@ -1,0 +1,21 @@
+"""Copy the bf16 errors a GPU run of the tests measured (gpurun_out/parity_measured.json, written by
+tests/conftest.py) into the committed tests/golden/parity_measured_bf16.json, from which tests/parity_bars.py
+derives the bf16 bars (2 x measured).  Usage: python tools/update_parity_bars.py [--merge]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "parity_measured.json")
+dst = os.path.join(ROOT, "tests", "golden", "parity_measured_bf16.json")
+rec = json.load(open(src))
+out = json.load(open(dst)) if "--merge" in sys.argv and os.path.exists(dst) else {}
+for k, v in rec.items():
+    if k.startswith("bf16/"):
+        out[k[len("bf16/"):]] = float(f"{v:.3e}")
+json.dump(dict(sorted(out.items())), open(dst, "w"), indent=1)
+print(f"{len(out)} bf16 entries -> {dst}")
+f32 = {k: v for k, v in rec.items() if k.startswith("f32/")}
+if f32:
+    worst = max(f32.items(), key=lambda kv: kv[1])
+    print(f"f32 entries: {len(f32)}, worst {worst[0]} = {worst[1]:.3e}")
