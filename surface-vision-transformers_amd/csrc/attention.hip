@@ -9,6 +9,8 @@
 // the accumulator is reused in registers as the next product's B operand, the LDS tile supplies the
 // A operand through ds_read_b64_tr_b16 (bf16) or ds_read_b32 (f32), so the query (forward, dQ) or
 // key (dK/dV) index stays on lane&15 through the whole kernel and per-row softmax state is per-lane.
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -748,6 +750,539 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Ring variants (bf16, 384 < N <= 2048: the 1281-token configurations of BASELINE configs 3 and 5).
+// One workgroup = WAVES waves = 2 * WAVES consecutive 16-row query (or key) tiles of one (batch, head); every wave keeps
+// TWO tiles in registers, so each fragment it reads from LDS feeds two MFMAs.  The other operand pair of the sweep
+// (K and V tiles for forward / dQ; Q and dO tiles for dK / dV) streams through a 3-stage LDS ring by LDS-DMA, one
+// barrier per tile.  Tile t + 2 is issued in iteration t right after the iteration's LAST LDS read that hipcc can see
+// (the transposed fragment reads, which stay builtins so that their two halves are allocated as one MFMA operand):
+// hipcc drains the DMA queue in front of compiler-visible LDS reads, so that read of iteration t + 1 is where tile
+// t + 2 is waited for -- a whole iteration after its issue -- and tile t + 1, which iteration t + 1 computes on, was
+// waited for an iteration earlier.  The row-fragment reads at the top of an iteration are inline asm (invisible to that
+// logic; a visible read there would wait for a DMA issued moments before).  Blocks of one (batch, head) are consecutive
+// logical ids (one XCD's L2 serves their shared tiles).  WAVES is chosen on the host so that 2 * WAVES * blocks covers
+// the ceil(N / 16) tiles with the least padding (N = 1281: 81 tiles = 6 blocks x 7 waves x 2).  The last, partly
+// filled tile of the sweep runs a separate instantiation of the loop body (masking; zero page for the missing rows).
+// ------------------------------------------------------------------------------------------
+constexpr int RING_STAGES = 3, RING_STAGE = 16384, RING_MAX_N = 2048;
+
+// 8 row fragments (4 sixteen-row blocks x 2 k-steps) of the 64-row tile at byte addresses a0 / a1 (k-step 0 / 1)
+#define SITK_RING_ROWS8(F, A0, A1, OFF)                                                                                   \
+  asm volatile("ds_read_b128 %0, %8 offset:" #OFF "\n\tds_read_b128 %1, %9 offset:" #OFF "\n\t"                           \
+               "ds_read_b128 %2, %8 offset:" #OFF "+2048\n\tds_read_b128 %3, %9 offset:" #OFF "+2048\n\t"                 \
+               "ds_read_b128 %4, %8 offset:" #OFF "+4096\n\tds_read_b128 %5, %9 offset:" #OFF "+4096\n\t"                 \
+               "ds_read_b128 %6, %8 offset:" #OFF "+6144\n\tds_read_b128 %7, %9 offset:" #OFF "+6144\n\t"                 \
+               "s_waitcnt lgkmcnt(0)"                                                                                     \
+               : "=&v"(F[0][0]), "=&v"(F[0][1]), "=&v"(F[1][0]), "=&v"(F[1][1]), "=&v"(F[2][0]), "=&v"(F[2][1]),          \
+                 "=&v"(F[3][0]), "=&v"(F[3][1])                                                                           \
+               : "v"(A0), "v"(A1)                                                                                         \
+               : "memory")
+
+SITK_DEV u32x4 pack_pair(const f32x4& a, const f32x4& b) {
+  bf16x8 pb;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { pb[e] = (bf16)a[e]; pb[e + 4] = (bf16)b[e]; }
+  return __builtin_bit_cast(u32x4, pb);
+}
+// transposed fragment (column block dt, row half s2) of the tile at `tile`: two compiler-visible ds_read_b64_tr_b16
+SITK_DEV u32x4 ring_tr_frag(const char* tile, const LaneOffs& o, int s2, int dt) {
+  const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(tile + o.tr[dt] + s2 * 4096));
+  const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(tile + o.tr[dt] + s2 * 4096 + 2048));
+  return u32x4{__builtin_bit_cast(u32x2, lo)[0], __builtin_bit_cast(u32x2, lo)[1], __builtin_bit_cast(u32x2, hi)[0],
+               __builtin_bit_cast(u32x2, hi)[1]};
+}
+
+// The DMA of one stage: pieces 0..7 = rows of tile A, 8..15 = rows of tile B (8 rows x 128 B each), 64 rows from row
+// t * 64.  Every wave issues exactly PPW instructions (piece index clamped: duplicates rewrite the same bytes).  Source =
+// wave-uniform tile base + 32-bit lane offset; rows >= nrows (last tile only) come from a zero page.
+template <int WAVES>
+struct RingLoader {
+  static constexpr int PPW = (16 + WAVES - 1) / WAVES;
+  const char *base_a, *base_b;           // row 0 of the two operands for this (batch, head)
+  size_t step_a, step_b;                 // bytes per 64 rows
+  uint32_t off[PPW];                     // lane offset of piece i (bytes, from the tile's first row)
+  int prow[PPW], pdst[PPW];
+  bool is_b[PPW];
+  SITK_DEV void init(const bf16* src_a, size_t ld_a, const bf16* src_b, size_t ld_b, int wave, int lane) {
+    base_a = reinterpret_cast<const char*>(src_a);
+    base_b = reinterpret_cast<const char*>(src_b);
+    step_a = 128 * ld_a;
+    step_b = 128 * ld_b;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int p = min(wave * PPW + i, 15);
+      const int row = (p & 7) * 8 + (lane >> 3);
+      const int chunk = (lane & 7) ^ (attn_res_key(row) << 1);
+      is_b[i] = p >= 8;
+      off[i] = (uint32_t)((size_t)row * (p >= 8 ? ld_b : ld_a) * 2 + chunk * 16);
+      prow[i] = row;
+      pdst[i] = p * 1024;
+    }
+  }
+  template <bool TAIL>
+  SITK_DEV void issue(char* smem, int t, int nrows) const {
+    char* dst = smem + (t % RING_STAGES) * RING_STAGE;   // (scalar arithmetic)
+    const char* ta = base_a + (size_t)t * step_a;
+    const char* tb = base_b + (size_t)t * step_b;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const char* gp = (is_b[i] ? tb : ta) + off[i];
+      if constexpr (TAIL) {
+        if (t * 64 + prow[i] >= nrows) gp = reinterpret_cast<const char*>(g_zero_page_attn);
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                       (__attribute__((address_space(3))) void*)(dst + pdst[i]), 16, 0, 0);
+    }
+  }
+  SITK_DEV void issue_any(char* smem, int t, int nrows) const {
+    if ((t + 1) * 64 > nrows) issue<true>(smem, t, nrows);
+    else issue<false>(smem, t, nrows);
+  }
+};
+
+struct RingBlock {
+  int x, h, b;
+};
+SITK_DEV RingBlock ring_block(int nxb, int H) {
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  return RingBlock{L % nxb, (L / nxb) % H, L / (nxb * H)};
+}
+
+template <int WAVES, int QT, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+                                                                   float* __restrict__ lse, int N, int H, float scale, int nqb) {
+  __shared__ __attribute__((aligned(256))) char smem[RING_STAGES * RING_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const RingBlock bc = ring_block(nqb, H);
+  const int h = bc.h, b = bc.b, I = H * 64, nkt = (N + 63) / 64;
+  const size_t ld = (size_t)3 * I;
+  const bf16* base = qkv + (size_t)b * N * ld;
+  RingLoader<WAVES> dma;
+  dma.init(base + I + h * 64, ld, base + 2 * I + h * 64, ld, wave, lane);
+  dma.issue_any(smem, 0, N);
+  if (nkt > 1) dma.issue_any(smem, 1, N);
+
+  const int qt0 = (bc.x * WAVES + wave) * QT;             // first 16-row query tile of this wave
+  const bool active = qt0 * 16 < N;                       // wave-uniform: padding waves only move tiles
+  u32x4 qf[QT][2];
+  int qrow[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    qrow[j] = (qt0 + j) * 16 + fr;
+    const int qc = min(qrow[j], N - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + ks * 32 + fq * 8);
+  }
+  const float c = scale * kLog2e;
+  const LaneOffs lo = lane_offs_bf16(lane);
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  float m[QT], l[QT];
+  f32x4 oacc[QT][4];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    m[j] = -1e30f; l[j] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0 and 1 (and the Q fragments) have landed
+
+  int ring_stage = 0;
+  auto body = [&](int t, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    __builtin_amdgcn_s_barrier();                         // every wave's pieces of tile t; stage (t + 2) % 3 no longer read
+    const int stage = ring_stage;
+    ring_stage = ring_stage == RING_STAGES - 1 ? 0 : ring_stage + 1;
+    const char* tile = smem + stage * RING_STAGE;
+    if (!active) {                                        // padding wave: moves its share of the tiles, computes nothing
+      if (t + 2 < nkt) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dma.issue_any(smem, t + 2, N); }
+      return;
+    }
+    const uint32_t sb = lbase + stage * RING_STAGE;
+    u32x4 kf[4][2];
+    SITK_RING_ROWS8(kf, sb + lo.row[0], sb + lo.row[1], 0);
+    f32x4 s[QT][4];
+#pragma unroll
+    for (int j = 0; j < QT; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) s[j][i] = Mma<bf16>::mma(kf[i][ks], qf[j][ks], s[j][i]);
+    u32x4 pf[QT][2];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+      float mx = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          if constexpr (TAIL) {
+            if (t * 64 + 16 * i + 4 * fq + jj >= N) s[j][i][jj] = -INFINITY;
+          }
+          mx = fmaxf(mx, s[j][i][jj]);
+        }
+      mx = xor_max4(mx) * c;
+      if (!__all(mx <= m[j])) {                           // a row maximum grew: rescale (exact: alpha == 1 otherwise)
+        const float mn = fmaxf(m[j], mx);
+        const float alpha = fast_exp2(m[j] - mn);
+        l[j] *= alpha;
+        m[j] = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[j][dt] *= alpha;
+      }
+      f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 x = s[j][i] * c - m[j];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(x[jj]);
+        s[j][i] = x;
+        ps += x;
+      }
+      l[j] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      pf[j][0] = pack_pair(s[j][0], s[j][1]);
+      pf[j][1] = pack_pair(s[j][2], s[j][3]);
+    }
+    u32x4 vf[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vf[s2][dt] = ring_tr_frag(tile + 8192, lo, s2, dt);
+    __builtin_amdgcn_sched_barrier(0);                    // the DMA issue stays behind the last LDS read of the iteration
+    if (t + 2 < nkt) dma.issue_any(smem, t + 2, N);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) oacc[j][dt] = Mma<bf16>::mma(vf[s2][dt], pf[j][s2], oacc[j][dt]);
+  };
+  const int nfull = N >> 6;
+  for (int t = 0; t < nfull; ++t) body(t, std::false_type{});
+  if (nfull < nkt) body(nfull, std::true_type{});
+  if (!active) return;
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    const float lt = xor_sum4(l[j]);
+    const float inv = 1.0f / lt;
+    const int q = qrow[j];
+    if (q < N) {
+      bf16* orow = o + ((size_t)b * N + q) * I + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt + 4 * fq, oacc[j][dt] * inv);
+      if (fq == 0) lse[((size_t)b * H + h) * N + q] = (m[j] + __log2f(lt)) * kLn2;
+    }
+  }
+}
+
+// backward, query side: dQ, delta; same sweep as forward (K and V tiles in the ring), three products per tile
+template <int WAVES, int QT, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
+                                                                      const bf16* __restrict__ d_o, const float* __restrict__ lse,
+                                                                      float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
+                                                                      int H, float scale, int nqb) {
+  __shared__ __attribute__((aligned(256))) char smem[RING_STAGES * RING_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const RingBlock bc = ring_block(nqb, H);
+  const int h = bc.h, b = bc.b, I = H * 64, nkt = (N + 63) / 64;
+  const size_t ld = (size_t)3 * I;
+  const bf16* base = qkv + (size_t)b * N * ld;
+  RingLoader<WAVES> dma;
+  dma.init(base + I + h * 64, ld, base + 2 * I + h * 64, ld, wave, lane);
+  dma.issue_any(smem, 0, N);
+  if (nkt > 1) dma.issue_any(smem, 1, N);
+
+  const int qt0 = (bc.x * WAVES + wave) * QT;
+  const bool active = qt0 * 16 < N;
+  u32x4 qf[QT][2], dof[QT][2];
+  int qrow[QT];
+  float Lq[QT], ndl[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    qrow[j] = (qt0 + j) * 16 + fr;
+    const int qc = min(qrow[j], N - 1);
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int eo = ks * 32 + fq * 8;
+      qf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
+      const bf16* dop = d_o + ((size_t)b * N + qc) * I + h * 64 + eo;
+      const bf16* op = o + ((size_t)b * N + qc) * I + h * 64 + eo;
+      dof[j][ks] = *reinterpret_cast<const u32x4*>(dop);
+      const bf16x8 dv8 = __builtin_bit_cast(bf16x8, dof[j][ks]);
+      const bf16x8 ov8 = *reinterpret_cast<const bf16x8*>(op);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dpart += (float)dv8[e] * (float)ov8[e];
+    }
+    const float dl = xor_sum4(dpart);
+    const size_t ridx = ((size_t)b * H + h) * N + qc;
+    if (active && qrow[j] < N && fq == 0) delta[ridx] = dl;
+    Lq[j] = lse[ridx] * kLog2e;
+    ndl[j] = -dl;
+  }
+  const float c = scale * kLog2e;
+  const LaneOffs lo = lane_offs_bf16(lane);
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  f32x4 dq[QT][4];
+#pragma unroll
+  for (int j = 0; j < QT; ++j)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  int ring_stage = 0;
+  auto body = [&](int t, auto tail_c) {
+    constexpr bool TAIL = decltype(tail_c)::value;
+    __builtin_amdgcn_s_barrier();
+    const int stage = ring_stage;
+    ring_stage = ring_stage == RING_STAGES - 1 ? 0 : ring_stage + 1;
+    const char* tile = smem + stage * RING_STAGE;
+    if (!active) {
+      if (t + 2 < nkt) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dma.issue_any(smem, t + 2, N); }
+      return;
+    }
+    const uint32_t sb = lbase + stage * RING_STAGE;
+    u32x4 pf[QT][2];
+    {
+      u32x4 kf[4][2], vf[4][2];
+      SITK_RING_ROWS8(kf, sb + lo.row[0], sb + lo.row[1], 0);
+      SITK_RING_ROWS8(vf, sb + lo.row[0], sb + lo.row[1], 8192);
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s[i] = Mma<bf16>::mma(kf[i][ks], qf[j][ks], s[i]);
+            dp[i] = Mma<bf16>::mma(vf[i][ks], dof[j][ks], dp[i]);
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 x = s[i] * c - Lq[j];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            x[jj] = fast_exp2(x[jj]);
+            if constexpr (TAIL) {
+              if (t * 64 + 16 * i + 4 * fq + jj >= N) x[jj] = 0.f;
+            }
+          }
+          s[i] = x * (dp[i] + ndl[j]);                    // dS / scale: the scale is applied once, to dQ
+        }
+        pf[j][0] = pack_pair(s[0], s[1]);
+        pf[j][1] = pack_pair(s[2], s[3]);
+      }
+    }
+    u32x4 kt[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) kt[s2][dt] = ring_tr_frag(tile, lo, s2, dt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nkt) dma.issue_any(smem, t + 2, N);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) dq[j][dt] = Mma<bf16>::mma(kt[s2][dt], pf[j][s2], dq[j][dt]);
+  };
+  const int nfull = N >> 6;
+  for (int t = 0; t < nfull; ++t) body(t, std::false_type{});
+  if (nfull < nkt) body(nfull, std::true_type{});
+  if (!active) return;
+#pragma unroll
+  for (int j = 0; j < QT; ++j)
+    if (qrow[j] < N) {
+      bf16* row = dqkv + ((size_t)b * N + qrow[j]) * ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt + 4 * fq, dq[j][dt] * scale);
+    }
+}
+
+// backward, key side: dK, dV.  Wave = two 16-key tiles (K and V fragments in registers); Q and dO tiles in the ring; the
+// per-query statistics of the whole sequence (-lse / scale and -delta) sit in LDS and START the accumulators of the
+// S and dP products (S' = Q K^T - lse / scale, p = exp2(c S'); dP' = dO V^T - delta), so the elementwise part is one
+// multiply + exp2 and one multiply per element.  Padded query rows carry -inf there: p = 0.
+template <int WAVES, int QT, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+                                                                       const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                       bf16* __restrict__ dqkv, int N, int H, float scale, int nkb) {
+  __shared__ __attribute__((aligned(256))) char smem[RING_STAGES * RING_STAGE + 2 * RING_MAX_N * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const RingBlock bc = ring_block(nkb, H);
+  const int h = bc.h, b = bc.b, I = H * 64, nqt = (N + 63) / 64;
+  const size_t ld = (size_t)3 * I;
+  const bf16* base = qkv + (size_t)b * N * ld;
+  RingLoader<WAVES> dma;
+  dma.init(base + h * 64, ld, d_o + (size_t)b * N * I + h * 64, (size_t)I, wave, lane);
+  float* sL = reinterpret_cast<float*>(smem + RING_STAGES * RING_STAGE);
+  float* sD = sL + RING_MAX_N;
+  const float inv_scale = 1.0f / scale;
+  for (int r = tid; r < nqt * 64; r += WAVES * 64) {
+    const size_t ridx = ((size_t)b * H + h) * N + min(r, N - 1);
+    sL[r] = r < N ? -lse[ridx] * inv_scale : -INFINITY;
+    sD[r] = r < N ? -delta[ridx] : 0.f;
+  }
+  dma.issue_any(smem, 0, N);
+  if (nqt > 1) dma.issue_any(smem, 1, N);
+
+  const int kt0 = (bc.x * WAVES + wave) * QT;
+  const bool active = kt0 * 16 < N;
+  u32x4 kf[QT][2], vf[QT][2];
+  int krow[QT];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) {
+    krow[j] = (kt0 + j) * 16 + fr;
+    const int kc = min(krow[j], N - 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int eo = ks * 32 + fq * 8;
+      kf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo);
+      vf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + eo);
+    }
+  }
+  const float c = scale * kLog2e;
+  const LaneOffs lo = lane_offs_bf16(lane);
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lstat = lbase + RING_STAGES * RING_STAGE + 16 * fq;      // + t * 256 + i * 64 ; sD at + RING_MAX_N * 4
+  f32x4 dk[QT][4], dv[QT][4];
+#pragma unroll
+  for (int j = 0; j < QT; ++j)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                        // statistics visible
+
+  int ring_stage = 0;
+  auto body = [&](int t) {
+    __builtin_amdgcn_s_barrier();
+    const int stage = ring_stage;
+    ring_stage = ring_stage == RING_STAGES - 1 ? 0 : ring_stage + 1;
+    const char* tile = smem + stage * RING_STAGE;
+    if (!active) {
+      if (t + 2 < nqt) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dma.issue_any(smem, t + 2, N); }
+      return;
+    }
+    const uint32_t sb = lbase + stage * RING_STAGE;
+    const uint32_t st = lstat + t * 256;
+    u32x4 pp[QT][2], pds[QT][2];
+    {
+      u32x4 qr[4][2], dor[4][2];
+      SITK_RING_ROWS8(qr, sb + lo.row[0], sb + lo.row[1], 0);
+      SITK_RING_ROWS8(dor, sb + lo.row[0], sb + lo.row[1], 8192);
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        f32x4 s[4], dp[4];
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\t"
+                     "ds_read_b128 %3, %8 offset:192\n\tds_read_b128 %4, %8 offset:8192\n\tds_read_b128 %5, %8 offset:8256\n\t"
+                     "ds_read_b128 %6, %8 offset:8320\n\tds_read_b128 %7, %8 offset:8384\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(dp[0]), "=&v"(dp[1]), "=&v"(dp[2]), "=&v"(dp[3])
+                     : "v"(st)
+                     : "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s[i] = Mma<bf16>::mma(qr[i][ks], kf[j][ks], s[i]);
+            dp[i] = Mma<bf16>::mma(dor[i][ks], vf[j][ks], dp[i]);
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 x = s[i] * c;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(x[jj]);
+          s[i] = x;
+          dp[i] = x * dp[i];                              // dS / scale: the scale is applied once, to dK
+        }
+        pp[j][0] = pack_pair(s[0], s[1]);
+        pp[j][1] = pack_pair(s[2], s[3]);
+        pds[j][0] = pack_pair(dp[0], dp[1]);
+        pds[j][1] = pack_pair(dp[2], dp[3]);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const u32x4 f = ring_tr_frag(tile + 8192, lo, s2, dt);          // dO^T
+#pragma unroll
+        for (int j = 0; j < QT; ++j) dv[j][dt] = Mma<bf16>::mma(f, pp[j][s2], dv[j][dt]);
+      }
+    u32x4 qt_[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) qt_[s2][dt] = ring_tr_frag(tile, lo, s2, dt);   // Q^T
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 2 < nqt) dma.issue_any(smem, t + 2, N);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) dk[j][dt] = Mma<bf16>::mma(qt_[s2][dt], pds[j][s2], dk[j][dt]);
+  };
+  for (int t = 0; t < nqt; ++t) body(t);
+  if (!active) return;
+#pragma unroll
+  for (int j = 0; j < QT; ++j)
+    if (krow[j] < N) {
+      bf16* row = dqkv + ((size_t)b * N + krow[j]) * ld + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store4(row + I + 16 * dt + 4 * fq, dk[j][dt] * scale);
+        store4(row + 2 * I + 16 * dt + 4 * fq, dv[j][dt]);
+      }
+    }
+}
+
+// waves per workgroup (4..8) that cover ceil(N / 16) tiles (qt per wave) with the least padding; ties -> more waves
+static int ring_waves(int N, int qt, int* nblocks) {
+  const int tiles = (N + 15) / 16;
+  int best = 8, best_pad = 1 << 30;
+  for (int w = 8; w >= 4; --w) {
+    const int nb = (tiles + qt * w - 1) / (qt * w), pad = nb * qt * w - tiles;
+    if (pad < best_pad) { best_pad = pad; best = w; }
+  }
+  *nblocks = (tiles + qt * best - 1) / (qt * best);
+  return best;
+}
+static bool ring_supported(int N) { return N > RES_MAX_N && N <= RING_MAX_N; }
+// tiles per wave of the three ring kernels (SITK_RING_QT=fwd,dq,dkv overrides: timing experiments)
+static void ring_qt(int (&qt)[3]) {
+  static int v[3] = {0, 0, 0};
+  if (!v[0]) {
+    int a = 2, b = 2, c = 2;
+    if (const char* e = getenv("SITK_RING_QT")) sscanf(e, "%d,%d,%d", &a, &b, &c);
+    v[0] = a == 1 ? 1 : 2; v[1] = b == 1 ? 1 : 2; v[2] = c == 1 ? 1 : 2;
+  }
+  qt[0] = v[0]; qt[1] = v[1]; qt[2] = v[2];
+}
+
+#define SITK_RING_LAUNCH_Q(KERNEL, W, QT, MINW, GRID, S, ...)                                               \
+  switch (W) {                                                                                              \
+    case 4: hipLaunchKernelGGL((KERNEL<4, QT, MINW>), GRID, dim3(256), 0, S, __VA_ARGS__); break;           \
+    case 5: hipLaunchKernelGGL((KERNEL<5, QT, MINW>), GRID, dim3(320), 0, S, __VA_ARGS__); break;           \
+    case 6: hipLaunchKernelGGL((KERNEL<6, QT, MINW>), GRID, dim3(384), 0, S, __VA_ARGS__); break;           \
+    case 7: hipLaunchKernelGGL((KERNEL<7, QT, MINW>), GRID, dim3(448), 0, S, __VA_ARGS__); break;           \
+    default: hipLaunchKernelGGL((KERNEL<8, QT, MINW>), GRID, dim3(512), 0, S, __VA_ARGS__); break;          \
+  }
+// MINW1 / MINW2: minimum waves per SIMD (register budget) of the one- and two-tiles-per-wave builds
+#define SITK_RING_LAUNCH(KERNEL, W, QT, MINW1, MINW2, GRID, S, ...)                                         \
+  if ((QT) == 1) { SITK_RING_LAUNCH_Q(KERNEL, W, 1, MINW1, GRID, S, __VA_ARGS__) }                          \
+  else { SITK_RING_LAUNCH_Q(KERNEL, W, 2, MINW2, GRID, S, __VA_ARGS__) }
+
 template <typename T>
 static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
@@ -755,6 +1290,15 @@ static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, fl
       hipLaunchKernelGGL(attn_fwd_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
                          reinterpret_cast<bf16*>(o), lse, N, H, scale);
       return check_launch("attention_fwd_res");
+    }
+    if (ring_supported(N)) {
+      int nqb, qt[3];
+      ring_qt(qt);
+      const int w = ring_waves(N, qt[0], &nqb);
+      const bf16* q_ = reinterpret_cast<const bf16*>(qkv);
+      bf16* o_ = reinterpret_cast<bf16*>(o);
+      SITK_RING_LAUNCH(attn_fwd_ring_kernel, w, qt[0], 4, 3, dim3(nqb * H * B), s, q_, o_, lse, N, H, scale, nqb);
+      return check_launch("attention_fwd_ring");
     }
   }
   dim3 grid(cdiv(N, 64) * H * B);
@@ -795,6 +1339,22 @@ static int run_bwd(const void* qkv, const void* o, const void* d_o, const float*
       hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
                          reinterpret_cast<const bf16*>(d_o), lse, delta, reinterpret_cast<bf16*>(dqkv), N, H, scale);
       return check_launch("attention_bwd_dkv_res");
+    }
+    if (ring_supported(N)) {
+      int nb, qt[3];
+      ring_qt(qt);
+      const bf16 *q_ = reinterpret_cast<const bf16*>(qkv), *o_ = reinterpret_cast<const bf16*>(o), *do_ = reinterpret_cast<const bf16*>(d_o);
+      bf16* dq_ = reinterpret_cast<bf16*>(dqkv);
+      if (phases & 1) {
+        const int w = ring_waves(N, qt[1], &nb);
+        SITK_RING_LAUNCH(attn_bwd_dq_ring_kernel, w, qt[1], 3, 2, dim3(nb * H * B), s, q_, o_, do_, lse, delta, dq_, N, H, scale, nb);
+      }
+      SITK_LAUNCH_CHECK("attention_bwd_dq_ring");
+      if (phases & 2) {
+        const int w = ring_waves(N, qt[2], &nb);
+        SITK_RING_LAUNCH(attn_bwd_dkv_ring_kernel, w, qt[2], 3, 2, dim3(nb * H * B), s, q_, do_, lse, delta, dq_, N, H, scale, nb);
+      }
+      return check_launch("attention_bwd_dkv_ring");
     }
   }
   dim3 grid(cdiv(N, 64) * H * B);

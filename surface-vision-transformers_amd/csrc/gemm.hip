@@ -9,6 +9,7 @@
 // Operand tiles are staged global -> registers -> LDS ([rows][128 B] swizzled image, common.h) with
 // the next tile's loads issued before the current tile's MFMAs.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -406,15 +407,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_wres_kernel(GemmParams p, 
 
 // WM = waves along the token dimension (4: 128-token tiles, 3: 96-token tiles for grids that would
 // otherwise leave a third of the CUs idle); 2 waves along the 192 features.
-template <typename TO, int EPI, int WM>
-__global__ __launch_bounds__(WM * 128) void gemm_nt_n192_kernel(GemmParams p) {
+template <typename TO, int EPI, int WM, int NSTG = 4, int MINW = 1>
+__global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams p) {
   using T = bf16;
   constexpr int BM = WM * 32;
   constexpr int APC = BM / 8;              // 8-row DMA pieces of the A tile
   constexpr int PIECES = (APC + 24) / (2 * WM);  // per wave and stage: 5 (WM 4) / 6 (WM 3)
   static_assert(PIECES * 2 * WM == APC + 24, "pieces must divide evenly");
   constexpr int STG = (BM + 192) * 128;    // A rows then W rows 0..191
-  constexpr int NSTG = 4;                  // 160 KB: the whole LDS of a CU
+  // NSTG = 4: 160 KB, the whole LDS of a CU; NSTG = 2: 80 KB, two workgroups per CU (each other's fill and epilogue cover)
   __shared__ __attribute__((aligned(256))) char smem[NSTG * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
@@ -517,9 +518,15 @@ template <typename TO, int EPI>
 static int launch_gemm_nt_n192(const GemmParams& p, hipStream_t s) {
   const int tiles_n = p.N / 192;
   const int g128 = cdiv(p.M, 128) * tiles_n, g96 = cdiv(p.M, 96) * tiles_n;
-  // one workgroup per CU (the 4-stage ring takes the whole LDS): prefer the tile height that fills more
-  // of the 256 CUs in a single round
-  if (g128 < 205 && g96 <= 256) {
+  // More than one round of tiles (dim 384 / 768: 1 900 - 7 700 tiles): a 2-stage ring of 80 KB and <= 128 registers, so
+  // that TWO workgroups share a CU and each runs its MFMAs under the other's ring fill and epilogue (with K = 384 a
+  // tile has six k-steps: a workgroup alone on its CU spends as long filling and storing as multiplying).  Measured on
+  // the eight encoder GEMMs (tools/gemm_bench.py, 40 992 tokens): dim 384 717 -> 622 us, dim 768 2019 -> 1628 us; a
+  // persistent one-workgroup-per-CU form whose k-tile stream ran across tile boundaries gained 3 % / 0 % (its epilogue
+  // still stalls the only workgroup of the CU).  One round: the 4-stage ring, tile height by CU coverage.
+  if (g128 > 256) {
+    hipLaunchKernelGGL((gemm_nt_n192_kernel<TO, EPI, 4, 2, 4>), dim3(g128), dim3(512), 0, s, p);
+  } else if (g128 < 205 && g96 <= 256) {
     hipLaunchKernelGGL((gemm_nt_n192_kernel<TO, EPI, 3>), dim3(g96), dim3(384), 0, s, p);
   } else {
     hipLaunchKernelGGL((gemm_nt_n192_kernel<TO, EPI, 4>), dim3(g128), dim3(512), 0, s, p);

@@ -56,7 +56,7 @@ def _worker(rank, world, port, use_graph, q):
         eng.step(x[shard].cuda(), y[shard].cuda())
     torch.cuda.synchronize()
     if rank == 0:
-        q.put(eng.fp.flat.cpu())
+        q.put(eng.fp.flat.cpu().numpy())      # by value: a tensor travels as an fd the parent must fetch while this process lives
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,7 +78,7 @@ def test_two_rank_engine_matches_single_process_full_batch(use_graph):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, use_graph, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=300)
+    got = torch.from_numpy(q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

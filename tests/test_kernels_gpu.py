@@ -312,7 +312,11 @@ def _attn_ref(qkv, B, N, H, scale):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,N,H", [(2, 321, 3), (1, 81, 6), (2, 64, 1), (1, 130, 2), (1, 1281, 2), (1, 100, 2), (1, 96, 1),
-                                   (1, 80, 1), (1, 384, 1), (1, 17, 1)])
+                                   (1, 80, 1), (1, 384, 1), (1, 17, 1),
+                                   # LDS-ring kernels (bf16, 384 < N <= 2048): every waves-per-workgroup variant, ragged
+                                   # tails (N % 64 = 1, 20, 0, 63, 33), several (batch, head) pairs; above 2048: tiled kernels
+                                   (2, 1281, 6), (1, 385, 2), (1, 500, 1), (2, 640, 2), (1, 1023, 1), (1, 2048, 1), (1, 1313, 3),
+                                   (1, 2100, 1)])
 def test_attention_fwd_bwd(ops, dtype, B, N, H):
     td = tdt(dtype)
     qkv = rnd("at/qkv", (B * N, 3 * H * 64), 1.0).to(td)
@@ -360,6 +364,22 @@ def test_attention_large_scores_online_softmax(ops):
     o, lse = ops.attention_fwd(qkv, B, N, H, 0.125, "f32")
     oref, lref = _attn_ref(qkv, B, N, H, 0.125)
     assert rel(o, oref) < 2e-5 and rel(lse, lref) < 1e-5
+
+
+def test_attention_ring_large_scores_rescale_branch(ops):
+    """bf16 LDS-ring forward (N = 700): the deferred rescale (taken only when a row maximum grows) is forced late -- key 650
+    dominates query 10, key 400 dominates query 333 -- and must agree with the softmax reference; lse too."""
+    B, N, H = 1, 700, 2
+    qkv = rnd("at3/qkv", (N, 3 * H * 64), 0.3)
+    qkv[:, 0:128] *= 4.0
+    qkv[650, 128:192] = 6.0 * qkv[10, 0:64]                  # head 0
+    qkv[400, 192:256] = 5.0 * qkv[333, 64:128]               # head 1
+    qb = qkv.to(torch.bfloat16)
+    o, lse = ops.attention_fwd(qb, B, N, H, 0.125, "bf16")
+    oref, lref = _attn_ref(qb, B, N, H, 0.125)
+    assert rel(o, oref) < 1e-2 and rel(lse, lref) < 2e-3
+    assert rel(o.float().view(N, H, 64)[10, 0], oref.view(N, H, 64)[10, 0]) < 1e-2
+    assert rel(o.float().view(N, H, 64)[333, 1], oref.view(N, H, 64)[333, 1]) < 1e-2
 
 
 # ---------------------------------------------------------------------------------------------------
