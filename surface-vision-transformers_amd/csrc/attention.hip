@@ -445,6 +445,53 @@ SITK_DEV void tr_mma_o(f32x4 (&acc)[4], const f32x4 (&p)[4], const char* tile, c
   }
 }
 
+// The same with the row sums of P taken by the matrix pipe: one more MFMA per 32-key half whose A operand is all ones
+// (bf16 1.0), so lsum[.] += sum_k P[k][lane & 15] in every register of lsum -- no VALU adds, no cross-lane reduction,
+// and the sum is taken over the bf16-rounded P that multiplies V.
+constexpr uint32_t kOnesBf16x2 = 0x3F803F80u;
+template <int NS2 = 2>
+SITK_DEV void tr_mma_o_sum(f32x4 (&acc)[4], f32x4& lsum, const f32x4 (&p)[4], const char* tile, const LaneOffs& o) {
+  const u32x4 ones = {kOnesBf16x2, kOnesBf16x2, kOnesBf16x2, kOnesBf16x2};
+#pragma unroll
+  for (int s2 = 0; s2 < NS2; ++s2) {
+    bf16x8 pb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pb[e] = (bf16)p[2 * s2][e]; pb[e + 4] = (bf16)p[2 * s2 + 1][e]; }
+    const u32x4 pf = __builtin_bit_cast(u32x4, pb);
+    lsum = Mma<bf16>::mma(ones, pf, lsum);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(tile + o.tr[dt] + s2 * 4096));
+      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) i16x4*)(tile + o.tr[dt] + s2 * 4096 + 2048));
+      u32x4 vf;
+      vf[0] = __builtin_bit_cast(u32x2, lo)[0];
+      vf[1] = __builtin_bit_cast(u32x2, lo)[1];
+      vf[2] = __builtin_bit_cast(u32x2, hi)[0];
+      vf[3] = __builtin_bit_cast(u32x2, hi)[1];
+      acc[dt] = Mma<bf16>::mma(vf, pf, acc[dt]);
+    }
+  }
+}
+
+// one operand fragment (8 bf16) times a scalar, one rounding: the softmax scale (times log2 e) is folded into the Q (or K)
+// fragments a wave keeps in registers, so the score MFMAs deliver log2-domain scores and the elementwise part starts at exp2
+SITK_DEV u32x4 scale_frag(u32x4 f, float c) {
+  bf16x8 v = __builtin_bit_cast(bf16x8, f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * c);
+  return __builtin_bit_cast(u32x4, v);
+}
+SITK_DEV f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+// Online softmax, VALU-lean form (the attention kernels are bound by vector-instruction ISSUE, profiles/README):
+//   * scores arrive as s' = c q.k - m: the running maximum m is the INITIAL ACCUMULATOR of the score MFMAs;
+//   * the maximum is re-examined per lane only (8 v_max3 + one vote); the cross-lane reduction, the rescale of O and l
+//     and the shift of the tile's scores run only when some score exceeds m by more than kRescaleThr (log2 units): until
+//     then probabilities may reach 2^kRescaleThr, harmless in f32 / bf16 (same exponent range);
+//   * the first tile of a sweep (m unknown) takes that path unconditionally with a zero initial accumulator.
+constexpr float kRescaleThr = 8.0f;
+
 // rows [0, ntiles*64) x 64 bf16 columns of `src` (leading dim ld) -> LDS tiles [t][64][128 B]; rows >= nrows are zero
 SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, int nrows, int ntiles, int wave, int lane, int nwaves) {
   const char* zero = reinterpret_cast<const char*>(g_zero_page_attn);
@@ -490,20 +537,22 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
     u32x4 qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-      qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + ks * 32 + fq * 8);
-    float m = -1e30f, l = 0.f;
+      qf[ks] = scale_frag(*reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + ks * 32 + fq * 8), c);
+    float m = 0.f;
+    f32x4 negm = splat4(0.f), lacc = splat4(0.f);
     f32x4 oacc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nfull = N >> 6;   // key tiles without padding: no masking instructions in their body
     // masked = 0: full key tile; masked = NT > 0: the last, partly filled tile, NT of its 16-key blocks computed
-    auto kv_tile = [&](int t, auto masked) {
+    auto kv_tile = [&](int t, auto masked, auto first_c) {
       constexpr int MK = decltype(masked)::value, NT = MK ? MK : 4, NS2 = (NT + 1) / 2;
+      constexpr bool FIRST = decltype(first_c)::value;
       f32x4 s[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      row_mma_o<NT>(s, sK + t * 8192, qf, lo);
-      float mx = -1e30f;
+      for (int i = 0; i < 4; ++i) s[i] = FIRST ? splat4(0.f) : negm;
+      row_mma_o<NT>(s, sK + t * 8192, qf, lo);       // s' = c q.k - m
+      float mxl = -INFINITY;
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -511,31 +560,37 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
           if constexpr (MK != 0) {
             if (t * 64 + 16 * i + 4 * fq + jj >= N) s[i][jj] = -INFINITY;
           }
-          mx = fmaxf(mx, s[i][jj]);
+          mxl = fmaxf(mxl, s[i][jj]);
         }
-      mx = xor_max4(mx) * c;                       // c > 0: max commutes with the scale
-      const float mn = fmaxf(m, mx);
-      const float alpha = fast_exp2(m - mn);
-      // (scalar forms on purpose: the whole-vector v_pk_fma / v_pk_add forms the backward kernels use measured 0.8 us
-      //  SLOWER here -- the kernel is bound by the dependent chain of one tile, not by VALU issue slots)
-      float ps = 0.f;
+      if (FIRST || __any(mxl > kRescaleThr)) {
+        const float mx = xor_max4(mxl);
+        const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+        if constexpr (!FIRST) {
+          const float alpha = fast_exp2(-delta);
+          lacc *= alpha;
 #pragma unroll
-      for (int i = 0; i < NT; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const float pv = fast_exp2(fmaf(s[i][jj], c, -mn));
-          s[i][jj] = pv;
-          ps += pv;
+          for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
         }
-      l = l * alpha + ps;
-      m = mn;
+        m += delta;
+        negm = splat4(-m);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
-      tr_mma_o<NS2>(oacc, s, sV + t * 8192, lo);     // s[i >= NT] = 0
+        for (int i = 0; i < NT; ++i) s[i] -= delta;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) s[i][jj] = i < NT ? fast_exp2(s[i][jj]) : 0.f;
+      tr_mma_o_sum<NS2>(oacc, lacc, s, sV + t * 8192, lo);
     };
-    for (int t = 0; t < nfull; ++t) kv_tile(t, std::integral_constant<int, 0>{});
-    if (nfull < nkt) tail_dispatch(N - 64 * nfull, [&](auto nt) { kv_tile(nfull, nt); });
-    const float lt = xor_sum4(l);
+    constexpr std::integral_constant<int, 0> full{};
+    if (nfull > 0) {
+      kv_tile(0, full, std::true_type{});
+      for (int t = 1; t < nfull; ++t) kv_tile(t, full, std::false_type{});
+      if (nfull < nkt) tail_dispatch(N - 64 * nfull, [&](auto nt) { kv_tile(nfull, nt, std::false_type{}); });
+    } else {
+      tail_dispatch(N, [&](auto nt) { kv_tile(0, nt, std::true_type{}); });
+    }
+    const float lt = lacc[0];                      // every register / lane of a column holds the column's full sum
     const float inv = 1.0f / lt;
     if (q < N) {
       T* orow = o + ((size_t)b * N + q) * I + h * 64;
@@ -640,29 +695,31 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const bf16*
     const float dl = xor_sum4(dpart);
     const size_t ridx = ((size_t)b * H + h) * N + qc;
     if (q < N && fq == 0) delta[ridx] = dl;
-    const float Lq = lse[ridx] * kLog2e, ndl = -dl;
+    const float nLq = -lse[ridx] * kLog2e, ndl = -dl;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = scale_frag(qf[ks], c);   // scores in log2 units straight from the MFMA
     f32x4 dq[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nfull = N >> 6;
     auto kv_tile = [&](int t, auto masked) {
       constexpr int MK = decltype(masked)::value, NT = MK ? MK : 4, NS2 = (NT + 1) / 2;
-      f32x4 s[4], dp[4];
+      f32x4 s[4], dp[4];                               // row constants start the accumulators: s' = c q.k - lse, dp' = dO.v - delta
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int i = 0; i < 4; ++i) { s[i] = i < NT ? splat4(nLq) : splat4(0.f); dp[i] = i < NT ? splat4(ndl) : splat4(0.f); }
       row_mma_o<NT>(s, sK + t * 8192, qf, lo);
       row_mma_o<NT>(dp, sV + t * 8192, dof, lo);
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        f32x4 x = s[i] * c - Lq;
+        f32x4 x;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          x[jj] = fast_exp2(x[jj]);
+          x[jj] = fast_exp2(s[i][jj]);
           if constexpr (MK != 0) {
             if (t * 64 + 16 * i + 4 * fq + jj >= N) x[jj] = 0.f;
           }
         }
-        s[i] = x * (dp[i] + ndl);                      // dS / scale: the scale is applied once, to dQ
+        s[i] = x * dp[i];                              // dS / scale: the scale is applied once, to dQ
       }
       tr_mma_o<NS2>(dq, s, sK + t * 8192, lo);        // s[i >= NT] = 0
     };
@@ -709,7 +766,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int eo = ks * 32 + fq * 8;
-      kf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo);
+      kf[ks] = scale_frag(*reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo), c);   // log2-domain scores
       vf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + eo);
     }
     f32x4 dk[4], dv[4];
@@ -719,20 +776,21 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16
     // nt = 0: full query tile; nt > 0: the last, partly filled tile (its padded rows have L = inf, so p = 0 there)
     auto q_tile = [&](int t, auto nt) {
       constexpr int NT = decltype(nt)::value ? decltype(nt)::value : 4, NS2 = (NT + 1) / 2;
-      f32x4 s[4], dp[4];
+      f32x4 s[4], dp[4];                               // the per-query statistics start the accumulators
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int i = 0; i < 4; ++i) {
+        s[i] = i < NT ? *reinterpret_cast<const f32x4*>(sL + t * 64 + 16 * i + 4 * fq) : splat4(0.f);    // -lse log2 e
+        dp[i] = i < NT ? *reinterpret_cast<const f32x4*>(sD + t * 64 + 16 * i + 4 * fq) : splat4(0.f);   // -delta
+      }
       row_mma_o<NT>(s, sQ + t * 8192, kf, lo);
       row_mma_o<NT>(dp, sDO + t * 8192, vf, lo);
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
-        const f32x4 Lr = *reinterpret_cast<const f32x4*>(sL + t * 64 + 16 * i + 4 * fq);
-        const f32x4 Dr = *reinterpret_cast<const f32x4*>(sD + t * 64 + 16 * i + 4 * fq);
-        f32x4 x = s[i] * c + Lr;
+        f32x4 x;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(x[jj]);
+        for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(s[i][jj]);
         s[i] = x;
-        dp[i] = x * (dp[i] + Dr);                     // dS / scale: the scale is applied once, to dK
+        dp[i] = x * dp[i];                            // dS / scale: the scale is applied once, to dK
       }
       tr_mma_o<NS2>(dv, s, sDO + t * 8192, lo);       // s, dp [i >= NT] = 0
       tr_mma_o<NS2>(dk, dp, sQ + t * 8192, lo);
@@ -761,9 +819,9 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16
 // t + 2 is waited for -- a whole iteration after its issue -- and tile t + 1, which iteration t + 1 computes on, was
 // waited for an iteration earlier.  The row-fragment reads at the top of an iteration are inline asm (invisible to that
 // logic; a visible read there would wait for a DMA issued moments before).  Blocks of one (batch, head) are consecutive
-// logical ids (one XCD's L2 serves their shared tiles).  WAVES is chosen on the host so that 2 * WAVES * blocks covers
-// the ceil(N / 16) tiles with the least padding (N = 1281: 81 tiles = 6 blocks x 7 waves x 2).  The last, partly
-// filled tile of the sweep runs a separate instantiation of the loop body (masking; zero page for the missing rows).
+// logical ids (one XCD's L2 serves their shared tiles).  Launch geometry (4 waves x 2 tiles): ring_blocks() below.  The
+// last, partly filled tile of the sweep runs a separate instantiation of the loop body (masking; zero page for the
+// missing rows).
 // ------------------------------------------------------------------------------------------
 constexpr int RING_STAGES = 3, RING_STAGE = 16384, RING_MAX_N = 2048;
 
@@ -874,24 +932,25 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     const int qc = min(qrow[j], N - 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-      qf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + ks * 32 + fq * 8);
+      qf[j][ks] = scale_frag(*reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + ks * 32 + fq * 8), scale * kLog2e);
   }
-  const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_bf16(lane);
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  float m[QT], l[QT];
+  const u32x4 ones = {kOnesBf16x2, kOnesBf16x2, kOnesBf16x2, kOnesBf16x2};
+  float m[QT];
+  f32x4 negm[QT], lacc[QT];
   f32x4 oacc[QT][4];
 #pragma unroll
   for (int j = 0; j < QT; ++j) {
-    m[j] = -1e30f; l[j] = 0.f;
+    m[j] = 0.f; negm[j] = splat4(0.f); lacc[j] = splat4(0.f);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0 and 1 (and the Q fragments) have landed
 
   int ring_stage = 0;
-  auto body = [&](int t, auto tail_c) {
-    constexpr bool TAIL = decltype(tail_c)::value;
+  auto body = [&](int t, auto tail_c, auto first_c) {
+    constexpr bool TAIL = decltype(tail_c)::value, FIRST = decltype(first_c)::value;
     __builtin_amdgcn_s_barrier();                         // every wave's pieces of tile t; stage (t + 2) % 3 no longer read
     const int stage = ring_stage;
     ring_stage = ring_stage == RING_STAGES - 1 ? 0 : ring_stage + 1;
@@ -903,11 +962,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     const uint32_t sb = lbase + stage * RING_STAGE;
     u32x4 kf[4][2];
     SITK_RING_ROWS8(kf, sb + lo.row[0], sb + lo.row[1], 0);
-    f32x4 s[QT][4];
+    f32x4 s[QT][4];                                       // s' = c q.k - m: the running maximum starts the accumulators
 #pragma unroll
     for (int j = 0; j < QT; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) s[j][i] = FIRST ? splat4(0.f) : negm[j];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -917,7 +976,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     u32x4 pf[QT][2];
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
-      float mx = -1e30f;
+      float mxl = -INFINITY;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -925,27 +984,26 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
           if constexpr (TAIL) {
             if (t * 64 + 16 * i + 4 * fq + jj >= N) s[j][i][jj] = -INFINITY;
           }
-          mx = fmaxf(mx, s[j][i][jj]);
+          mxl = fmaxf(mxl, s[j][i][jj]);
         }
-      mx = xor_max4(mx) * c;
-      if (!__all(mx <= m[j])) {                           // a row maximum grew: rescale (exact: alpha == 1 otherwise)
-        const float mn = fmaxf(m[j], mx);
-        const float alpha = fast_exp2(m[j] - mn);
-        l[j] *= alpha;
-        m[j] = mn;
+      if (FIRST || __any(mxl > kRescaleThr)) {            // see kRescaleThr: rare after the first tile
+        const float mx = xor_max4(mxl);
+        const float delta = FIRST ? mx : fmaxf(mx, 0.f);
+        if constexpr (!FIRST) {
+          const float alpha = fast_exp2(-delta);
+          lacc[j] *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) oacc[j][dt] *= alpha;
+          for (int dt = 0; dt < 4; ++dt) oacc[j][dt] *= alpha;
+        }
+        m[j] += delta;
+        negm[j] = splat4(-m[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[j][i] -= delta;
       }
-      f32x4 ps = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 x = s[j][i] * c - m[j];
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(x[jj]);
-        s[j][i] = x;
-        ps += x;
-      }
-      l[j] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        for (int jj = 0; jj < 4; ++jj) s[j][i][jj] = fast_exp2(s[j][i][jj]);
       pf[j][0] = pack_pair(s[j][0], s[j][1]);
       pf[j][1] = pack_pair(s[j][2], s[j][3]);
     }
@@ -957,19 +1015,23 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     __builtin_amdgcn_sched_barrier(0);                    // the DMA issue stays behind the last LDS read of the iteration
     if (t + 2 < nkt) dma.issue_any(smem, t + 2, N);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int j = 0; j < QT; ++j) lacc[j] = Mma<bf16>::mma(ones, pf[j][s2], lacc[j]);    // row sums of P on the matrix pipe
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int j = 0; j < QT; ++j) oacc[j][dt] = Mma<bf16>::mma(vf[s2][dt], pf[j][s2], oacc[j][dt]);
+    }
   };
-  const int nfull = N >> 6;
-  for (int t = 0; t < nfull; ++t) body(t, std::false_type{});
-  if (nfull < nkt) body(nfull, std::true_type{});
+  const int nfull = N >> 6;                               // >= 1 (ring kernels take N >= 64)
+  body(0, std::false_type{}, std::true_type{});
+  for (int t = 1; t < nfull; ++t) body(t, std::false_type{}, std::false_type{});
+  if (nfull < nkt) body(nfull, std::true_type{}, std::false_type{});
   if (!active) return;
 #pragma unroll
   for (int j = 0; j < QT; ++j) {
-    const float lt = xor_sum4(l[j]);
+    const float lt = lacc[j][0];
     const float inv = 1.0f / lt;
     const int q = qrow[j];
     if (q < N) {
@@ -1024,10 +1086,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
     const float dl = xor_sum4(dpart);
     const size_t ridx = ((size_t)b * H + h) * N + qc;
     if (active && qrow[j] < N && fq == 0) delta[ridx] = dl;
-    Lq[j] = lse[ridx] * kLog2e;
+    Lq[j] = -lse[ridx] * kLog2e;                          // (negated: the initial accumulator of the score product)
     ndl[j] = -dl;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[j][ks] = scale_frag(qf[j][ks], scale * kLog2e);
   }
-  const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_bf16(lane);
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   f32x4 dq[QT][4];
@@ -1056,27 +1119,26 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
       SITK_RING_ROWS8(vf, sb + lo.row[0], sb + lo.row[1], 8192);
 #pragma unroll
       for (int j = 0; j < QT; ++j) {
-        f32x4 s[4], dp[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            s[i] = Mma<bf16>::mma(kf[i][ks], qf[j][ks], s[i]);
-            dp[i] = Mma<bf16>::mma(vf[i][ks], dof[j][ks], dp[i]);
-          }
+        f32x4 s[4], dp[4];                                // row constants start the accumulators
+        const f32x4 s0 = splat4(Lq[j]), d0 = splat4(ndl[j]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          f32x4 x = s[i] * c - Lq[j];
+          s[i] = Mma<bf16>::mma(kf[i][0], qf[j][0], s0);
+          dp[i] = Mma<bf16>::mma(vf[i][0], dof[j][0], d0);
+          s[i] = Mma<bf16>::mma(kf[i][1], qf[j][1], s[i]);
+          dp[i] = Mma<bf16>::mma(vf[i][1], dof[j][1], dp[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 x;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
-            x[jj] = fast_exp2(x[jj]);
+            x[jj] = fast_exp2(s[i][jj]);
             if constexpr (TAIL) {
               if (t * 64 + 16 * i + 4 * fq + jj >= N) x[jj] = 0.f;
             }
           }
-          s[i] = x * (dp[i] + ndl[j]);                    // dS / scale: the scale is applied once, to dQ
+          s[i] = x * dp[i];                               // dS / scale: the scale is applied once, to dQ
         }
         pf[j][0] = pack_pair(s[0], s[1]);
         pf[j][1] = pack_pair(s[2], s[3]);
@@ -1128,10 +1190,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
   dma.init(base + h * 64, ld, d_o + (size_t)b * N * I + h * 64, (size_t)I, wave, lane);
   float* sL = reinterpret_cast<float*>(smem + RING_STAGES * RING_STAGE);
   float* sD = sL + RING_MAX_N;
-  const float inv_scale = 1.0f / scale;
   for (int r = tid; r < nqt * 64; r += WAVES * 64) {
     const size_t ridx = ((size_t)b * H + h) * N + min(r, N - 1);
-    sL[r] = r < N ? -lse[ridx] * inv_scale : -INFINITY;
+    sL[r] = r < N ? -lse[ridx] * kLog2e : -INFINITY;
     sD[r] = r < N ? -delta[ridx] : 0.f;
   }
   dma.issue_any(smem, 0, N);
@@ -1148,11 +1209,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int eo = ks * 32 + fq * 8;
-      kf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo);
+      kf[j][ks] = scale_frag(*reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo), scale * kLog2e);
       vf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + eo);
     }
   }
-  const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_bf16(lane);
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lstat = lbase + RING_STAGES * RING_STAGE + 16 * fq;      // + t * 256 + i * 64 ; sD at + RING_MAX_N * 4
@@ -1181,27 +1241,28 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
       u32x4 qr[4][2], dor[4][2];
       SITK_RING_ROWS8(qr, sb + lo.row[0], sb + lo.row[1], 0);
       SITK_RING_ROWS8(dor, sb + lo.row[0], sb + lo.row[1], 8192);
+      f32x4 sl[4], sd[4];                                 // -lse log2 e and -delta of the tile's 64 queries: the initial accumulators
+      asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\t"
+                   "ds_read_b128 %3, %8 offset:192\n\tds_read_b128 %4, %8 offset:8192\n\tds_read_b128 %5, %8 offset:8256\n\t"
+                   "ds_read_b128 %6, %8 offset:8320\n\tds_read_b128 %7, %8 offset:8384\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(sl[0]), "=&v"(sl[1]), "=&v"(sl[2]), "=&v"(sl[3]), "=&v"(sd[0]), "=&v"(sd[1]), "=&v"(sd[2]), "=&v"(sd[3])
+                   : "v"(st)
+                   : "memory");
 #pragma unroll
       for (int j = 0; j < QT; ++j) {
         f32x4 s[4], dp[4];
-        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:64\n\tds_read_b128 %2, %8 offset:128\n\t"
-                     "ds_read_b128 %3, %8 offset:192\n\tds_read_b128 %4, %8 offset:8192\n\tds_read_b128 %5, %8 offset:8256\n\t"
-                     "ds_read_b128 %6, %8 offset:8320\n\tds_read_b128 %7, %8 offset:8384\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(s[0]), "=&v"(s[1]), "=&v"(s[2]), "=&v"(s[3]), "=&v"(dp[0]), "=&v"(dp[1]), "=&v"(dp[2]), "=&v"(dp[3])
-                     : "v"(st)
-                     : "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            s[i] = Mma<bf16>::mma(qr[i][ks], kf[j][ks], s[i]);
-            dp[i] = Mma<bf16>::mma(dor[i][ks], vf[j][ks], dp[i]);
-          }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          f32x4 x = s[i] * c;
+          s[i] = Mma<bf16>::mma(qr[i][0], kf[j][0], sl[i]);
+          dp[i] = Mma<bf16>::mma(dor[i][0], vf[j][0], sd[i]);
+          s[i] = Mma<bf16>::mma(qr[i][1], kf[j][1], s[i]);
+          dp[i] = Mma<bf16>::mma(dor[i][1], vf[j][1], dp[i]);
+        }
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(x[jj]);
+        for (int i = 0; i < 4; ++i) {
+          f32x4 x;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(s[i][jj]);
           s[i] = x;
           dp[i] = x * dp[i];                              // dS / scale: the scale is applied once, to dK
         }
@@ -1247,41 +1308,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
     }
 }
 
-// waves per workgroup (4..8) that cover ceil(N / 16) tiles (qt per wave) with the least padding; ties -> more waves
-static int ring_waves(int N, int qt, int* nblocks) {
-  const int tiles = (N + 15) / 16;
-  int best = 8, best_pad = 1 << 30;
-  for (int w = 8; w >= 4; --w) {
-    const int nb = (tiles + qt * w - 1) / (qt * w), pad = nb * qt * w - tiles;
-    if (pad < best_pad) { best_pad = pad; best = w; }
-  }
-  *nblocks = (tiles + qt * best - 1) / (qt * best);
-  return best;
-}
+// Launch geometry of the ring kernels: workgroups of FOUR waves (one per SIMD), two 16-row tiles per wave.  Measured at
+// B = 32, N = 1281, H = 6 (tools/attn_bench.py; forward / query side / key side, us): 4 waves x 2 tiles 123 / 158 / 200;
+// 7 x 2 (least padding) 152 / 188 / 232; 8 x 2 150 / 184 / 237; 5 x 2 188 / 216 / 289; 8 x 1 140 / 209 / 250.  Small
+// workgroups win although they re-stream K / V more often and pad more (88 tile slots for 81 tiles): three (forward) or two
+// of them share a CU, each SIMD then holds waves of DIFFERENT barrier domains, and one workgroup's MFMA phase runs under
+// another's softmax and waits.  (At N = 321 the sequence-resident kernels stay ahead: 17 / 22 / 27 us against 19 / 26 / 33.)
+constexpr int RING_W = 4, RING_QT = 2;
+static int ring_blocks(int N) { return ((N + 15) / 16 + RING_W * RING_QT - 1) / (RING_W * RING_QT); }
 static bool ring_supported(int N) { return N > RES_MAX_N && N <= RING_MAX_N; }
-// tiles per wave of the three ring kernels (SITK_RING_QT=fwd,dq,dkv overrides: timing experiments)
-static void ring_qt(int (&qt)[3]) {
-  static int v[3] = {0, 0, 0};
-  if (!v[0]) {
-    int a = 2, b = 2, c = 2;
-    if (const char* e = getenv("SITK_RING_QT")) sscanf(e, "%d,%d,%d", &a, &b, &c);
-    v[0] = a == 1 ? 1 : 2; v[1] = b == 1 ? 1 : 2; v[2] = c == 1 ? 1 : 2;
-  }
-  qt[0] = v[0]; qt[1] = v[1]; qt[2] = v[2];
-}
-
-#define SITK_RING_LAUNCH_Q(KERNEL, W, QT, MINW, GRID, S, ...)                                               \
-  switch (W) {                                                                                              \
-    case 4: hipLaunchKernelGGL((KERNEL<4, QT, MINW>), GRID, dim3(256), 0, S, __VA_ARGS__); break;           \
-    case 5: hipLaunchKernelGGL((KERNEL<5, QT, MINW>), GRID, dim3(320), 0, S, __VA_ARGS__); break;           \
-    case 6: hipLaunchKernelGGL((KERNEL<6, QT, MINW>), GRID, dim3(384), 0, S, __VA_ARGS__); break;           \
-    case 7: hipLaunchKernelGGL((KERNEL<7, QT, MINW>), GRID, dim3(448), 0, S, __VA_ARGS__); break;           \
-    default: hipLaunchKernelGGL((KERNEL<8, QT, MINW>), GRID, dim3(512), 0, S, __VA_ARGS__); break;          \
-  }
-// MINW1 / MINW2: minimum waves per SIMD (register budget) of the one- and two-tiles-per-wave builds
-#define SITK_RING_LAUNCH(KERNEL, W, QT, MINW1, MINW2, GRID, S, ...)                                         \
-  if ((QT) == 1) { SITK_RING_LAUNCH_Q(KERNEL, W, 1, MINW1, GRID, S, __VA_ARGS__) }                          \
-  else { SITK_RING_LAUNCH_Q(KERNEL, W, 2, MINW2, GRID, S, __VA_ARGS__) }
 
 template <typename T>
 static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
@@ -1292,12 +1327,9 @@ static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, fl
       return check_launch("attention_fwd_res");
     }
     if (ring_supported(N)) {
-      int nqb, qt[3];
-      ring_qt(qt);
-      const int w = ring_waves(N, qt[0], &nqb);
-      const bf16* q_ = reinterpret_cast<const bf16*>(qkv);
-      bf16* o_ = reinterpret_cast<bf16*>(o);
-      SITK_RING_LAUNCH(attn_fwd_ring_kernel, w, qt[0], 4, 3, dim3(nqb * H * B), s, q_, o_, lse, N, H, scale, nqb);
+      const int nqb = ring_blocks(N);
+      hipLaunchKernelGGL((attn_fwd_ring_kernel<RING_W, RING_QT, 3>), dim3(nqb * H * B), dim3(RING_W * 64), 0, s,
+                         reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(o), lse, N, H, scale, nqb);
       return check_launch("attention_fwd_ring");
     }
   }
@@ -1341,19 +1373,16 @@ static int run_bwd(const void* qkv, const void* o, const void* d_o, const float*
       return check_launch("attention_bwd_dkv_res");
     }
     if (ring_supported(N)) {
-      int nb, qt[3];
-      ring_qt(qt);
+      const int nb = ring_blocks(N);
       const bf16 *q_ = reinterpret_cast<const bf16*>(qkv), *o_ = reinterpret_cast<const bf16*>(o), *do_ = reinterpret_cast<const bf16*>(d_o);
       bf16* dq_ = reinterpret_cast<bf16*>(dqkv);
-      if (phases & 1) {
-        const int w = ring_waves(N, qt[1], &nb);
-        SITK_RING_LAUNCH(attn_bwd_dq_ring_kernel, w, qt[1], 3, 2, dim3(nb * H * B), s, q_, o_, do_, lse, delta, dq_, N, H, scale, nb);
-      }
+      if (phases & 1)
+        hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<RING_W, RING_QT, 2>), dim3(nb * H * B), dim3(RING_W * 64), 0, s, q_, o_, do_, lse,
+                           delta, dq_, N, H, scale, nb);
       SITK_LAUNCH_CHECK("attention_bwd_dq_ring");
-      if (phases & 2) {
-        const int w = ring_waves(N, qt[2], &nb);
-        SITK_RING_LAUNCH(attn_bwd_dkv_ring_kernel, w, qt[2], 3, 2, dim3(nb * H * B), s, q_, do_, lse, delta, dq_, N, H, scale, nb);
-      }
+      if (phases & 2)
+        hipLaunchKernelGGL((attn_bwd_dkv_ring_kernel<RING_W, RING_QT, 2>), dim3(nb * H * B), dim3(RING_W * 64), 0, s, q_, do_, lse,
+                           delta, dq_, N, H, scale, nb);
       return check_launch("attention_bwd_dkv_ring");
     }
   }
