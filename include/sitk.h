@@ -100,6 +100,9 @@ typedef struct {
 #define SITK_EPI_BIAS_RES 1  /* out(f32) = acc + bias + aux(f32)   residual / pos-embedding add   */
 #define SITK_EPI_BIAS_GELU 2 /* out = u = acc + bias ; out2 = gelu_erf(u)          both `dtype`   */
 #define SITK_EPI_DGELU 3     /* out = acc * gelu_erf'(aux)          aux = saved u, both `dtype`   */
+#define SITK_EPI_MPP_LOSS 4  /* models/mpp.py:129,132 in one pass: out(f32) = acc + bias (batch_out); on rows with
+                                row_flags[m] != 0: *loss += sum (out - aux)^2 * loss_scale and out2 = 2 (out - aux)
+                                loss_scale, out2 = 0 on the other rows (out2: `dtype`, leading dim ldo2, row map omap) */
 
 typedef struct {
   int M, N, K;
@@ -119,6 +122,10 @@ typedef struct {
   const void* aux;
   int ldaux;
   sitk_rowmap auxmap;
+  const uint8_t* row_flags; /* SITK_EPI_MPP_LOSS only: (M) */
+  float* loss;              /* ... scalar, accumulated  */
+  float loss_scale;         /* ... 1 / (masked rows * N) */
+  int ldo2;                 /* ... leading dim of out2   */
 } sitk_gemm_desc;
 
 int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream);
@@ -128,7 +135,9 @@ int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream);
  * depends on arrival order in the last bits).  sitk_gemm_wgrad_group_ws on eligible shapes (the encoder's): 128 x 192
  * tiles, no float atomics -- a tile that covers all tokens is added straight into dW, token-split tiles go through a
  * slab in the workspace and a fixed-order reduction.
- *   dY (M, N): `dtype` or fp32 (dy_is_f32); X (M, K) `dtype`; row maps as above.               */
+ *   dY (M, N): `dtype` or fp32 (dy_is_f32); X (M, K) `dtype`; row maps as above.  The large-tile path reads whole
+ * 16-byte vectors: when N (or K) is not a multiple of 8, columns [N, round_up(N, 8)) of dY (X) must exist (lddy / ldx
+ * cover them) and hold zeros.                                                                    */
 typedef struct {
   int M, N, K;
   const void* dY;
@@ -315,6 +324,14 @@ int sitk_encoder_bwd_embed(const sitk_encoder_cfg* cfg, const sitk_layer_params*
                            const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
                            size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,
                            const sitk_wgrad_desc* embed, void* dx_c, int* embed_done, sitk_stream_t stream);
+/* The same with n_extra more weight-gradient problems (fully specified; e.g. to_original of models/mpp.py:66,129, whose
+ * operands exist before the encoder's backward starts) taken into that one launch: *extra_done = 1 when they were, 0
+ * when the caller has to run them itself (sitk_gemm_wgrad).                                                          */
+int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_layer_params* params,
+                           const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
+                           size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,
+                           const sitk_wgrad_desc* embed, void* dx_c, int* embed_done, const sitk_wgrad_desc* extra,
+                           int n_extra, int* extra_done, sitk_stream_t stream);
 
 /* Row 0 of every sample of the residual stream: x[b, 0, :] = cls_token + pos_embedding[0, :]
  * (models/sit.py:70-73; rows 1..P come from the patch-embedding GEMM's BIAS_RES epilogue).      */
@@ -358,6 +375,24 @@ int sitk_colsum_f32_dup(const float* in, int64_t rows, int cols, int ld, float* 
 int sitk_mpp_corrupt(const float* tokens, const uint8_t* masked, const uint8_t* swap_draw,
                      const int32_t* random_patches, const uint8_t* replace_draw, const float* mask_token,
                      void* corrupted, int B, int P, int K, int ld, int dtype, sitk_stream_t stream);
+
+/* The engine's form of the same step (no host-drawn tensors, nothing but the surfaces is read twice):
+ * sitk_mpp_draw fills masked / swap_draw / random_patches / replace_draw (shapes as above) and replaced_full (B, P + 1) uint8
+ * (masked & replace_draw at token p + 1, 0 at the cls token) from a Philox4x32-10 stream; state = 2 x uint64 in device memory
+ * {seed, draws so far}.  masked has EXACTLY n_mask ones per sample (the n_mask largest of P uniform scores: models/mpp.py:25-33);
+ * swap_draw = U < p_swap, random_patches uniform in [0, P), replace_draw = U < p_replace (models/mpp.py:36-43,95-110).  Same
+ * distribution as the reference's draws, not the same stream: parity tests replay the reference's captured tensors through
+ * sitk_mpp_corrupt instead.  P <= 2048.
+ * sitk_mpp_gather_corrupt = sitk_gather_tokens_idx (sample_idx / mean / stdv may be NULL) + sitk_mpp_corrupt in one pass:
+ * clean (B*P, V*C) fp32 and corrupted (B*P, ld) `dtype` are both written; when state != NULL it also advances state[1],
+ * so the next sitk_mpp_draw (e.g. the next replay of a captured graph) draws fresh masks.                                  */
+int sitk_mpp_draw(const uint64_t* state, uint8_t* masked, uint8_t* swap_draw, int32_t* random_patches, uint8_t* replace_draw,
+                  uint8_t* replaced_full, int B, int P, int n_mask, float p_swap, float p_replace, sitk_stream_t stream);
+int sitk_mpp_gather_corrupt(const float* x, const uint16_t* table_pv, const int32_t* sample_idx, const float* mean,
+                            const float* stdv, const uint8_t* masked, const uint8_t* swap_draw, const int32_t* random_patches,
+                            const uint8_t* replace_draw, const float* mask_token, float* clean, void* corrupted,
+                            uint64_t* state, int B, int n_vertices, int C, int P, int V, int ld, int dtype,
+                            sitk_stream_t stream);
 /* loss[0] += sum_{masked rows} (out - tokens)^2 / (n_masked_total * K); dout likewise (0 elsewhere). */
 int sitk_mpp_loss_fwd_bwd(const float* out, const float* tokens, const uint8_t* masked, float* loss,
                           float* dout, int64_t rows, int K, int64_t n_masked_total, sitk_stream_t stream);

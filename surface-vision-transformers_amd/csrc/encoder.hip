@@ -202,7 +202,7 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
     L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg.data(), 4 * nslot, c.dtype);
     if (L.scratch.wgrad_ws_bytes < sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype))     // a one-layer slice splits 12 ways
       L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype);
-    if (L.scratch.wgrad_ws_bytes) L.scratch.wgrad_ws_bytes += (size_t)64 * 128 * 192 * 4;   // + the patch embedding's tiles (sitk_encoder_bwd_embed)
+    if (L.scratch.wgrad_ws_bytes) L.scratch.wgrad_ws_bytes += (size_t)128 * 128 * 192 * 4;   // + the patch embedding's and the caller's extra tiles (sitk_encoder_bwd_extra)
     L.scratch.wgrad_ws = stake(L.scratch.wgrad_ws_bytes);
   }
   L.scratch.ln_partial_floats = sitk_layernorm_bwd_partial_floats((int64_t)R, (int)D);
@@ -370,7 +370,17 @@ extern "C" int sitk_encoder_bwd_embed(const sitk_encoder_cfg* cfg, const sitk_la
                                       const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
                                       size_t scratch_bytes, int layer_begin, int layer_end, const sitk_wgrad_desc* embed,
                                       void* dx_c, int* embed_done, sitk_stream_t stream) {
+  return sitk_encoder_bwd_extra(cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, embed, dx_c,
+                                embed_done, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
+                                      const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
+                                      size_t scratch_bytes, int layer_begin, int layer_end, const sitk_wgrad_desc* embed,
+                                      void* dx_c, int* embed_done, const sitk_wgrad_desc* extra, int n_extra, int* extra_done,
+                                      sitk_stream_t stream) {
   if (embed_done) *embed_done = 0;
+  if (extra_done) *extra_done = 0;
   SITK_TRY(check_cfg(cfg));
   SITK_REQUIRE(P && G && x_in && dx && acts && scratch, "encoder_bwd: null pointer");
   const sitk_encoder_cfg& c = *cfg;
@@ -470,6 +480,17 @@ extern "C" int sitk_encoder_bwd_embed(const sitk_encoder_cfg* cfg, const sitk_la
     take_embed = sitk_gemm_wgrad_group_ws_bytes(wg_all.data(), (int)wg_all.size(), dt) <= S.wgrad_ws_bytes;
     if (!take_embed) wg_all.pop_back();          // (cannot happen with make_layout's sizing; the caller then runs it)
     else *embed_done = 1;
+  }
+  // caller-supplied problems (to_original of the MPP head): taken when the slice ends at layer 0, all of them take the
+  // large-tile path and the slab still has room (make_layout sizes it for the encoder's own tiles + 64 more)
+  if (extra && n_extra > 0 && extra_done && layer_begin == 0 && S.wg_batch && (int)wg_all.size() + n_extra <= 52) {
+    const size_t before = wg_all.size();
+    wg_all.insert(wg_all.end(), extra, extra + n_extra);
+    if (sitk_gemm_wgrad_group_ws_bytes(extra, n_extra, dt) > 0 &&
+        sitk_gemm_wgrad_group_ws_bytes(wg_all.data(), (int)wg_all.size(), dt) <= S.wgrad_ws_bytes)
+      *extra_done = 1;
+    else
+      wg_all.resize(before);
   }
   if (S.wg_batch && !wg_all.empty())
     SITK_TRY(sitk_gemm_wgrad_group_ws(wg_all.data(), (int)wg_all.size(), dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));

@@ -275,6 +275,113 @@ __global__ __launch_bounds__(256) void mpp_corrupt_kernel(const float* __restric
   }
 }
 
+// ---- the four random tensors of models/mpp.py:25-43,85-112 drawn ON THE DEVICE (engine path) -------------------------
+// Philox4x32-10 (Salmon et al., SC'11) keyed by the 64-bit seed; counter = (draw index, element, stream id, sample).
+// state[0] = seed, state[1] = number of draws made so far: read by every block here, advanced by the kernel that
+// consumes the flags (sitk_mpp_gather_corrupt), i.e. after this launch has completed -- so a captured hipGraph draws new
+// masks at every replay.
+SITK_DEV void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+SITK_DEV void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+SITK_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0, 1), 24 bits
+
+// One workgroup per sample.  corrupted_sequence: EXACTLY n_mask patches per sample, the n_mask largest of P uniform
+// scores (models/mpp.py:25-33, get_mask_from_prob: rand -> topk -> scatter_), found by ranking (ties by index); swap draw
+// U < p_swap, random_patches uniform in [0, P), replace draw U < p_replace (models/mpp.py:36-43, 95-110).
+constexpr int MPP_MAX_P = 2048;
+__global__ __launch_bounds__(256) void mpp_draw_kernel(const uint64_t* __restrict__ state, uint8_t* __restrict__ masked,
+                                                       uint8_t* __restrict__ swap_draw, int32_t* __restrict__ random_patches,
+                                                       uint8_t* __restrict__ replace_draw, uint8_t* __restrict__ replaced_full,
+                                                       int P, int n_mask, float p_swap, float p_replace) {
+  __shared__ float score[MPP_MAX_P];
+  const int b = blockIdx.x;
+  const uint64_t seed = state[0], draw = state[1];
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int i = threadIdx.x; i < P; i += 256) {
+    uint32_t c[4] = {(uint32_t)draw, (uint32_t)i, (uint32_t)(draw >> 32), (uint32_t)b};
+    philox4x32(c, k0, k1);
+    score[i] = u01(c[0]);
+    const size_t row = (size_t)b * P + i;
+    if (swap_draw) { swap_draw[row] = u01(c[1]) < p_swap; random_patches[row] = (int32_t)(((uint64_t)c[2] * (uint32_t)P) >> 32); }
+    replace_draw[row] = u01(c[3]) < p_replace;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P; i += 256) {
+    const float si = score[i];
+    int rank = 0;
+    for (int j = 0; j < P; ++j) {
+      const float sj = score[j];
+      rank += (sj > si) || (sj == si && j < i);
+    }
+    const size_t row = (size_t)b * P + i;
+    const uint8_t m = rank < n_mask;
+    masked[row] = m;
+    replaced_full[(size_t)b * (P + 1) + 1 + i] = m && replace_draw[row];
+  }
+  if (threadIdx.x == 0) replaced_full[(size_t)b * (P + 1)] = 0;
+}
+
+// Patch gather (tools/preprocessing.py:74-84 + Rearrange, as gather_tokens_kernel) fused with the corruption of
+// models/mpp.py:85-112: one pass writes the clean fp32 tokens (the regression target of models/mpp.py:132) AND the corrupted
+// compute-dtype tokens.  A swapped patch reads the surface through the table row of its random partner (same sample),
+// a replaced one takes mask_token (replacement wins).  Thread (0, 0, 0) advances the draw counter of mpp_draw_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void mpp_gather_corrupt_kernel(const float* __restrict__ x, const uint16_t* __restrict__ table,
+                                                                 const int32_t* __restrict__ sample_idx, const float* __restrict__ mean,
+                                                                 const float* __restrict__ stdv, const uint8_t* __restrict__ masked,
+                                                                 const uint8_t* __restrict__ swap_draw,
+                                                                 const int32_t* __restrict__ random_patches,
+                                                                 const uint8_t* __restrict__ replace_draw,
+                                                                 const float* __restrict__ mask_token, float* __restrict__ clean,
+                                                                 T* __restrict__ corrupted, uint64_t* __restrict__ state, int64_t rows,
+                                                                 int n_vertices, int P, int V, int K, int ld) {
+  if (state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) state[1] += 1;
+  const int slots = ld >> 2;
+  const bool norm = mean != nullptr;
+  const f32x4 mu = norm ? load4(mean) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 sd = norm ? load4(stdv) : f32x4{1.f, 1.f, 1.f, 1.f};
+  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
+    const int p = (int)(row % P);
+    const int64_t b = sample_idx ? (int64_t)sample_idx[row / P] : row / P;
+    const bool m = masked[row] != 0;
+    const bool rep = m && replace_draw[row] != 0;
+    const bool swp = m && !rep && swap_draw != nullptr && swap_draw[row] != 0;
+    const int p2 = swp ? random_patches[row] : p;
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < slots; v += gridDim.x * 256) {
+      f32x4 val = {0.f, 0.f, 0.f, 0.f}, cor = {0.f, 0.f, 0.f, 0.f};
+      if (v < V) {
+        val = *reinterpret_cast<const f32x4*>(x + ((size_t)b * n_vertices + table[(size_t)p * V + v]) * 4);
+        if (norm) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) val[e] = (val[e] - mu[e]) / sd[e];
+        }
+        cor = val;
+        if (rep) {
+          cor = load4(mask_token + 4 * v);
+        } else if (swp) {
+          cor = *reinterpret_cast<const f32x4*>(x + ((size_t)b * n_vertices + table[(size_t)p2 * V + v]) * 4);
+          if (norm) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cor[e] = (cor[e] - mu[e]) / sd[e];
+          }
+        }
+        store4(clean + (size_t)row * K + 4 * v, val);
+      }
+      store4(corrupted + (size_t)row * ld + 4 * v, cor);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void mpp_loss_kernel(const float* __restrict__ out, const float* __restrict__ tokens,
                                                        const uint8_t* __restrict__ masked, float* __restrict__ loss,
                                                        float* __restrict__ dout, int64_t rows, int K, float inv_count) {
@@ -555,4 +662,44 @@ extern "C" int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, flo
   hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, state,
                      beta1, beta2, eps, weight_decay, decoupled_wd, grad_scale, zero_grad, n_extra, keep_idx, keep_dst);
   return check_launch("adam_step_dev");
+}
+
+extern "C" int sitk_mpp_draw(const uint64_t* state, uint8_t* masked, uint8_t* swap_draw, int32_t* random_patches,
+                             uint8_t* replace_draw, uint8_t* replaced_full, int B, int P, int n_mask, float p_swap,
+                             float p_replace, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(state && masked && replace_draw && replaced_full, "mpp_draw: null pointer");
+  SITK_REQUIRE((swap_draw == nullptr) == (random_patches == nullptr), "mpp_draw: swap_draw and random_patches go together");
+  SITK_REQUIRE(B > 0 && P > 0 && P <= MPP_MAX_P && n_mask >= 0 && n_mask <= P, "mpp_draw: bad shape (P <= %d)", MPP_MAX_P);
+  hipLaunchKernelGGL(mpp_draw_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), state, masked, swap_draw,
+                     random_patches, replace_draw, replaced_full, P, n_mask, p_swap, p_replace);
+  return check_launch("mpp_draw");
+}
+
+extern "C" int sitk_mpp_gather_corrupt(const float* x, const uint16_t* table_pv, const int32_t* sample_idx, const float* mean,
+                                       const float* stdv, const uint8_t* masked, const uint8_t* swap_draw,
+                                       const int32_t* random_patches, const uint8_t* replace_draw, const float* mask_token,
+                                       float* clean, void* corrupted, uint64_t* state, int B, int n_vertices, int C, int P, int V,
+                                       int ld, int dtype, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x && table_pv && masked && replace_draw && mask_token && clean && corrupted, "mpp_gather_corrupt: null pointer");
+  SITK_REQUIRE((swap_draw == nullptr) == (random_patches == nullptr), "mpp_gather_corrupt: swap_draw and random_patches go together");
+  SITK_REQUIRE((mean == nullptr) == (stdv == nullptr), "mpp_gather_corrupt: mean and std go together");
+  SITK_REQUIRE(C == 4, "mpp_gather_corrupt: channels-last gather is specialised for num_channels == 4 (got %d)", C);
+  SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "mpp_gather_corrupt: bad shape");
+  const int K = V * C;
+  SITK_REQUIRE(ld >= K && ld % 4 == 0, "mpp_gather_corrupt: ld=%d must be >= V*C=%d and a multiple of 4", ld, K);
+  const int64_t rows = (int64_t)B * P;
+  dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SITK_BF16)
+    hipLaunchKernelGGL((mpp_gather_corrupt_kernel<bf16>), grid, dim3(256), 0, s, x, table_pv, sample_idx, mean, stdv, masked, swap_draw,
+                       random_patches, replace_draw, mask_token, clean, reinterpret_cast<bf16*>(corrupted), state, rows,
+                       n_vertices, P, V, K, ld);
+  else if (dtype == SITK_F32)
+    hipLaunchKernelGGL((mpp_gather_corrupt_kernel<float>), grid, dim3(256), 0, s, x, table_pv, sample_idx, mean, stdv, masked, swap_draw,
+                       random_patches, replace_draw, mask_token, clean, reinterpret_cast<float*>(corrupted), state, rows,
+                       n_vertices, P, V, K, ld);
+  else { set_error("mpp_gather_corrupt: bad dtype %d", dtype); return SITK_ERR_INVALID; }
+  return check_launch("mpp_gather_corrupt");
 }

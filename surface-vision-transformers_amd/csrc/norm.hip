@@ -176,36 +176,49 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
 }
 
 // out[c] += sum_r in[r][c], optional row flags (row counted iff fa[r] && (fb == null || fb[r])).
+// A workgroup covers a group of 4 * CG columns (CG threads across) with 256 / CG row lanes, sums its row range, folds
+// the row lanes through LDS and issues ONE atomic per column: few workgroups per column group, because float atomics
+// of many workgroups on the same few addresses serialise (2 048 workgroups on 192 addresses took 184 us for 15.8 MB).
 template <typename TI>
 __global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ in, int ld, const uint8_t* __restrict__ fa,
                                                      const uint8_t* __restrict__ fb, int64_t rows, int cols,
                                                      int64_t rows_per_block, float* __restrict__ out,
-                                                     float* __restrict__ out2 = nullptr, int cols2 = 0) {
-  // thread -> 4 consecutive columns; grid.x covers column groups of 1024, grid.y covers row blocks
-  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-  if (c4 >= cols) return;
+                                                     float* __restrict__ out2, int cols2, int cg) {
+  __shared__ f32x4 red[256];
+  const int tc = threadIdx.x % cg, tr = threadIdx.x / cg, nr = 256 / cg;
+  const int c4 = (blockIdx.x * cg + tc) * 4;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = std::min<int64_t>(rows, r0 + rows_per_block);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int64_t r = r0; r < r1; ++r) {
-    if (fa && !(fa[r] && (!fb || fb[r]))) continue;
-    s += load4(in + r * ld + c4);
-  }
+  if (c4 < cols && tr < nr)
+    for (int64_t r = r0 + tr; r < r1; r += nr) {
+      if (fa && !(fa[r] && (!fb || fb[r]))) continue;
+      s += load4(in + r * ld + c4);
+    }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (tr == 0 && c4 < cols) {
+    for (int k = 1; k < nr; ++k) s += red[k * cg + tc];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out + c4 + e, s[e]);
-  if (out2 && c4 < cols2) {      // the first cols2 sums once more (d cls_token = d pos_embedding[0])
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out + c4 + e, s[e]);
+    if (out2 && c4 < cols2) {      // the first cols2 sums once more (d cls_token = d pos_embedding[0])
 #pragma unroll
-    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out2 + c4 + e, s[e]);
+      for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out2 + c4 + e, s[e]);
+    }
   }
 }
 
 template <typename TI>
 static int launch_colsum(const TI* in, int ld, const uint8_t* fa, const uint8_t* fb, int64_t rows, int cols,
                          float* out, hipStream_t s, float* out2 = nullptr, int cols2 = 0) {
-  const int gx = cdiv(cols, 1024);
-  int64_t gy = std::max<int64_t>(1, std::min<int64_t>(cdiv64(rows, 8), 2048 / gx));
+  const int c4n = cols / 4;
+  int cg = 256;                                             // threads across columns: a power of two covering cols / 4, <= 256
+  while (cg / 2 >= c4n && cg > 1) cg /= 2;
+  const int gx = cdiv(c4n, cg);
+  // row ranges: enough workgroups to fill the chip once, at most ~64 atomics per output address
+  int64_t gy = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cdiv64(rows, 256 / cg), 64), std::max(1, 512 / gx)));
   const int64_t rpb = cdiv64(rows, gy);
   gy = cdiv64(rows, rpb);
-  hipLaunchKernelGGL((colsum_kernel<TI>), dim3(gx, (unsigned)gy), dim3(256), 0, s, in, ld, fa, fb, rows, cols, rpb, out, out2, cols2);
+  hipLaunchKernelGGL((colsum_kernel<TI>), dim3(gx, (unsigned)gy), dim3(256), 0, s, in, ld, fa, fb, rows, cols, rpb, out, out2, cols2, cg);
   return check_launch("colsum");
 }
 

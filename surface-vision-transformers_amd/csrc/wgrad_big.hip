@@ -370,7 +370,9 @@ __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, cons
 }
 
 static bool wb_eligible(const sitk_wgrad_desc& d) {
-  const bool align = d.N % 8 == 0 && d.K % 8 == 0 && d.lddy % 8 == 0 && d.ldx % 8 == 0;
+  // 16-byte operand vectors: a column count that is not a multiple of 8 needs its zero-filled tail inside the row pitch
+  const bool align = d.N % 4 == 0 && d.K % 4 == 0 && d.lddy % 8 == 0 && d.ldx % 8 == 0 && d.lddy >= ((d.N + 7) & ~7) &&
+                     d.ldx >= ((d.K + 7) & ~7);
   const bool plain = (d.dymap.group == 0 || d.dymap.group % 64 == 0) && d.xmap.group == 0 && !d.dy_is_f32;
   return align && plain && d.M >= 2048 && (d.K % 192 == 0 || d.N % 192 == 0);
 }

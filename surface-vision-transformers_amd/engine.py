@@ -166,11 +166,18 @@ class TrainEngine:
             self.wo_t = torch.empty((D, ops.pad8(K)), dtype=self.tdt, device=dev)
             self.we_t = torch.empty((K, D), dtype=self.tdt, device=dev)      # embedding weight^T (for d mask_token)
             self.out = torch.empty((B * P, K), dtype=f32, device=dev)
-            self.dout = torch.empty((B * P, K), dtype=f32, device=dev)
+            self.dout_c = torch.zeros((B * P, ld), dtype=self.tdt, device=dev)   # d batch_out, compute dtype; pad columns stay 0
+            self._extra_wgrad_done = False
             self.masked = torch.zeros((B * P,), dtype=torch.uint8, device=dev)
+            self.repl = torch.zeros((B * P,), dtype=torch.uint8, device=dev)
+            self.swap = torch.zeros((B * P,), dtype=torch.uint8, device=dev) if ssl.swap_prob > 0 else None
+            self.rpatch = torch.zeros((B * P,), dtype=torch.int32, device=dev) if ssl.swap_prob > 0 else None
             self.replaced_full = torch.zeros((B, N), dtype=torch.uint8, device=dev)
             self.rsum = self.fp.extra((1, D))
-            self.dmt = torch.zeros((1, K), dtype=f32, device=dev)
+            # Philox stream of the on-device draws: {seed, draws so far}; every rank its own seed
+            rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+            self.rng_state = torch.tensor([(torch.initial_seed() + 0x9E3779B97F4A7C15 * rank) & 0x7FFFFFFFFFFFFFFF, 0],
+                                          dtype=torch.int64, device=dev)
         if optimizer == "sgd":
             self.state = [torch.zeros_like(self.fp.flat)] if momentum != 0 else [None]
         elif optimizer in ("adam", "adamw"):
@@ -260,52 +267,55 @@ class TrainEngine:
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
         if self.keep_grads:
             self.fp.grad_all.zero_()                    # gradients + loss + padded embedding gradient + rsum
+        # the four random tensors of models/mpp.py:25-43,95-110 are drawn on the device (Philox; same distribution, not the
+        # reference's stream: the parity path replays the reference's generator order through sitk.models.mpp instead)
+        p_swap = ssl.swap_prob / (1 - ssl.replace_prob) if ssl.swap_prob > 0 else 0.0
+        rt.check(L.sitk_mpp_draw(self.rng_state.data_ptr(), self.masked.data_ptr(), rt.ptr(self.swap), rt.ptr(self.rpatch),
+                                 self.repl.data_ptr(), self.replaced_full.data_ptr(), B, P, self.n_mask, p_swap,
+                                 ssl.replace_prob, s))
+        mt = ssl.mask_token.data_ptr()
         if self.layout == "surface":
-            self._gather(self.tok32, K, rt.F32)
+            # gather + corruption in one pass: clean fp32 tokens (the regression target) and corrupted compute-dtype tokens
+            mean, std = (self.norm[0].data_ptr(), self.norm[1].data_ptr()) if self.norm else (None, None)
+            src = self.dataset[0] if self.dataset is not None else self.inp
+            rt.check(L.sitk_mpp_gather_corrupt(src.data_ptr(), self.table.data_ptr(),
+                                               self.idx.data_ptr() if self.dataset is not None else None, mean, std,
+                                               self.masked.data_ptr(), rt.ptr(self.swap), rt.ptr(self.rpatch), self.repl.data_ptr(),
+                                               mt, self.tok32.data_ptr(), self.tokens.data_ptr(), self.rng_state.data_ptr(), B,
+                                               40962, self.Cc, P, self.V, ld, dt, s))
         else:
             rt.check(L.sitk_patchify(self.inp.data_ptr(), self.tok32.data_ptr(), B, self.Cc, P, self.V, K, rt.F32, s))
-        # on-device draws (statistically equivalent to models/mpp.py:25-43; the parity path replays
-        # the reference's CPU/GPU generator order through sitk.models.mpp instead)
-        dev = self.device
-        scores = torch.rand((B, P), device=dev)
-        picked = scores.topk(self.n_mask, dim=-1).indices
-        masked = torch.zeros((B, P), device=dev).scatter_(1, picked, 1).bool()
-        self.masked.copy_(masked.reshape(-1))
-        swap = rpatch = None
-        if ssl.swap_prob > 0:
-            swap = (torch.rand((B, P), device=dev) < ssl.swap_prob / (1 - ssl.replace_prob)).reshape(-1).to(torch.uint8)
-            rpatch = torch.randint(0, P, (B * P,), device=dev, dtype=torch.int32)
-        repl = torch.rand((B, P), device=dev) < ssl.replace_prob
-        self.replaced_full[:, 1:] = (masked & repl).to(torch.uint8)
-        self.last_randoms = {"corrupted_sequence": masked, "replace_draw": repl}
-        if swap is not None:
-            self.last_randoms.update(swap_draw=swap.view(B, P).bool(), random_patches=rpatch.view(B, P))
-        rt.check(L.sitk_mpp_corrupt(self.tok32.data_ptr(), self.masked.data_ptr(), rt.ptr(swap), rt.ptr(rpatch),
-                                    repl.reshape(-1).to(torch.uint8).data_ptr(), ssl.mask_token.data_ptr(),
-                                    self.tokens.data_ptr(), B, P, K, ld, dt, s))
+            rt.check(L.sitk_mpp_corrupt(self.tok32.data_ptr(), self.masked.data_ptr(), rt.ptr(self.swap), rt.ptr(self.rpatch),
+                                        self.repl.data_ptr(), mt, self.tokens.data_ptr(), B, P, K, ld, dt, s))
+            self.rng_state[1:2] += 1
         self._embed_forward(self.tokens)
         ops.encoder_fwd(self.cfg, self.Pa, self.x0, self.xL, self.acts, self.scratch, save=True)
         # to_original on tokens 1..P (models/mpp.py:129) and masked MSE (models/mpp.py:132)
         lo = ssl.to_original
         rt.check(L.sitk_stage_weight(lo.weight.data_ptr(), K, D, self.wo_c.data_ptr(), D, self.wo_t.data_ptr(),
                                      self.wo_t.shape[1], dt, s))
-        ops.gemm_nt(self.xL, self.wo_c, self.out, dt, M=B * P, N=K, K=D, bias=lo.bias.data, amap=(P, N, 1))
-        rt.check(L.sitk_mpp_loss_fwd_bwd(self.out.data_ptr(), self.tok32.data_ptr(), self.masked.data_ptr(),
-                                         self.loss_acc.data_ptr(), self.dout.data_ptr(), B * P, K, B * self.n_mask, s))
-        g = self.fp.g
-        # d to_original: X = encoder output rows 1..P (fp32 -> compute dtype copy)
+        # batch_out, the masked squared error and its gradient (compute dtype) leave ONE GEMM
+        ops.gemm_nt(self.xL, self.wo_c, self.out, dt, M=B * P, N=K, K=D, epilogue=ops.EPI_MPP_LOSS, bias=lo.bias.data,
+                    aux=self.tok32, out2=self.dout_c, amap=(P, N, 1), row_flags=self.masked, loss=self.loss_acc,
+                    loss_scale=1.0 / (B * self.n_mask * K))
+        # d to_original: X = encoder output rows 1..P (fp32 -> compute dtype copy); the weight gradient itself joins the
+        # encoder's one weight-gradient launch (sitk_encoder_bwd_extra), see _backward_slice / _finish_backward
         rt.check(L.sitk_cast_rows(self.xL.data_ptr() + 4 * D, N * D, self.enc_out.data_ptr(), P * D, B, P * D, dt, s))
-        ops.gemm_wgrad(self.dout, self.enc_out, g(lo.weight), dt, db=g(lo.bias), M=B * P, N=K, K=D)
         self.dx.zero_()
-        ops.gemm_nt(self.dout, self.wo_t, self.dx, dt, M=B * P, N=D, K=K, omap=(P, N, 1))
+        ops.gemm_nt(self.dout_c, self.wo_t, self.dx, dt, M=B * P, N=D, K=self.wo_t.shape[1], omap=(P, N, 1))
 
     def _backward_slice(self, lb, le):
         if lb == 0 and self.dx_c is not None:
             # the slice that ends at layer 0 also carries the patch embedding's weight gradient (one launch for all)
             lin = self.sit.to_patch_embedding[1]
-            self._embed_wgrad_done = ops.encoder_bwd_embed(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch,
-                                                           lb, le, self.tokens, self.dW_embed, self.fp.g(lin.bias), self.dx_c,
-                                                           self.P)
+            extra = None
+            if self.task == "mpp":
+                lo = self.ssl.to_original
+                extra = [ops.wgrad_desc(self.dout_c, self.enc_out, self.fp.g(lo.weight), db=self.fp.g(lo.bias), M=self.B * self.P,
+                                        N=self.K, K=self.D)]
+            self._embed_wgrad_done, self._extra_wgrad_done = ops.encoder_bwd_embed(
+                self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, lb, le, self.tokens, self.dW_embed,
+                self.fp.g(lin.bias), self.dx_c, self.P, extra=extra)
             return
         ops.encoder_bwd(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, layer_begin=lb, layer_end=le)
 
@@ -315,10 +325,22 @@ class TrainEngine:
             ssl, sit, L, s = self.ssl, self.sit, rt.lib, self._s()
             D, K, dt = self.D, self.K, self.dtype
             lin = sit.to_patch_embedding[1]
+            if not self._extra_wgrad_done:
+                lo = ssl.to_original
+                ops.gemm_wgrad(self.dout_c, self.enc_out, self.fp.g(lo.weight), dt, db=self.fp.g(lo.bias), M=self.B * self.P,
+                               N=K, K=D)
             ops.masked_colsum(self.dx, self.replaced_full.view(-1), None, self.rsum, "f32")
             rt.check(L.sitk_stage_weight(lin.weight.data_ptr(), D, K, None, 0, self.we_t.data_ptr(), D, dt, s))
-            ops.gemm_nt(self.rsum, self.we_t, self.dmt, dt, M=1, N=K, K=D)
-            self.fp.g(ssl.mask_token).view(-1).copy_(self.dmt.view(-1))
+            ops.gemm_nt(self.rsum, self.we_t, self.fp.g(ssl.mask_token).view(1, K), dt, M=1, N=K, K=D)
+
+    @property
+    def last_randoms(self):
+        """The random tensors of the most recent MPP step (models/mpp.py's names), e.g. to replay it through the modules."""
+        B, P = self.B, self.P
+        out = {"corrupted_sequence": self.masked.view(B, P).bool().clone(), "replace_draw": self.repl.view(B, P).bool().clone()}
+        if self.swap is not None:
+            out.update(swap_draw=self.swap.view(B, P).bool().clone(), random_patches=self.rpatch.view(B, P).long().clone())
+        return out
 
     def set_lr(self, lr):
         """New learning rate from the next step on (a device-side write: captured graphs read it from memory)."""
@@ -418,18 +440,26 @@ class TrainEngine:
         elif x is not None:
             self.load_batch(x, target)
         segs = self._segment_fns()
+        if self.world == 1:
+            # one GPU: nothing happens between the segments -- the whole step is ONE graph (one replay per step)
+            def whole():
+                for fn in segs:
+                    fn()
+                self._finish_backward()
+                self._optimizer()
+            self._run(whole, "step")
+            self.nsteps += 1
+            return self.loss
         for i, fn in enumerate(segs):
             self._run(fn, i)
-            if self.world > 1:
-                lo, hi = self._grad_range_after(i)
-                if i < len(segs) - 1:
-                    self._allreduce(lo, hi)
+            lo, hi = self._grad_range_after(i)
+            if i < len(segs) - 1:
+                self._allreduce(lo, hi)
         self._run(self._finish_backward, "finish")
-        if self.world > 1:
-            self._allreduce(0, self._grad_range_after(len(segs) - 1)[1])
-            for w in self._pending:
-                w.wait()
-            self._pending.clear()
+        self._allreduce(0, self._grad_range_after(len(segs) - 1)[1])
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
         self._run(self._optimizer, "opt")
         self.nsteps += 1
         return self.loss

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import runtime as rt
-from .runtime import BF16, F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_STORE  # noqa: F401
+from .runtime import BF16, F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_MPP_LOSS, EPI_STORE  # noqa: F401
 
 
 def pad8(n):
@@ -86,7 +86,7 @@ def stage_weight(w, dtype, ldc=None, want_c=True, want_t=True):
 
 # ---- GEMMs -----------------------------------------------------------------------------------------
 def gemm_nt(A, W, out, dtype, M=None, N=None, K=None, epilogue=EPI_STORE, bias=None, aux=None, out2=None,
-            amap=None, omap=None, auxmap=None):
+            amap=None, omap=None, auxmap=None, row_flags=None, loss=None, loss_scale=0.0):
     """out[m, n] = sum_k A[m, k] W[n, k] (+ epilogue).  A: compute dtype or fp32; W: compute dtype;
     out: compute dtype or fp32.  2-D tensors with unit inner stride; leading dims from strides."""
     rt.require_cuda(A, W, out, bias, aux, out2)
@@ -102,6 +102,8 @@ def gemm_nt(A, W, out, dtype, M=None, N=None, K=None, epilogue=EPI_STORE, bias=N
     d.out2 = rt.ptr(out2)
     d.bias = rt.ptr(bias)
     d.aux, d.ldaux, d.auxmap = rt.ptr(aux), (aux.stride(0) if aux is not None else 0), _rowmap(auxmap)
+    d.row_flags, d.loss, d.loss_scale = rt.ptr(row_flags), rt.ptr(loss), loss_scale
+    d.ldo2 = out2.stride(0) if out2 is not None else 0
     rt.check(rt.lib.sitk_gemm_nt(C.byref(d), code, rt.stream_ptr()))
     return out
 
@@ -373,19 +375,34 @@ def encoder_bwd(cfg, params, grads, x_in, dx, acts, scratch, layer_begin=0, laye
     return dx
 
 
-def encoder_bwd_embed(cfg, params, grads, x_in, dx, acts, scratch, layer_begin, layer_end, tokens, dW, db, dx_c, P):
+def wgrad_desc(dY, X, dW, db=None, M=None, N=None, K=None, dymap=None):
+    d = rt.WgradDesc()
+    d.M = M if M is not None else dY.shape[0]
+    d.N = N if N is not None else dW.shape[0]
+    d.K = K if K is not None else dW.shape[1]
+    d.dY, d.lddy, d.dy_is_f32, d.dymap = dY.data_ptr(), dY.stride(0), int(dY.dtype == torch.float32), _rowmap(dymap)
+    d.X, d.ldx, d.xmap = X.data_ptr(), X.stride(0), _rowmap(None)
+    d.dW, d.lddw, d.db = dW.data_ptr(), dW.stride(0), rt.ptr(db)
+    return d
+
+
+def encoder_bwd_embed(cfg, params, grads, x_in, dx, acts, scratch, layer_begin, layer_end, tokens, dW, db, dx_c, P, extra=None):
     """encoder_bwd with the patch embedding's weight gradient (dW (D, ld) fp32 += d(x_in)[rows 1..P]^T tokens, db) taken
-    into the slice's one weight-gradient launch.  Returns True when it was (else the caller runs gemm_wgrad)."""
+    into the slice's one weight-gradient launch; `extra`: more WgradDesc problems for the same launch.  Returns
+    (embed taken, extra taken): what was not taken the caller runs itself (gemm_wgrad)."""
     d = rt.WgradDesc()
     d.M, d.N, d.K = tokens.shape[0], dW.shape[0], dW.shape[1]
     d.dY, d.lddy, d.dy_is_f32, d.dymap = 0, dW.shape[0], 0, _rowmap((P, P + 1, 1))
     d.X, d.ldx, d.xmap = tokens.data_ptr(), tokens.stride(0), _rowmap(None)
     d.dW, d.lddw, d.db = dW.data_ptr(), dW.stride(0), rt.ptr(db)
-    done = C.c_int(0)
-    rt.check(rt.lib.sitk_encoder_bwd_embed(C.byref(cfg), params, grads, x_in.data_ptr(), dx.data_ptr(), acts.data_ptr(),
+    done, xdone = C.c_int(0), C.c_int(0)
+    extra = extra or []
+    xarr = (rt.WgradDesc * max(1, len(extra)))(*extra)
+    rt.check(rt.lib.sitk_encoder_bwd_extra(C.byref(cfg), params, grads, x_in.data_ptr(), dx.data_ptr(), acts.data_ptr(),
                                            acts.numel(), scratch.data_ptr(), scratch.numel(), layer_begin, layer_end,
-                                           C.byref(d), dx_c.data_ptr(), C.byref(done), rt.stream_ptr()))
-    return bool(done.value)
+                                           C.byref(d), dx_c.data_ptr(), C.byref(done), xarr, len(extra), C.byref(xdone),
+                                           rt.stream_ptr()))
+    return bool(done.value), bool(xdone.value)
 
 
 def embed_cls_rows(x, cls_token, pos, B, N, D):

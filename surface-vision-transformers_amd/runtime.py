@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SITK_LIB") or os.path.join(_HERE, "libsitk.so")
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
+EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU, EPI_MPP_LOSS = 0, 1, 2, 3, 4
 ABI_VERSION = 7
 
 
@@ -32,7 +32,8 @@ class GemmDesc(C.Structure):
                 ("W", C.c_void_p), ("ldw", C.c_int), ("epilogue", C.c_int),
                 ("out", C.c_void_p), ("ldo", C.c_int), ("out_is_f32", C.c_int), ("omap", RowMap),
                 ("out2", C.c_void_p), ("bias", C.c_void_p),
-                ("aux", C.c_void_p), ("ldaux", C.c_int), ("auxmap", RowMap)]
+                ("aux", C.c_void_p), ("ldaux", C.c_int), ("auxmap", RowMap),
+                ("row_flags", C.c_void_p), ("loss", C.c_void_p), ("loss_scale", C.c_float), ("ldo2", C.c_int)]
 
 
 class WgradDesc(C.Structure):
@@ -96,6 +97,9 @@ _SIGS = {
                                    _P, _Z, _P, _Z, _I, _I, _P]),
     "sitk_encoder_bwd_embed": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,
                                          _P, _Z, _P, _Z, _I, _I, C.POINTER(WgradDesc), _P, C.POINTER(C.c_int), _P]),
+    "sitk_encoder_bwd_extra": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,
+                                         _P, _Z, _P, _Z, _I, _I, C.POINTER(WgradDesc), _P, C.POINTER(C.c_int),
+                                         C.POINTER(WgradDesc), _I, C.POINTER(C.c_int), _P]),
     "sitk_embed_cls_rows": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "sitk_head_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sitk_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -104,6 +108,8 @@ _SIGS = {
     "sitk_colsum_f32": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "sitk_colsum_f32_dup": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P]),
     "sitk_mpp_corrupt": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sitk_mpp_draw": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
+    "sitk_mpp_gather_corrupt": (C.c_int, [_P] * 13 + [_I, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_mpp_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _P]),
     "sitk_masked_colsum": (C.c_int, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P]),
     "sitk_sgd_step": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _I, _F, _P]),

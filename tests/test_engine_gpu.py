@@ -187,7 +187,7 @@ def test_graph_follows_lr_schedule_and_step_count(pk, optimizer):
             eng.set_lr(lr)
             eng.step(x, y)
         if use_graph:
-            assert eng._graphs and "opt" in eng._graphs, "the optimizer must run from the captured graph"
+            assert eng._graphs and "step" in eng._graphs, "the optimizer must run from the captured graph"
         flats[use_graph] = eng.fp.flat.clone()
         worst = max((rel(p.data, q.data), k) for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()))
         assert worst[0] < 2e-5, worst

@@ -562,3 +562,67 @@ def test_optimizers_match_torch(ops):
             opt.step()
             ops.adam_step(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, dec, step)
         assert rel(p, pr.detach()) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# MPP on-device draws and the fused gather + corruption (engine path)
+def test_mpp_device_draws_statistics_and_fresh_masks():
+    """sitk_mpp_draw (Philox): exactly ceil(mask_prob P) masked patches per sample (models/mpp.py:25-33), swap / replace
+    frequencies and the random partner index uniform (models/mpp.py:36-43,95-110), replaced_full = masked & replace shifted by
+    the cls token; a new draw index gives new masks, the same (seed, index) the same ones."""
+    import math
+    from sitk import runtime as rt
+    B, P = 64, 320
+    n_mask, p_swap, p_rep = math.ceil(0.75 * P), 0.1, 0.8
+    dev = DEV
+    state = torch.tensor([1234567, 0], dtype=torch.int64, device=dev)
+    bufs = lambda: (torch.zeros(B * P, dtype=torch.uint8, device=dev), torch.zeros(B * P, dtype=torch.uint8, device=dev),  # noqa: E731
+                    torch.zeros(B * P, dtype=torch.int32, device=dev), torch.zeros(B * P, dtype=torch.uint8, device=dev),
+                    torch.full((B, P + 1), 7, dtype=torch.uint8, device=dev))
+
+    def draw(st):
+        m, sw, rp, re_, rf = bufs()
+        rt.check(rt.lib.sitk_mpp_draw(st.data_ptr(), m.data_ptr(), sw.data_ptr(), rp.data_ptr(), re_.data_ptr(), rf.data_ptr(), B, P,
+                                      n_mask, p_swap, p_rep, rt.stream_ptr()))
+        return m.view(B, P), sw.view(B, P), rp.view(B, P), re_.view(B, P), rf
+    m, sw, rp, re_, rf = draw(state)
+    assert (m.sum(1) == n_mask).all()
+    assert abs(float(sw.float().mean()) - p_swap) < 0.01 and abs(float(re_.float().mean()) - p_rep) < 0.01
+    assert int(rp.min()) >= 0 and int(rp.max()) < P and abs(float(rp.float().mean()) - (P - 1) / 2) < 3.0
+    assert torch.equal(rf[:, 1:], m & re_) and int(rf[:, 0].sum()) == 0
+    # every patch is masked about equally often across samples (no positional bias)
+    freq = m.float().mean(0)
+    assert float((freq - 0.75).abs().max()) < 0.25
+    m2 = draw(state)[0]
+    assert torch.equal(m, m2)                                     # same (seed, draw index)
+    state[1] += 1
+    m3 = draw(state)[0]
+    assert not torch.equal(m, m3) and (m3.sum(1) == n_mask).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_mpp_gather_corrupt_equals_gather_then_corrupt(ops, dtype):
+    """One pass (engine) == sitk_gather_tokens(fp32) + sitk_mpp_corrupt, bit for bit, and the draw counter advances."""
+    from sitk import runtime as rt
+    from sitk import tables
+    B, P, V = 3, 320, 153
+    K, ld = 4 * V, 640
+    xs = rnd("mg/x", (B, 40962, 4))
+    table = tables.table_tensor(tables.load_table(P, V), DEV)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    masked = (torch.rand(B * P, device=DEV, generator=g) < 0.75).to(torch.uint8)
+    swap = (torch.rand(B * P, device=DEV, generator=g) < 0.3).to(torch.uint8)
+    repl = (torch.rand(B * P, device=DEV, generator=g) < 0.5).to(torch.uint8)
+    rpatch = torch.randint(0, P, (B * P,), device=DEV, generator=g, dtype=torch.int32)
+    mask_token = rnd("mg/mt", (K,))
+    clean_ref = ops.gather_tokens(xs, table, "f32", ld=K)
+    cor_ref = ops.mpp_corrupt(clean_ref, masked, swap, rpatch, repl, mask_token, B, P, K, dtype, ld=ld)
+    clean = torch.empty((B * P, K), dtype=torch.float32, device=DEV)
+    cor = torch.empty((B * P, ld), dtype=tdt(dtype), device=DEV)
+    state = torch.tensor([5, 41], dtype=torch.int64, device=DEV)
+    rt.check(rt.lib.sitk_mpp_gather_corrupt(xs.data_ptr(), table.data_ptr(), None, None, None, masked.data_ptr(), swap.data_ptr(),
+                                            rpatch.data_ptr(), repl.data_ptr(), mask_token.data_ptr(), clean.data_ptr(),
+                                            cor.data_ptr(), state.data_ptr(), B, 40962, 4, P, V, ld, rt.dtype_code(dtype),
+                                            rt.stream_ptr()))
+    assert torch.equal(clean, clean_ref) and torch.equal(cor, cor_ref)
+    assert state.tolist() == [5, 42]
