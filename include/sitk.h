@@ -275,10 +275,23 @@ int sitk_attention_bwd_phases(const void* qkv, const void* o, const void* d_o_in
  * Whole encoder = vit_pytorch.vit.Transformer(dim, depth, heads, dim_head=64, mlp_dim, dropout=0)
  * as constructed at models/sit.py:57 and called at models/sit.py:76 / models/mpp.py:128:
  * depth x [ x += to_out(attn(to_qkv(LN(x)))) ; x += W2 gelu(W1 LN(x) + b1) + b2 ].             */
+typedef struct sitk_timeline sitk_timeline;
 typedef struct {
   int B, N, dim, depth, heads, mlp_dim; /* dim_head fixed at 64 */
   int dtype;
+  sitk_timeline* timeline; /* NULL, or a timeline that gets one mark (HIP event + label) behind every launch of
+                              sitk_encoder_fwd / _bwd: per-kernel times of the REAL chain (bench.py's roofline rows)   */
 } sitk_encoder_cfg;
+
+/* Profiling aid (never part of a training step: recording an event between two kernels costs about a microsecond and
+ * events cannot be timed inside a captured graph).  The library owns the events.  read: waits for the last mark, then
+ * us[i] = time from mark i to mark i + 1 and labels[i] = label of mark i + 1 (static strings), i < count - 1; returns
+ * the number of intervals written (<= max), < 0 on error.                                                            */
+sitk_timeline* sitk_timeline_create(int capacity);
+void sitk_timeline_destroy(sitk_timeline* t);
+void sitk_timeline_reset(sitk_timeline* t);
+int sitk_timeline_mark(sitk_timeline* t, const char* label, sitk_stream_t stream);
+int sitk_timeline_read(sitk_timeline* t, float* us, const char** labels, int max);
 
 /* Per-layer fp32 parameter (or gradient) pointers, in state-dict order. */
 typedef struct {
@@ -396,6 +409,10 @@ int sitk_mpp_gather_corrupt(const float* x, const uint16_t* table_pv, const int3
 /* loss[0] += sum_{masked rows} (out - tokens)^2 / (n_masked_total * K); dout likewise (0 elsewhere). */
 int sitk_mpp_loss_fwd_bwd(const float* out, const float* tokens, const uint8_t* masked, float* loss,
                           float* dout, int64_t rows, int K, int64_t n_masked_total, sitk_stream_t stream);
+/* the same over row-padded buffers (leading dimensions ldo / ldt / lddo) with the gradient in `dout_dtype` (engine path) */
+int sitk_mpp_loss_fwd_bwd_ld(const float* out, int ldo, const float* tokens, int ldt, const uint8_t* masked, float* loss,
+                             void* dout, int lddo, int dout_dtype, int64_t rows, int K, int64_t n_masked_total,
+                             sitk_stream_t stream);
 /* out[c] += sum over rows with flag[r] != 0 of in[r][c]   (mask_token gradient, stage 1) */
 int sitk_masked_colsum(const void* in, int ld, int in_is_f32, int dtype, const uint8_t* flag_a,
                        const uint8_t* flag_b, int64_t rows, int cols, float* out, sitk_stream_t stream);

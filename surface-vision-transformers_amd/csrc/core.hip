@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace sitk {
@@ -26,6 +28,51 @@ int check_launch(const char* what) {
 }
 
 }  // namespace sitk
+
+// ---- timeline: HIP events between the launches of a chain (profiling aid, see sitk.h) ----
+struct sitk_timeline {
+  std::vector<hipEvent_t> ev;
+  std::vector<const char*> label;
+  int n = 0;
+};
+extern "C" sitk_timeline* sitk_timeline_create(int capacity) {
+  if (capacity < 2) return nullptr;
+  sitk_timeline* t = new sitk_timeline;
+  t->ev.resize(capacity);
+  t->label.assign(capacity, "");
+  for (int i = 0; i < capacity; ++i)
+    if (hipEventCreate(&t->ev[i]) != hipSuccess) { sitk::set_error("timeline: hipEventCreate failed"); t->ev.resize(i); sitk_timeline_destroy(t); return nullptr; }
+  return t;
+}
+extern "C" void sitk_timeline_destroy(sitk_timeline* t) {
+  if (!t) return;
+  for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
+  delete t;
+}
+extern "C" void sitk_timeline_reset(sitk_timeline* t) { if (t) t->n = 0; }
+extern "C" int sitk_timeline_mark(sitk_timeline* t, const char* label, sitk_stream_t stream) {
+  if (!t) return SITK_OK;
+  if (t->n >= (int)t->ev.size()) return SITK_OK;                 // full: further marks are dropped
+  if (hipEventRecord(t->ev[t->n], reinterpret_cast<hipStream_t>(stream)) != hipSuccess) {
+    sitk::set_error("timeline: hipEventRecord failed");
+    return SITK_ERR_LAUNCH;
+  }
+  t->label[t->n++] = label;
+  return SITK_OK;
+}
+extern "C" int sitk_timeline_read(sitk_timeline* t, float* us, const char** labels, int max) {
+  if (!t || !us || !labels) return SITK_ERR_INVALID;
+  if (t->n < 2) return 0;
+  if (hipEventSynchronize(t->ev[t->n - 1]) != hipSuccess) { sitk::set_error("timeline: hipEventSynchronize failed"); return SITK_ERR_LAUNCH; }
+  int k = 0;
+  for (int i = 0; i + 1 < t->n && k < max; ++i, ++k) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t->ev[i], t->ev[i + 1]) != hipSuccess) { sitk::set_error("timeline: hipEventElapsedTime failed"); return SITK_ERR_LAUNCH; }
+    us[k] = ms * 1e3f;
+    labels[k] = t->label[i + 1];
+  }
+  return k;
+}
 
 extern "C" int sitk_abi_version(void) { return SITK_ABI_VERSION; }
 extern "C" const char* sitk_last_error(void) { return sitk::g_err; }

@@ -211,6 +211,9 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
   return L;
 }
 
+// one timeline mark behind a launch (no-op without a timeline)
+#define SITK_MARK(label) SITK_TRY(sitk_timeline_mark(c.timeline, label, stream))
+
 static int check_cfg(const sitk_encoder_cfg* c) {
   SITK_REQUIRE(c != nullptr, "encoder: null config");
   SITK_REQUIRE(c->B > 0 && c->N > 0 && c->depth > 0 && c->heads > 0, "encoder: bad shape");
@@ -298,7 +301,9 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   const bool f32 = dt == SITK_F32;
   const float scale = 0.125f;  // dim_head ** -0.5, dim_head = 64
 
+  SITK_MARK("begin");
   SITK_TRY(stage_all(c, P, L, s));
+  SITK_MARK("stage_weights");
 
   const float* x = x_in;
   bool have_qkv = false;   // the previous block's fused kernel already produced this block's h1 / statistics / qkv
@@ -315,13 +320,17 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
       // this block's LayerNorm + to_qkv were appended to the previous block's fused kernel
     } else if (qkv_fused(c)) {
       SITK_TRY(sitk_ln_gemm_fwd(x, P[l].ln1_w, P[l].ln1_b, wqkv, a.h1, a.mean1, a.rstd1, a.qkv, R, D, 3 * I, dt, stream));
+      SITK_MARK("ln_gemm_fwd");
     } else {
       SITK_TRY(sitk_layernorm_fwd(x, P[l].ln1_w, P[l].ln1_b, a.h1, a.mean1, a.rstd1, R, D, dt, stream));
+      SITK_MARK("layernorm_fwd");
       sitk_gemm_desc g1 = gemm_desc(R, 3 * I, D, a.h1, D, 0, wqkv, SITK_EPI_STORE, a.qkv, 3 * I, 0);
       SITK_TRY(sitk_gemm_nt(&g1, dt, stream));
+      SITK_MARK("gemm:to_qkv");
     }
     have_qkv = false;
     SITK_TRY(sitk_attention_fwd(a.qkv, a.o, a.lse, c.B, c.N, c.heads, scale, dt, stream));
+    SITK_MARK("attn_fwd");
     if (mlp_fused(c) && sitk_attn_out_mlp_fused_supported(R, D, I, M, dt)) {   // to_out + residual + norm + MLP + residual
       if (l + 1 < c.depth && qkv_fused(c)) {                                    // ... + the next block's norm + to_qkv
         const LayerActs& an = L.layers[save ? l + 1 : 0];
@@ -329,10 +338,12 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
         SITK_TRY(sitk_attn_out_mlp_next_fwd(a.o, wo, P[l].bo, x, a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2,
                                             a.mean2, a.rstd2, a.u, save ? a.g : nullptr, xnext, P[l + 1].ln1_w, P[l + 1].ln1_b,
                                             wqkv_n, an.h1, an.mean1, an.rstd1, an.qkv, 3 * I, R, D, I, M, dt, stream));
+        SITK_MARK("block_tail_next");
         have_qkv = true;
       } else {
         SITK_TRY(sitk_attn_out_mlp_fwd(a.o, wo, P[l].bo, x, a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2,
                                        a.mean2, a.rstd2, a.u, save ? a.g : nullptr, xnext, R, D, I, M, dt, stream));
+        SITK_MARK("block_tail");
       }
       x = xnext;
       continue;
@@ -340,19 +351,24 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
     sitk_gemm_desc g2 = gemm_desc(R, D, I, a.o, I, 0, wo, SITK_EPI_BIAS_RES, a.xmid, D, 1);
     g2.bias = P[l].bo; g2.aux = x; g2.ldaux = D;
     SITK_TRY(sitk_gemm_nt(&g2, dt, stream));
+    SITK_MARK("gemm:to_out");
     if (mlp_fused(c)) {
       SITK_TRY(sitk_mlp_fwd(a.xmid, P[l].ln2_w, P[l].ln2_b, w1, P[l].b1, w2, P[l].b2, a.h2, a.mean2, a.rstd2, a.u, save ? a.g : nullptr,
                             xnext, R, D, M, dt, stream));
+      SITK_MARK("mlp_fwd");
       x = xnext;
       continue;
     }
     SITK_TRY(sitk_layernorm_fwd(a.xmid, P[l].ln2_w, P[l].ln2_b, a.h2, a.mean2, a.rstd2, R, D, dt, stream));
+    SITK_MARK("layernorm_fwd");
     sitk_gemm_desc g3 = gemm_desc(R, M, D, a.h2, D, 0, w1, SITK_EPI_BIAS_GELU, a.u, M, 0);
     g3.bias = P[l].b1; g3.out2 = a.g;
     SITK_TRY(sitk_gemm_nt(&g3, dt, stream));
+    SITK_MARK("gemm:net0");
     sitk_gemm_desc g4 = gemm_desc(R, D, M, a.g, M, 0, w2, SITK_EPI_BIAS_RES, xnext, D, 1);
     g4.bias = P[l].b2; g4.aux = a.xmid; g4.ldaux = D;
     SITK_TRY(sitk_gemm_nt(&g4, dt, stream));
+    SITK_MARK("gemm:net3");
     x = xnext;
   }
   (void)s;
@@ -412,7 +428,9 @@ extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_la
   }
   std::vector<sitk_wgrad_desc> wg_all;
   wg_all.reserve(4 * (layer_end - layer_begin));
+  SITK_MARK("begin");
   SITK_TRY(sitk_cast_rows(dx, D, S.dxAc[slot(layer_end - 1)], D, R, D, dt, stream));
+  SITK_MARK("cast_rows");
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const LayerActs& a = L.layers[l];
     const float* xl = l == 0 ? x_in : a.x_in;
@@ -430,25 +448,40 @@ extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_la
     if (mlp_fused(c)) {
       SITK_TRY(sitk_mlp_bwd(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, a.g ? nullptr : S.g[sl], S.dxB, dxBc,
                             part2, R, D, M, dt, stream));
+      SITK_MARK("mlp_bwd");
       ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, (int)(sitk_mlp_bwd_partial_floats(R) / (2 * D))});
       gact = a.g ? a.g : S.g[sl];
     } else {
       sitk_gemm_desc d1 = gemm_desc(R, M, D, dxAc, D, 0, a.w2_t, SITK_EPI_DGELU, du, M, 0);
       d1.aux = a.u; d1.ldaux = M;
       SITK_TRY(sitk_gemm_nt(&d1, dt, stream));
+      SITK_MARK("gemm:dnet3");
       sitk_gemm_desc d2 = gemm_desc(R, D, M, du, M, 0, a.w1_t, SITK_EPI_STORE, S.dh, D, 0);
       SITK_TRY(sitk_gemm_nt(&d2, dt, stream));
+      SITK_MARK("gemm:dnet0");
       SITK_TRY(layernorm_bwd_deferred(S.dh, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, dx, S.dxB, dxBc, part2, R, D, dt, hs));
+      SITK_MARK("layernorm_bwd");
       ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, 0});
     }
     // ---- attention branch: xmid = x + Wo attn(Wqkv LN1(x)) + bo ----
     if (sitk_attention_bwd_proj_supported(c.N, D, dt)) {     // d_o = dx_mid Wo inside the query-side kernel
-      SITK_TRY(sitk_attention_bwd_proj(a.qkv, a.o, dxBc, a.wo_t, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale, dt,
-                                       stream));
+      // (two single-phase calls = the two launches of sitk_attention_bwd_proj, with room for a timeline mark in between)
+      SITK_TRY(sitk_attention_bwd_phases(a.qkv, a.o, nullptr, dxBc, a.wo_t, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale,
+                                         dt, 1, stream));
+      SITK_MARK("attn_bwd_dq");
+      SITK_TRY(sitk_attention_bwd_phases(a.qkv, a.o, nullptr, dxBc, a.wo_t, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale,
+                                         dt, 2, stream));
+      SITK_MARK("attn_bwd_dkv");
     } else {
       sitk_gemm_desc d3 = gemm_desc(R, I, D, dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
       SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
-      SITK_TRY(sitk_attention_bwd(a.qkv, a.o, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, scale, dt, stream));
+      SITK_MARK("gemm:dto_out");
+      SITK_TRY(sitk_attention_bwd_phases(a.qkv, a.o, S.d_o, nullptr, nullptr, nullptr, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale,
+                                         dt, 1, stream));
+      SITK_MARK("attn_bwd_dq");
+      SITK_TRY(sitk_attention_bwd_phases(a.qkv, a.o, S.d_o, nullptr, nullptr, nullptr, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale,
+                                         dt, 2, stream));
+      SITK_MARK("attn_bwd_dkv");
     }
     // ---- the four weight (+ bias) gradients of the layer, one launch ----
     sitk_wgrad_desc wg[4] = {
@@ -458,16 +491,19 @@ extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_la
         wgrad_desc(R, 3 * I, D, dqkv, 0, a.h1, G[l].wqkv, nullptr),
     };
     if (S.wg_batch) wg_all.insert(wg_all.end(), wg, wg + 4);       // launched once, after the slice's last layer
-    else SITK_TRY(sitk_gemm_wgrad_group_ws(wg, 4, dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
+    else { SITK_TRY(sitk_gemm_wgrad_group_ws(wg, 4, dt, S.wgrad_ws, S.wgrad_ws_bytes, stream)); SITK_MARK("wgrad"); }
     float* part1 = S.ln_partials + (size_t)(2 * l) * S.ln_partial_floats;
     if (qkv_fused(c)) {
       SITK_TRY(sitk_ln_gemm_bwd(dqkv, a.wqkv_t, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, dxc_next, part1, R, D, 3 * I, dt,
                                 stream));
+      SITK_MARK("ln_gemm_bwd");
       ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, (int)(sitk_ln_gemm_bwd_partial_floats(R) / (2 * D))});
     } else {
       sitk_gemm_desc d4 = gemm_desc(R, D, 3 * I, dqkv, 3 * I, 0, a.wqkv_t, SITK_EPI_STORE, S.dh, D, 0);
       SITK_TRY(sitk_gemm_nt(&d4, dt, stream));
+      SITK_MARK("gemm:dqkv");
       SITK_TRY(layernorm_bwd_deferred(S.dh, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, dxc_next, part1, R, D, dt, hs));
+      SITK_MARK("layernorm_bwd");
       ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, 0});
     }
   }
@@ -492,8 +528,12 @@ extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_la
     else
       wg_all.resize(before);
   }
-  if (S.wg_batch && !wg_all.empty())
+  if (S.wg_batch && !wg_all.empty()) {
     SITK_TRY(sitk_gemm_wgrad_group_ws(wg_all.data(), (int)wg_all.size(), dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
+    SITK_MARK("wgrad");
+  }
   // every LayerNorm parameter gradient of the slice in one reduction launch
-  return layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs);
+  SITK_TRY(layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs));
+  SITK_MARK("ln_finalize");
+  return SITK_OK;
 }

@@ -304,31 +304,40 @@ __global__ __launch_bounds__(256) void mpp_draw_kernel(const uint64_t* __restric
                                                        uint8_t* __restrict__ replace_draw, uint8_t* __restrict__ replaced_full,
                                                        int P, int n_mask, float p_swap, float p_replace) {
   __shared__ float score[MPP_MAX_P];
-  const int b = blockIdx.x;
-  const uint64_t seed = state[0], draw = state[1];
+  const int b = blockIdx.x, i_begin = blockIdx.y * 64;      // grid (B, ceil(P / 64)): every block scores the whole sample (cheap)
+  const uint64_t seed = state[0], draw = state[1];          // and ranks / flags 64 of its patches
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   for (int i = threadIdx.x; i < P; i += 256) {
     uint32_t c[4] = {(uint32_t)draw, (uint32_t)i, (uint32_t)(draw >> 32), (uint32_t)b};
     philox4x32(c, k0, k1);
     score[i] = u01(c[0]);
-    const size_t row = (size_t)b * P + i;
-    if (swap_draw) { swap_draw[row] = u01(c[1]) < p_swap; random_patches[row] = (int32_t)(((uint64_t)c[2] * (uint32_t)P) >> 32); }
-    replace_draw[row] = u01(c[3]) < p_replace;
+    if (i >= i_begin && i < i_begin + 64) {
+      const size_t row = (size_t)b * P + i;
+      if (swap_draw) { swap_draw[row] = u01(c[1]) < p_swap; random_patches[row] = (int32_t)(((uint64_t)c[2] * (uint32_t)P) >> 32); }
+      replace_draw[row] = u01(c[3]) < p_replace;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < P; i += 256) {
-    const float si = score[i];
+  // rank of score i = number of scores that beat it (ties by index); four lanes share one i and a quarter of the j each
+  const int q4 = threadIdx.x & 3;
+  {
+    const int i = i_begin + (threadIdx.x >> 2);
+    const float si = i < P ? score[i] : 0.f;
     int rank = 0;
-    for (int j = 0; j < P; ++j) {
+    for (int j = q4; j < P; j += 4) {
       const float sj = score[j];
       rank += (sj > si) || (sj == si && j < i);
     }
-    const size_t row = (size_t)b * P + i;
-    const uint8_t m = rank < n_mask;
-    masked[row] = m;
-    replaced_full[(size_t)b * (P + 1) + 1 + i] = m && replace_draw[row];
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
+    if (i < P && q4 == 0) {
+      const size_t row = (size_t)b * P + i;
+      const uint8_t m = rank < n_mask;
+      masked[row] = m;
+      replaced_full[(size_t)b * (P + 1) + 1 + i] = m && replace_draw[row];
+    }
   }
-  if (threadIdx.x == 0) replaced_full[(size_t)b * (P + 1)] = 0;
+  if (threadIdx.x == 0 && blockIdx.y == 0) replaced_full[(size_t)b * (P + 1)] = 0;
 }
 
 // Patch gather (tools/preprocessing.py:74-84 + Rearrange, as gather_tokens_kernel) fused with the corruption of
@@ -398,6 +407,33 @@ __global__ __launch_bounds__(256) void mpp_loss_kernel(const float* __restrict__
         g = d * (2.f * inv_count);
       }
       store4(dout + (size_t)row * K + 4 * c, g);
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
+}
+
+// the same with leading dimensions and the gradient in the compute dtype (engine path: batch_out lives in a row-padded buffer
+// written by the weight-resident GEMM, the gradient feeds bf16 GEMMs): whole rows, 16-byte accesses
+template <typename T>
+__global__ __launch_bounds__(256) void mpp_loss_ld_kernel(const float* __restrict__ out, int ldo, const float* __restrict__ tokens,
+                                                          int ldt, const uint8_t* __restrict__ masked, float* __restrict__ loss,
+                                                          T* __restrict__ dout, int lddo, int64_t rows, int K, float inv_count) {
+  __shared__ float red[4];
+  const int nvec = K >> 2;
+  float s = 0.f;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const bool m = masked[row] != 0;
+    for (int c = threadIdx.x; c < nvec; c += 256) {
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (m) {
+        const f32x4 d = load4(out + (size_t)row * ldo + 4 * c) - load4(tokens + (size_t)row * ldt + 4 * c);
+        s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        g = d * (2.f * inv_count);
+      }
+      store4(dout + (size_t)row * lddo + 4 * c, g);
     }
   }
   s = wave_sum(s);
@@ -671,7 +707,7 @@ extern "C" int sitk_mpp_draw(const uint64_t* state, uint8_t* masked, uint8_t* sw
   SITK_REQUIRE(state && masked && replace_draw && replaced_full, "mpp_draw: null pointer");
   SITK_REQUIRE((swap_draw == nullptr) == (random_patches == nullptr), "mpp_draw: swap_draw and random_patches go together");
   SITK_REQUIRE(B > 0 && P > 0 && P <= MPP_MAX_P && n_mask >= 0 && n_mask <= P, "mpp_draw: bad shape (P <= %d)", MPP_MAX_P);
-  hipLaunchKernelGGL(mpp_draw_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), state, masked, swap_draw,
+  hipLaunchKernelGGL(mpp_draw_kernel, dim3(B, cdiv(P, 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), state, masked, swap_draw,
                      random_patches, replace_draw, replaced_full, P, n_mask, p_swap, p_replace);
   return check_launch("mpp_draw");
 }
@@ -702,4 +738,24 @@ extern "C" int sitk_mpp_gather_corrupt(const float* x, const uint16_t* table_pv,
                        n_vertices, P, V, K, ld);
   else { set_error("mpp_gather_corrupt: bad dtype %d", dtype); return SITK_ERR_INVALID; }
   return check_launch("mpp_gather_corrupt");
+}
+
+extern "C" int sitk_mpp_loss_fwd_bwd_ld(const float* out, int ldo, const float* tokens, int ldt, const uint8_t* masked, float* loss,
+                                        void* dout, int lddo, int dout_dtype, int64_t rows, int K, int64_t n_masked_total,
+                                        sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(out && tokens && masked && loss && dout, "mpp_loss_ld: null pointer");
+  SITK_REQUIRE(rows > 0 && K > 0 && K % 4 == 0 && n_masked_total > 0 && ldo >= K && ldt >= K && lddo >= K && ldo % 4 == 0 &&
+               ldt % 4 == 0 && lddo % 4 == 0, "mpp_loss_ld: bad shape");
+  const float inv = 1.0f / ((float)n_masked_total * (float)K);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(rows, 1, 4096);
+  if (dout_dtype == SITK_BF16)
+    hipLaunchKernelGGL((mpp_loss_ld_kernel<bf16>), dim3(grid), dim3(256), 0, s, out, ldo, tokens, ldt, masked, loss,
+                       reinterpret_cast<bf16*>(dout), lddo, rows, K, inv);
+  else if (dout_dtype == SITK_F32)
+    hipLaunchKernelGGL((mpp_loss_ld_kernel<float>), dim3(grid), dim3(256), 0, s, out, ldo, tokens, ldt, masked, loss,
+                       reinterpret_cast<float*>(dout), lddo, rows, K, inv);
+  else { set_error("mpp_loss_ld: bad dtype %d", dout_dtype); return SITK_ERR_INVALID; }
+  return check_launch("mpp_loss_ld");
 }

@@ -162,10 +162,12 @@ class TrainEngine:
             self.n_mask = math.ceil(ssl.mask_prob * P)
             self.tok32 = torch.zeros((B * P, K), dtype=f32, device=dev)
             self.enc_out = torch.empty((B * P, D), dtype=self.tdt, device=dev)
-            self.wo_c = torch.empty((K, D), dtype=self.tdt, device=dev)      # to_original, (K, D)
+            self.wo_c = torch.zeros((ld, D), dtype=self.tdt, device=dev)     # to_original (K, D), zero rows up to ld: the
+            self.bo_pad = torch.zeros((ld,), dtype=f32, device=dev)          # GEMM runs on N = ld columns (16-byte stores)
             self.wo_t = torch.empty((D, ops.pad8(K)), dtype=self.tdt, device=dev)
             self.we_t = torch.empty((K, D), dtype=self.tdt, device=dev)      # embedding weight^T (for d mask_token)
-            self.out = torch.empty((B * P, K), dtype=f32, device=dev)
+            self.out_pad = torch.empty((B * P, ld), dtype=f32, device=dev)   # batch_out in rows of ld floats
+            self.out = self.out_pad[:, :K]                                   # (B * P, K) view: models/mpp.py:129's batch_out
             self.dout_c = torch.zeros((B * P, ld), dtype=self.tdt, device=dev)   # d batch_out, compute dtype; pad columns stay 0
             self._extra_wgrad_done = False
             self.masked = torch.zeros((B * P,), dtype=torch.uint8, device=dev)
@@ -255,9 +257,9 @@ class TrainEngine:
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
         lin = sit.to_patch_embedding[1]
         g = self.fp.g
-        if not self._embed_wgrad_done:
+        if not self._embed_wgrad_done:      # (shapes outside the batched large-tile path: padded scratch, then a strided copy)
             ops.gemm_wgrad(self.dx, tokens, self.dW_embed, dt, db=g(lin.bias), M=B * P, N=D, K=ld, dymap=(P, N, 1))
-        g(lin.weight).copy_(self.dW_embed[:, :K])
+            g(lin.weight).copy_(self.dW_embed[:, :K])
         gpos = g(sit.pos_embedding).view(-1)[:N * D]
         rt.check(rt.lib.sitk_colsum_f32_dup(self.dx.data_ptr(), B, N * D, N * D, gpos.data_ptr(),
                                             g(sit.cls_token).data_ptr(), D, self._s()))
@@ -294,13 +296,15 @@ class TrainEngine:
         lo = ssl.to_original
         rt.check(L.sitk_stage_weight(lo.weight.data_ptr(), K, D, self.wo_c.data_ptr(), D, self.wo_t.data_ptr(),
                                      self.wo_t.shape[1], dt, s))
-        # batch_out, the masked squared error and its gradient (compute dtype) leave ONE GEMM
-        ops.gemm_nt(self.xL, self.wo_c, self.out, dt, M=B * P, N=K, K=D, epilogue=ops.EPI_MPP_LOSS, bias=lo.bias.data,
-                    aux=self.tok32, out2=self.dout_c, amap=(P, N, 1), row_flags=self.masked, loss=self.loss_acc,
-                    loss_scale=1.0 / (B * self.n_mask * K))
-        # d to_original: X = encoder output rows 1..P (fp32 -> compute dtype copy); the weight gradient itself joins the
-        # encoder's one weight-gradient launch (sitk_encoder_bwd_extra), see _backward_slice / _finish_backward
+        # encoder output rows 1..P in the compute dtype: operand of to_original and, later, of its weight gradient (which
+        # joins the encoder's one weight-gradient launch: sitk_encoder_bwd_extra, see _backward_slice / _finish_backward)
         rt.check(L.sitk_cast_rows(self.xL.data_ptr() + 4 * D, N * D, self.enc_out.data_ptr(), P * D, B, P * D, dt, s))
+        rt.check(L.sitk_cast_rows(lo.bias.data_ptr(), K, self.bo_pad.data_ptr(), ld, 1, K, rt.F32, s))
+        # batch_out on ld (zero-weight padded) columns: the weight-resident streaming GEMM with whole-row stores; then one
+        # row-layout pass for the masked squared error and its gradient in the compute dtype
+        ops.gemm_nt(self.enc_out, self.wo_c, self.out_pad, dt, M=B * P, N=ld, K=D, bias=self.bo_pad)
+        rt.check(L.sitk_mpp_loss_fwd_bwd_ld(self.out_pad.data_ptr(), ld, self.tok32.data_ptr(), K, self.masked.data_ptr(),
+                                            self.loss_acc.data_ptr(), self.dout_c.data_ptr(), ld, dt, B * P, K, B * self.n_mask, s))
         self.dx.zero_()
         ops.gemm_nt(self.dout_c, self.wo_t, self.dx, dt, M=B * P, N=D, K=self.wo_t.shape[1], omap=(P, N, 1))
 
@@ -314,8 +318,8 @@ class TrainEngine:
                 extra = [ops.wgrad_desc(self.dout_c, self.enc_out, self.fp.g(lo.weight), db=self.fp.g(lo.bias), M=self.B * self.P,
                                         N=self.K, K=self.D)]
             self._embed_wgrad_done, self._extra_wgrad_done = ops.encoder_bwd_embed(
-                self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, lb, le, self.tokens, self.dW_embed,
-                self.fp.g(lin.bias), self.dx_c, self.P, extra=extra)
+                self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, lb, le, self.tokens, self.fp.g(lin.weight),
+                self.fp.g(lin.bias), self.dx_c, self.P, extra=extra)   # written straight into the (D, K) gradient (tokens: zero pad to ld)
             return
         ops.encoder_bwd(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, layer_begin=lb, layer_end=le)
 

@@ -90,7 +90,11 @@ def layer_kernels(eng, nset):
     fused_proj = fused_mlp and ops.attn_out_mlp_fused_supported(R, D, I, M, dt)
     fused_chain = fused_proj and fused_qkv and L > 1
     rows = []
-    add = lambda *r: rows.append(r)  # noqa: E731
+    # op name -> label of the timeline marks csrc/encoder.hip records behind that launch
+    TL = {"norm + to_qkv (fused)": "ln_gemm_fwd", "norm (attention)": "layernorm_fwd", "to_qkv": "gemm:to_qkv", "attention forward": "attn_fwd", "to_out + norm + MLP + residuals + next block's norm + to_qkv (fused)": "block_tail_next", "to_out + residual + norm + net.0 + GELU + net.3 + residual (fused)": "block_tail", "to_out + residual": "gemm:to_out", "norm + net.0 + GELU + net.3 + residual (fused)": "mlp_fwd", "norm (MLP)": "layernorm_fwd", "net.0 + GELU": "gemm:net0", "net.3 + residual": "gemm:net3", "d net.3 x GELU' + d net.0 + norm backward (fused)": "mlp_bwd", "d net.3 (x GELU')": "gemm:dnet3", "d net.0": "gemm:dnet0", "norm backward (MLP)": "layernorm_bwd", "d to_out": "gemm:dto_out", "d to_qkv + norm backward (fused)": "ln_gemm_bwd", "d to_qkv": "gemm:dqkv", "norm backward (attention)": "layernorm_bwd"}
+
+    def add(name, kernel, fn, flops, nbytes, launches, label=None):
+        rows.append((name, kernel, fn, flops, nbytes, launches, label or TL.get(name)))
 
     def ln_bwd(i):
         dxc = torch.empty_like(S[i].h)
@@ -158,8 +162,8 @@ def layer_kernels(eng, nset):
     # algorithmic work (backward = 2 x forward = four products): dP and dQ count for the query side, dV and dK
     # for the key side; both kernels also recompute S (query side executes 3 products + the folded projection, key side 4)
     add("attention backward, query side (dQ" + (", d to_out folded in)" if fold else ")"), "attn_bwd_dq",
-        lambda i: att_bwd(i, 1), att + (2.0 * R * D * I if fold else 0.0), R * (5 * I + (D if fold else I)) * es, L)
-    add("attention backward, key side (dK, dV)", "attn_bwd_dkv", lambda i: att_bwd(i, 2), att, R * 6 * I * es, L)
+        lambda i: att_bwd(i, 1), att + (2.0 * R * D * I if fold else 0.0), R * (5 * I + (D if fold else I)) * es, L, "attn_bwd_dq")
+    add("attention backward, key side (dK, dV)", "attn_bwd_dkv", lambda i: att_bwd(i, 2), att, R * 6 * I * es, L, "attn_bwd_dkv")
     # the weight gradients of a whole backward slice run as one launch (csrc/encoder.hip): all L layers on one GPU
     probs = []
     nl = L if 4 * L <= 48 else 1
@@ -175,7 +179,7 @@ def layer_kernels(eng, nset):
     ws_all = torch.empty(max(nb_all, 16), dtype=torch.uint8, device=dev)
     add(f"weight gradients of {nl} layer(s), one launch", "wgrad_big_kernel" if nb_all else "wgrad_kernel",
         lambda i: ops.gemm_wgrad_group(probs, dt, workspace=ws_all if nb_all else None), wg_flops * nl,
-        nl * R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L // nl)
+        nl * R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L // nl, "wgrad")
     if fused_qkv:
         add("d to_qkv + norm backward (fused)", "ln_gemm_bwd_kernel",
             lambda i: ops.ln_gemm_bwd(S[i].qkv, S[i].wqkv_t, S[i].x32, S[i].mean, S[i].rstd, S[i].gam, S[i].dx32, dt),
@@ -197,16 +201,60 @@ def _desc_array(problems):
     return arr, len(problems)
 
 
+def step_timeline(eng, reps=3):
+    """Per-kernel device times INSIDE the real step: one train step runs eagerly with a timeline attached to the encoder
+    (csrc/encoder.hip records a HIP event behind every launch); returns {label: (average us, launches per step)}.  An
+    interval runs from the previous kernel's end to this kernel's end, i.e. it includes the ~1-2 us the hardware needs to
+    start a dependent kernel."""
+    import ctypes as C
+    if eng.world != 1:
+        return {}
+    cap = 4096
+    tl = rt.lib.sitk_timeline_create(cap)
+    if not tl:
+        return {}
+    us = (C.c_float * cap)()
+    lab = (C.c_char_p * cap)()
+    acc = {}
+    try:
+        eng.cfg.timeline = tl
+        for r in range(reps + 1):
+            rt.lib.sitk_timeline_reset(tl)
+            for fn in eng._segment_fns():
+                fn()
+            eng._finish_backward()
+            eng._optimizer()
+            n = rt.lib.sitk_timeline_read(tl, us, lab, cap)
+            if r == 0 or n <= 0:
+                continue                                  # first pass: warm-up
+            for i in range(n):
+                k = lab[i].decode()
+                if k == "begin":
+                    continue                              # the gap between forward and backward (head, loss) is not a kernel
+                a = acc.setdefault(k, [0.0, 0])
+                a[0] += us[i]
+                a[1] += 1
+    finally:
+        eng.cfg.timeline = None
+        rt.lib.sitk_timeline_destroy(tl)
+    return {k: (v[0] / v[1], v[1] // reps) for k, v in acc.items()}
+
+
 def dominant_kernel_roofline(eng, peak_tflops, peak_gbs, reps=None):
+    """`us` of every row = the kernel's average time inside the real step (step_timeline; what rocprofv3 --kernel-trace
+    --stats of the same command reports, plus the dependent-launch gap); `us_isolated` = the same launch replayed from a
+    hipGraph over rotating cold buffers.  The dominant kernel = the single kernel with the largest in-step share."""
     tr = eng.sit.transformer
     R, D, M, I = eng.B * eng.N, eng.D, tr.mlp_dim, tr.heads * 64
     per_set = R * (2 * (2 * D + 4 * I + 2 * M + D + I) + 8 * D) * 2.2     # operands + the outputs kept alive, bytes
     nset = int(max(2, min(eng.depth, 12, 40e9 // per_set)))
     reps = reps or nset
+    tline = step_timeline(eng)
     rows = []
-    for name, kernel, fn, flops, nbytes, launches in layer_kernels(eng, nset):
-        t = _time(fn, nset, reps)
-        rows.append(dict(op=name, kernel=kernel, us=round(t * 1e6, 2), launches_per_step=launches,
+    for name, kernel, fn, flops, nbytes, launches, label in layer_kernels(eng, nset):
+        t_iso = _time(fn, nset, reps)
+        t = tline[label][0] * 1e-6 if label in tline else t_iso
+        rows.append(dict(op=name, kernel=kernel, us=round(t * 1e6, 2), us_isolated=round(t_iso * 1e6, 2), launches_per_step=launches,
                          tflops=round(flops / t / 1e12, 1), gbs=round(nbytes / t / 1e9, 1),
                          mfma_frac=round(flops / t / 1e12 / peak_tflops, 4), hbm_frac=round(nbytes / t / 1e9 / peak_gbs, 4),
                          step_share_us=round(t * 1e6 * launches, 1)))
@@ -218,5 +266,5 @@ def dominant_kernel_roofline(eng, peak_tflops, peak_gbs, reps=None):
     return {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "op": dom["op"], "achieved": ach,
             "peak": peak, "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
             "avg_us": dom["us"], "launches_per_step": dom["launches_per_step"],
-            "mfma_frac": dom["mfma_frac"], "hbm_frac": dom["hbm_frac"],
+            "mfma_frac": dom["mfma_frac"], "hbm_frac": dom["hbm_frac"], "timing": "in-step HIP events (sitk_timeline)" if tline else "isolated replay",
             "buffer_sets": nset, "encoder_kernel_sum_us": round(total, 1), "kernels": rows}

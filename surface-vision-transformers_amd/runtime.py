@@ -45,7 +45,7 @@ class WgradDesc(C.Structure):
 
 class EncoderCfg(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("dim", C.c_int), ("depth", C.c_int), ("heads", C.c_int),
-                ("mlp_dim", C.c_int), ("dtype", C.c_int)]
+                ("mlp_dim", C.c_int), ("dtype", C.c_int), ("timeline", C.c_void_p)]
 
 
 LAYER_FIELDS = ("ln1_w", "ln1_b", "wqkv", "wo", "bo", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2")
@@ -60,6 +60,11 @@ _SIGS = {
     "sitk_abi_version": (C.c_int, []),
     "sitk_last_error": (C.c_char_p, []),
     "sitk_dtype_size": (C.c_int, [_I]),
+    "sitk_timeline_create": (C.c_void_p, [_I]),
+    "sitk_timeline_destroy": (None, [_P]),
+    "sitk_timeline_reset": (None, [_P]),
+    "sitk_timeline_mark": (C.c_int, [_P, C.c_char_p, _P]),
+    "sitk_timeline_read": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_char_p), _I]),
     "sitk_gather_tokens": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_gather_tokens_norm": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_gather_tokens_idx": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -111,6 +116,7 @@ _SIGS = {
     "sitk_mpp_draw": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "sitk_mpp_gather_corrupt": (C.c_int, [_P] * 13 + [_I, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_mpp_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _P]),
+    "sitk_mpp_loss_fwd_bwd_ld": (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _L, _I, _L, _P]),
     "sitk_masked_colsum": (C.c_int, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P]),
     "sitk_sgd_step": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _I, _F, _P]),
     "sitk_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _F, _P]),
