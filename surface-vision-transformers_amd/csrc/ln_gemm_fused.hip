@@ -17,6 +17,7 @@
 
 namespace sitk {
 
+__device__ u32x4 g_zero_page_lg[4];
 __device__ unsigned long long g_lg_stamps[8 * 16];   // diagnostic build only (SITK_LG_STAMPS)
 
 struct LnGemmParams {
@@ -237,75 +238,104 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_fwd_kernel(LnGemmParams p) {
 // ------------------------------------------------------------------------------------------------------
 // backward: dx = dres + LayerNorm'(dy W)
 // ------------------------------------------------------------------------------------------------------
+// The loop is nine chunks of 24 MFMAs per wave -- 0.2 us of matrix work per chunk against ~1.2 us for an LDS-DMA to
+// land -- so it runs at the speed of its prefetch: a 4-slot ring keeps THREE chunks in flight (2 slots: 24.1 us per
+// launch at the BASELINE shape; 4 slots: see profiles/README.md).  The B operand (the block's rows of dy, 64 columns per chunk) travels
+// through the same ring: as register loads it would sit in the in-order vmcnt queue between the DMA pieces and force
+// every older piece home with it.
+constexpr int LG_BWD_SLOTS = 4;
 template <int TG>
 __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
-  constexpr int D = LG_D, BLK = 32 * TG, NW = 2 * TG, PPW = 24 / NW;
-  __shared__ __attribute__((aligned(256))) char smem[LG_SMEM_BWD];
+  constexpr int D = LG_D, BLK = 32 * TG, NW = 2 * TG;
+  constexpr int DYB = BLK * 128;                       // dy chunk image: BLK rows x 128 B
+  constexpr int SLOT = LG_WB + DYB;                    // W^T chunk (24 KB) + dy chunk
+  constexpr int NP = 24 + BLK / 8, PPW = NP / NW;      // DMA pieces per chunk (36 / 40) and per wave (6 / 5)
+  static_assert(PPW * NW == NP, "pieces must divide evenly");
+  constexpr int RING = LG_BWD_SLOTS * SLOT;
+  constexpr int SMEM = RING > LG_SMEM_BWD ? RING : LG_SMEM_BWD;
+  static_assert(SMEM <= 163840, "LDS budget");
+  __shared__ __attribute__((aligned(256))) char smem[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int tg = wave >> 1, hh = wave & 1;
   const int blk0 = blockIdx.x * BLK;
   const int N = p.N, nchunks = N / 64;
 
-  // ---- W^T chunk DMA: 192 rows x 64 k (128 B), 24 pieces of 8 rows, PPW per wave ----
+  // ---- DMA pieces of one chunk: 24 of W^T (192 rows x 128 B) + BLK / 8 of dy (BLK rows x 128 B); PPW per wave ----
   const int r8 = lane >> 3;
-  int soff[PPW];
+  const bf16* psrc[PPW];
+  int pdst[PPW];
+  const bf16* zerop = reinterpret_cast<const bf16*>(g_zero_page_lg);
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
-    const int row = (wave * PPW + i) * 8 + r8;
+    const int q = wave * PPW + i;
+    const int row = (q < 24 ? q : q - 24) * 8 + r8;
     const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
-    soff[i] = row * N + (((lane & 7) ^ (key << 1)) * 8);
+    const int col = ((lane & 7) ^ (key << 1)) * 8;
+    if (q < 24) {
+      psrc[i] = p.w + (size_t)row * N + col;
+      pdst[i] = q * 1024;
+    } else {
+      psrc[i] = blk0 + row < p.R ? p.y + (size_t)(blk0 + row) * N + col : nullptr;     // rows past R: zero page
+      pdst[i] = LG_WB + (q - 24) * 1024;
+    }
   }
-  auto issue = [&](int c, int buf) {
-    char* base = smem + buf * LG_WB + wave * PPW * 1024;
-    const bf16* src = p.w + (size_t)c * 64;
+  auto issue = [&](int c) {
+    char* base = smem + (c % LG_BWD_SLOTS) * SLOT;
 #pragma unroll
-    for (int i = 0; i < PPW; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
-                                       (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+    for (int i = 0; i < PPW; ++i) {
+      const bf16* src = psrc[i] ? psrc[i] + (size_t)c * 64 : zerop;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + pdst[i]), 16, 0, 0);
+    }
   };
-
-  const size_t nrows = (size_t)(p.R - blk0 < BLK ? p.R - blk0 : BLK);
-  const __amdgpu_buffer_rsrc_t r_y = lg_rsrc(p.y + (size_t)blk0 * N, nrows * N * 2);
-  const int vo[2] = {((32 * tg + fr) * N + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * N + 32 * hh + 8 * fq) * 2};
-  // B fragments of chunk c: the lane's 8 consecutive k of token tile t, fetched one chunk ahead (before the DMA)
-  u32x4 bn[2];
-  bn[0] = __builtin_amdgcn_raw_buffer_load_b128(r_y, vo[0], 0, 0);
-  bn[1] = __builtin_amdgcn_raw_buffer_load_b128(r_y, vo[1], 0, 0);
-  issue(0, 0);
+#pragma unroll
+  for (int c = 0; c < LG_BWD_SLOTS - 1; ++c)
+    if (c < nchunks) issue(c);
 
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
-  const uint32_t aw2 = lbase + fr * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));        // + dt*2048 (+ buffer)
+  const uint32_t aw2 = lbase + fr * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));        // + dt*2048 (+ slot)
+  const uint32_t ab0 = lbase + LG_WB + (32 * tg + fr) * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));   // token tile 0; tile 1: + 2048
 
   f32x4 yacc[12][2];
 #pragma unroll
   for (int dt = 0; dt < 12; ++dt) { yacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; yacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
   for (int c = 0; c < nchunks; ++c) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // chunk c: W piece DMA and B fragments
-    __builtin_amdgcn_s_barrier();
-    const u32x4 pf[2] = {bn[0], bn[1]};
-    const uint32_t a2 = aw2 + (c & 1) * LG_WB;
-    u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
-    SITK_LG_ISSUE4(y0, y1, y2, y3, a2, a2, 0, 2048, 4096, 6144);
-    if (c + 1 < nchunks) {
-      bn[0] = __builtin_amdgcn_raw_buffer_load_b128(r_y, vo[0], (c + 1) * 128, 0);
-      bn[1] = __builtin_amdgcn_raw_buffer_load_b128(r_y, vo[1], (c + 1) * 128, 0);
-      issue(c + 1, (c + 1) & 1);
-    }
+    // chunk c has landed; chunks c + 1 .. c + SLOTS - 2 (PPW instructions each) may stay in flight
+    const int ahead = min(LG_BWD_SLOTS - 2, nchunks - 1 - c);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                            // ... for every wave; slot (c - 1) % SLOTS is no longer read
+    if (c + LG_BWD_SLOTS - 1 < nchunks) issue(c + LG_BWD_SLOTS - 1);
+    const uint32_t bo = (c % LG_BWD_SLOTS) * SLOT;
+    const uint32_t a2 = aw2 + bo, b2 = ab0 + bo;
+    u32x4 x0, x1, x2, x3, y0, y1, y2, y3, pf0, pf1;
+    asm volatile("ds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:2048\n\t"
+                 "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:2048\n\t"
+                 "ds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %6 offset:6144"
+                 : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(pf0), "=&v"(pf1)
+                 : "v"(a2), "v"(b2)
+                 : "memory");
 #define SITK_LG_MMAS2(J, f0, f1, f2, f3)                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    yacc[4 * J + 0][0] = Mma<bf16>::mma(f0, pf[0], yacc[4 * J + 0][0]);                                     \
-    yacc[4 * J + 0][1] = Mma<bf16>::mma(f0, pf[1], yacc[4 * J + 0][1]);                                     \
-    yacc[4 * J + 1][0] = Mma<bf16>::mma(f1, pf[0], yacc[4 * J + 1][0]);                                     \
-    yacc[4 * J + 1][1] = Mma<bf16>::mma(f1, pf[1], yacc[4 * J + 1][1]);                                     \
-    yacc[4 * J + 2][0] = Mma<bf16>::mma(f2, pf[0], yacc[4 * J + 2][0]);                                     \
-    yacc[4 * J + 2][1] = Mma<bf16>::mma(f2, pf[1], yacc[4 * J + 2][1]);                                     \
-    yacc[4 * J + 3][0] = Mma<bf16>::mma(f3, pf[0], yacc[4 * J + 3][0]);                                     \
-    yacc[4 * J + 3][1] = Mma<bf16>::mma(f3, pf[1], yacc[4 * J + 3][1]);                                     \
+    yacc[4 * J + 0][0] = Mma<bf16>::mma(f0, pf0, yacc[4 * J + 0][0]);                                       \
+    yacc[4 * J + 0][1] = Mma<bf16>::mma(f0, pf1, yacc[4 * J + 0][1]);                                       \
+    yacc[4 * J + 1][0] = Mma<bf16>::mma(f1, pf0, yacc[4 * J + 1][0]);                                       \
+    yacc[4 * J + 1][1] = Mma<bf16>::mma(f1, pf1, yacc[4 * J + 1][1]);                                       \
+    yacc[4 * J + 2][0] = Mma<bf16>::mma(f2, pf0, yacc[4 * J + 2][0]);                                       \
+    yacc[4 * J + 2][1] = Mma<bf16>::mma(f2, pf1, yacc[4 * J + 2][1]);                                       \
+    yacc[4 * J + 3][0] = Mma<bf16>::mma(f3, pf0, yacc[4 * J + 3][0]);                                       \
+    yacc[4 * J + 3][1] = Mma<bf16>::mma(f3, pf1, yacc[4 * J + 3][1]);                                       \
     __builtin_amdgcn_sched_barrier(0);
-    SITK_LG_WAIT_ISSUE4(y0, y1, y2, y3, x0, x1, x2, x3, a2, a2, 8192, 10240, 12288, 14336);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "ds_read_b128 %6, %10 offset:8192\n\tds_read_b128 %7, %10 offset:10240\n\t"
+                 "ds_read_b128 %8, %10 offset:12288\n\tds_read_b128 %9, %10 offset:14336"
+                 : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(pf0), "+v"(pf1), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                 : "v"(a2)
+                 : "memory");
     SITK_LG_MMAS2(0, y0, y1, y2, y3)
     SITK_LG_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a2, a2, 16384, 18432, 20480, 22528);
     SITK_LG_MMAS2(1, x0, x1, x2, x3)
