@@ -949,8 +949,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tiles 0 and 1 (and the Q fragments) have landed
 
   int ring_stage = 0;
+  // tail_c: 0 = full key tile; NT > 0 = the last, partly filled tile, of which only NT 16-key blocks are computed
   auto body = [&](int t, auto tail_c, auto first_c) {
-    constexpr bool TAIL = decltype(tail_c)::value, FIRST = decltype(first_c)::value;
+    constexpr int NT = decltype(tail_c)::value ? decltype(tail_c)::value : 4;
+    constexpr bool TAIL = decltype(tail_c)::value != 0, FIRST = decltype(first_c)::value;
     __builtin_amdgcn_s_barrier();                         // every wave's pieces of tile t; stage (t + 2) % 3 no longer read
     const int stage = ring_stage;
     ring_stage = ring_stage == RING_STAGES - 1 ? 0 : ring_stage + 1;
@@ -968,7 +970,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
 #pragma unroll
       for (int i = 0; i < 4; ++i) s[j][i] = FIRST ? splat4(0.f) : negm[j];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     for (int j = 0; j < QT; ++j) {
       float mxl = -INFINITY;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           if constexpr (TAIL) {
@@ -998,12 +1000,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
         m[j] += delta;
         negm[j] = splat4(-m[j]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[j][i] -= delta;
+        for (int i = 0; i < NT; ++i) s[j][i] -= delta;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) s[j][i][jj] = fast_exp2(s[j][i][jj]);
+        for (int jj = 0; jj < 4; ++jj) s[j][i][jj] = i < NT ? fast_exp2(s[j][i][jj]) : 0.f;
       pf[j][0] = pack_pair(s[j][0], s[j][1]);
       pf[j][1] = pack_pair(s[j][2], s[j][3]);
     }
@@ -1015,7 +1017,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     __builtin_amdgcn_sched_barrier(0);                    // the DMA issue stays behind the last LDS read of the iteration
     if (t + 2 < nkt) dma.issue_any(smem, t + 2, N);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int s2 = 0; s2 < (NT + 1) / 2; ++s2) {
 #pragma unroll
       for (int j = 0; j < QT; ++j) lacc[j] = Mma<bf16>::mma(ones, pf[j][s2], lacc[j]);    // row sums of P on the matrix pipe
 #pragma unroll
@@ -1025,9 +1027,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     }
   };
   const int nfull = N >> 6;                               // >= 1 (ring kernels take N >= 64)
-  body(0, std::false_type{}, std::true_type{});
-  for (int t = 1; t < nfull; ++t) body(t, std::false_type{}, std::false_type{});
-  if (nfull < nkt) body(nfull, std::true_type{}, std::false_type{});
+  constexpr std::integral_constant<int, 0> full{};
+  body(0, full, std::true_type{});
+  for (int t = 1; t < nfull; ++t) body(t, full, std::false_type{});
+  if (nfull < nkt) tail_dispatch(N - 64 * nfull, [&](auto nt) { body(nfull, nt, std::false_type{}); });
   if (!active) return;
 #pragma unroll
   for (int j = 0; j < QT; ++j) {
@@ -1102,7 +1105,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
 
   int ring_stage = 0;
   auto body = [&](int t, auto tail_c) {
-    constexpr bool TAIL = decltype(tail_c)::value;
+    constexpr int NT = decltype(tail_c)::value ? decltype(tail_c)::value : 4;
+    constexpr bool TAIL = decltype(tail_c)::value != 0;
     __builtin_amdgcn_s_barrier();
     const int stage = ring_stage;
     ring_stage = ring_stage == RING_STAGES - 1 ? 0 : ring_stage + 1;
@@ -1123,13 +1127,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
         const f32x4 s0 = splat4(Lq[j]), d0 = splat4(ndl[j]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          if (i >= NT) { s[i] = splat4(0.f); continue; }
           s[i] = Mma<bf16>::mma(kf[i][0], qf[j][0], s0);
           dp[i] = Mma<bf16>::mma(vf[i][0], dof[j][0], d0);
           s[i] = Mma<bf16>::mma(kf[i][1], qf[j][1], s[i]);
           dp[i] = Mma<bf16>::mma(vf[i][1], dof[j][1], dp[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NT; ++i) {
           f32x4 x;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) {
@@ -1152,15 +1157,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
     __builtin_amdgcn_sched_barrier(0);
     if (t + 2 < nkt) dma.issue_any(smem, t + 2, N);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < (NT + 1) / 2; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int j = 0; j < QT; ++j) dq[j][dt] = Mma<bf16>::mma(kt[s2][dt], pf[j][s2], dq[j][dt]);
   };
   const int nfull = N >> 6;
-  for (int t = 0; t < nfull; ++t) body(t, std::false_type{});
-  if (nfull < nkt) body(nfull, std::true_type{});
+  for (int t = 0; t < nfull; ++t) body(t, std::integral_constant<int, 0>{});
+  if (nfull < nkt) tail_dispatch(N - 64 * nfull, [&](auto nt) { body(nfull, nt); });
   if (!active) return;
 #pragma unroll
   for (int j = 0; j < QT; ++j)
@@ -1225,7 +1230,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
   __syncthreads();                                        // statistics visible
 
   int ring_stage = 0;
-  auto body = [&](int t) {
+  // nt_c: 0 = full query tile; NT > 0 = the last, partly filled tile (only NT of its 16-query blocks are computed)
+  auto body = [&](int t, auto nt_c) {
+    constexpr int NT = decltype(nt_c)::value ? decltype(nt_c)::value : 4, NS2 = (NT + 1) / 2;
     __builtin_amdgcn_s_barrier();
     const int stage = ring_stage;
     ring_stage = ring_stage == RING_STAGES - 1 ? 0 : ring_stage + 1;
@@ -1253,13 +1260,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          if (i >= NT) { s[i] = splat4(0.f); dp[i] = splat4(0.f); continue; }
           s[i] = Mma<bf16>::mma(qr[i][0], kf[j][0], sl[i]);
           dp[i] = Mma<bf16>::mma(dor[i][0], vf[j][0], sd[i]);
           s[i] = Mma<bf16>::mma(qr[i][1], kf[j][1], s[i]);
           dp[i] = Mma<bf16>::mma(dor[i][1], vf[j][1], dp[i]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NT; ++i) {
           f32x4 x;
 #pragma unroll
           for (int jj = 0; jj < 4; ++jj) x[jj] = fast_exp2(s[i][jj]);
@@ -1273,7 +1281,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
       }
     }
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < NS2; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         const u32x4 f = ring_tr_frag(tile + 8192, lo, s2, dt);          // dO^T
@@ -1288,13 +1296,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
     __builtin_amdgcn_sched_barrier(0);
     if (t + 2 < nqt) dma.issue_any(smem, t + 2, N);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
+    for (int s2 = 0; s2 < NS2; ++s2)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int j = 0; j < QT; ++j) dk[j][dt] = Mma<bf16>::mma(qt_[s2][dt], pds[j][s2], dk[j][dt]);
   };
-  for (int t = 0; t < nqt; ++t) body(t);
+  const int nfull = N >> 6;
+  for (int t = 0; t < nfull; ++t) body(t, std::integral_constant<int, 0>{});
+  if (nfull < nqt) tail_dispatch(N - 64 * nfull, [&](auto nt) { body(nfull, nt); });
   if (!active) return;
 #pragma unroll
   for (int j = 0; j < QT; ++j)
