@@ -108,11 +108,11 @@ SITK_DEV void gemm_epilogue(const GemmParams& p, int m, int n, f32x4 v, float& l
 }
 
 // Epilogue math only (no stores): v <- acc (+bias) (+residual | * gelu'(u)); v2 <- gelu(v) for BIAS_GELU.
-template <typename T, int EPI>
+template <typename T, int EPI, bool RES_LATER = false>
 SITK_DEV void epilogue_math(const GemmParams& p, int m, int n, f32x4& v, f32x4& v2) {
   if (p.bias) v += load4(p.bias + n);
   if constexpr (EPI == SITK_EPI_BIAS_RES) {
-    v += load4(reinterpret_cast<const float*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
+    if constexpr (!RES_LATER) v += load4(reinterpret_cast<const float*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
   } else if constexpr (EPI == SITK_EPI_BIAS_GELU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v2[i] = v[i] * gelu_parts<T>(v[i]).cdf;
@@ -128,7 +128,9 @@ SITK_DEV void epilogue_math(const GemmParams& p, int m, int n, f32x4& v, f32x4& 
 
 // A 16-row x BN-column half tile held as v[i] = 4 features (16 i + 4*(lane>>4) ..) of row lane&15 goes
 // through a wave-private LDS region and out to global memory as whole rows, 16 bytes per lane.
-template <typename TS, int BN>
+// RES (fp32 outputs of the BIAS_RES epilogue): the residual is added HERE, read as whole rows like the store, instead of in
+// accumulator layout in front of the staging (16 rows x 64 B per wave instruction there).
+template <typename TS, int BN, bool RES = false>
 SITK_DEV void staged_rows_store(char* slot, const f32x4 (&v)[BN / 16], TS* out, const GemmParams& p, int mrow, int n0, int lane) {
   constexpr int PB = BN * (int)sizeof(TS) + 16;     // padded row pitch (bytes)
   constexpr int CPRW = BN * (int)sizeof(TS) / 16;   // 16-byte chunks per row
@@ -139,9 +141,16 @@ SITK_DEV void staged_rows_store(char* slot, const f32x4 (&v)[BN / 16], TS* out, 
 #pragma unroll
   for (int c0 = 0; c0 < 16 * CPRW; c0 += 64) {
     const int c = c0 + lane, row = c / CPRW, cc = c % CPRW;
-    const u32x4 d = *reinterpret_cast<const u32x4*>(slot + row * PB + cc * 16);
+    u32x4 d = *reinterpret_cast<const u32x4*>(slot + row * PB + cc * 16);
     const int m = mrow + row, n = n0 + cc * EPC;
-    if (m < p.M && n < p.N) *reinterpret_cast<u32x4*>(out + (size_t)map_row(p.omap, m) * p.ldo + n) = d;
+    if (m < p.M && n < p.N) {
+      if constexpr (RES) {
+        static_assert(!RES || sizeof(TS) == 4, "residual epilogue writes fp32");
+        const f32x4 r = load4(reinterpret_cast<const float*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
+        d = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, d) + r);
+      }
+      *reinterpret_cast<u32x4*>(out + (size_t)map_row(p.omap, m) * p.ldo + n) = d;
+    }
   }
 }
 
@@ -397,9 +406,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_wres_kernel(GemmParams p, 
         const int n = n0 + 16 * i + 4 * fq, m = mrow + fr;
         v1[i] = acc[i][j];
         v2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (m < p.M && n < p.N) epilogue_math<T, EPI>(p, m, n, v1[i], v2[i]);
+        if (m < p.M && n < p.N) epilogue_math<T, EPI, true>(p, m, n, v1[i], v2[i]);   // (residual: row layout, below)
       }
-      staged_rows_store<TO, BN>(slot, v1, reinterpret_cast<TO*>(p.out), p, mrow, n0, lane);
+      staged_rows_store<TO, BN, EPI == SITK_EPI_BIAS_RES>(slot, v1, reinterpret_cast<TO*>(p.out), p, mrow, n0, lane);
       if constexpr (EPI == SITK_EPI_BIAS_GELU) staged_rows_store<T, BN>(slot, v2, reinterpret_cast<T*>(p.out2), p, mrow, n0, lane);
     }
     if (strip + nunits < nstrips) issue(strip + nunits);            // slot free again: refill it
@@ -528,9 +537,9 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams
       const int n = n0 + wn * 96 + 16 * i + 4 * fq, m = mrow + fr;
       v1[i] = acc[i][j];
       v2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m < p.M && n < p.N) epilogue_math<T, EPI>(p, m, n, v1[i], v2[i]);
+      if (m < p.M && n < p.N) epilogue_math<T, EPI, true>(p, m, n, v1[i], v2[i]);     // (the residual joins in row layout below)
     }
-    staged_rows_store<TO, 96>(slot, v1, reinterpret_cast<TO*>(p.out), p, mrow, n0 + wn * 96, lane);
+    staged_rows_store<TO, 96, EPI == SITK_EPI_BIAS_RES>(slot, v1, reinterpret_cast<TO*>(p.out), p, mrow, n0 + wn * 96, lane);
     if constexpr (EPI == SITK_EPI_BIAS_GELU) staged_rows_store<T, 96>(slot, v2, reinterpret_cast<T*>(p.out2), p, mrow, n0 + wn * 96, lane);
   }
 }
