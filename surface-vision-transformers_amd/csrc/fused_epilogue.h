@@ -17,7 +17,8 @@ namespace sitk {
 
 constexpr int FE_D = 192;
 constexpr int FE_PITCH = 196;                              // floats; rows shift by 16 B per row in the 256-B bank window
-// A workgroup owns 32 TG rows (TG token groups of 32 rows = 2 TG waves); TG = 4 or 3 (see fused_block_rows()).
+// A workgroup owns 16 TT TG rows: TG token groups of TT 16-row MFMA tiles, 2 waves per group (the two halves of
+// the feature dimension).  (TG, TT) = (4, 2), (3, 2) or (6, 1); see fused_block_rows().
 constexpr int fe_smem_bytes(int tg) { return 32 * tg * FE_PITCH * 4; }   // row buffer (the column partials alias it)
 constexpr int FE_SMEM_BYTES = fe_smem_bytes(4);            // 100352
 
@@ -27,11 +28,11 @@ constexpr int FE_SMEM_BYTES = fe_smem_bytes(4);            // 100352
 // workgroups of 96 instead of 161 of 128).
 static inline int fused_block_rows(int64_t rows) { return (rows + 95) / 96 <= 256 ? 96 : 128; }
 
-// v[i][t]: this wave's finished half of dh -- features 96 hh + 16 i + 4 fq + e of token 32 tg + 16 t + fr
+// v[i][t]: this wave's finished half of dh -- features 96 hh + 16 i + 4 fq + e of token 16 TT tg + 16 t + fr
 // (pair exchange already done).  smem: >= FE_SMEM_BYTES, free for use by every wave (callers sync before).
 // All threads of the workgroup must call it.
-template <int TG>
-SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, int blk0, int R, const float* __restrict__ x,
+template <int TG, int TT = 2>
+SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][TT], int tid, int blk0, int R, const float* __restrict__ x,
                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                    const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
                                    bf16* __restrict__ dxc, float* __restrict__ partials_block) {
@@ -41,18 +42,18 @@ SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, 
   const int j = lane & 15, sub = lane >> 4;                   // row pass: 16 lanes per row, 4 rows per pass
   float* rowbuf = reinterpret_cast<float*>(smem);
 
-  // ---- request this wave's 16 rows of x and dres (4 passes x 3 x 16 B per lane each), statistics, gamma ----
-  constexpr int BLK = 32 * TG;
+  // ---- request this wave's 8 TT rows of x and dres (2 TT passes x 3 x 16 B per lane each), statistics, gamma ----
+  constexpr int BLK = 16 * TT * TG;
   const size_t nrows = (size_t)(R - blk0 < BLK ? R - blk0 : BLK);
   const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)blk0 * D, 0,
                                                                        (int)(nrows * D * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dres ? dres : x) + (size_t)blk0 * D, 0,
                                                                        dres ? (int)(nrows * D * 4) : 0, 0x00020000);
-  f32x4 xv[4][3], dv[4][3], gm[3];
-  float mu[4], rs[4];
+  f32x4 xv[2 * TT][3], dv[2 * TT][3], gm[3];
+  float mu[2 * TT], rs[2 * TT];
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int r = wave * 16 + pass * 4 + sub;
+  for (int pass = 0; pass < 2 * TT; ++pass) {
+    const int r = wave * (8 * TT) + pass * 4 + sub;
     const bool ok = blk0 + r < R;
     mu[pass] = ok ? mean[blk0 + r] : 0.f;
     rs[pass] = ok ? rstd[blk0 + r] : 0.f;
@@ -69,20 +70,20 @@ SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, 
   // ---- dh: accumulator layout -> row-major fp32 (the callers' exchange area is being overwritten) ----
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < TT; ++t)
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      *reinterpret_cast<f32x4*>(rowbuf + (32 * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
+      *reinterpret_cast<f32x4*>(rowbuf + (16 * TT * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
   __syncthreads();
 
   // ---- LayerNorm backward, 4 rows per pass ----
   f32x4 dgs[3], dbs[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) { dgs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dbs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  f32x4 outv[4][3];
+  f32x4 outv[2 * TT][3];
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int r = wave * 16 + pass * 4 + sub;
+  for (int pass = 0; pass < 2 * TT; ++pass) {
+    const int r = wave * (8 * TT) + pass * 4 + sub;
     f32x4 dh[3], xh[3];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -110,8 +111,8 @@ SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, 
   const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(dxc ? dxc + (size_t)blk0 * D : (bf16*)dx, 0,
                                                                        dxc ? (int)(nrows * D * 2) : 0, 0x00020000);
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int r = wave * 16 + pass * 4 + sub;
+  for (int pass = 0; pass < 2 * TT; ++pass) {
+    const int r = wave * (8 * TT) + pass * 4 + sub;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int col = 4 * (j + 16 * i);
@@ -140,38 +141,38 @@ SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, 
 }
 
 // Forward counterpart: out = v + bias + x, rows of x re-read and rows of out written whole (same layouts as above).
-template <int TG>
-SITK_DEV void residual_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid, int blk0, int R, const float* __restrict__ x,
+template <int TG, int TT = 2>
+SITK_DEV void residual_rows_epilogue(char* smem, const f32x4 (&v)[6][TT], int tid, int blk0, int R, const float* __restrict__ x,
                                      const float* __restrict__ bias, float* __restrict__ out) {
   constexpr int D = FE_D;
   const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4, tg = wave >> 1, hh = wave & 1;
   const int j = lane & 15, sub = lane >> 4;
   float* rowbuf = reinterpret_cast<float*>(smem);
-  constexpr int BLK = 32 * TG;
+  constexpr int BLK = 16 * TT * TG;
   const size_t nrows = (size_t)(R - blk0 < BLK ? R - blk0 : BLK);
   const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)blk0 * D, 0,
                                                                        (int)(nrows * D * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_o = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)blk0 * D, 0, (int)(nrows * D * 4), 0x00020000);
-  f32x4 xv[4][3], bb[3];
+  f32x4 xv[2 * TT][3], bb[3];
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass)
+  for (int pass = 0; pass < 2 * TT; ++pass)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       xv[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-          r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+          r_x, ((wave * (8 * TT) + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
 #pragma unroll
   for (int i = 0; i < 3; ++i) bb[i] = load4(bias + 4 * (j + 16 * i));
   __syncthreads();                                            // the callers' exchange area is being overwritten
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < TT; ++t)
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      *reinterpret_cast<f32x4*>(rowbuf + (32 * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
+      *reinterpret_cast<f32x4*>(rowbuf + (16 * TT * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
   __syncthreads();
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int r = wave * 16 + pass * 4 + sub;
+  for (int pass = 0; pass < 2 * TT; ++pass) {
+    const int r = wave * (8 * TT) + pass * 4 + sub;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int col = 4 * (j + 16 * i);
@@ -185,13 +186,13 @@ SITK_DEV void residual_rows_epilogue(char* smem, const f32x4 (&v)[6][2], int tid
 // above).  Rows take the trip through LDS, then per row: x_mid = v + bias + x (stored whole), LayerNorm
 // statistics, h = LN(x_mid) into the operand strip `strip` ([k-panel][32 TG rows][128 B], swizzled with lds_off)
 // and, when asked for, to global memory.  Ends with a workgroup barrier (the strip is complete).
-template <int TG>
-SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4 (&v)[6][2], int tid, int blk0, int R,
+template <int TG, int TT = 2>
+SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4 (&v)[6][TT], int tid, int blk0, int R,
                                     const float* __restrict__ x, const float* __restrict__ bias,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     float* __restrict__ xmid, bf16* __restrict__ h, float* __restrict__ mean,
                                     float* __restrict__ rstd) {
-  constexpr int D = FE_D, BLK = 32 * TG;
+  constexpr int D = FE_D, BLK = 16 * TT * TG;
   const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4, tg = wave >> 1, hh = wave & 1;
   const int j = lane & 15, sub = lane >> 4;
@@ -202,13 +203,13 @@ SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4
   const __amdgpu_buffer_rsrc_t r_m = __builtin_amdgcn_make_buffer_rsrc(xmid + (size_t)blk0 * D, 0, (int)(nrows * D * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc(h ? h + (size_t)blk0 * D : (bf16*)xmid, 0,
                                                                        h ? (int)(nrows * D * 2) : 0, 0x00020000);
-  f32x4 xv[4][3], bb[3], gm[3], bt[3];
+  f32x4 xv[2 * TT][3], bb[3], gm[3], bt[3];
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass)
+  for (int pass = 0; pass < 2 * TT; ++pass)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       xv[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-          r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+          r_x, ((wave * (8 * TT) + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     bb[i] = load4(bias + 4 * (j + 16 * i));
@@ -216,14 +217,14 @@ SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4
     bt[i] = load4(beta + 4 * (j + 16 * i));
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < TT; ++t)
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      *reinterpret_cast<f32x4*>(rowbuf + (32 * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
+      *reinterpret_cast<f32x4*>(rowbuf + (16 * TT * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
   __syncthreads();
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int r = wave * 16 + pass * 4 + sub, row = blk0 + r;
+  for (int pass = 0; pass < 2 * TT; ++pass) {
+    const int r = wave * (8 * TT) + pass * 4 + sub, row = blk0 + r;
     const bool ok = row < R;
     f32x4 xm[3];
     float s = 0.f;

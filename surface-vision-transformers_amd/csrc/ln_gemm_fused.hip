@@ -12,6 +12,8 @@
 // the layouts, the slot permutation that makes a lane's 8 accumulator values consecutive features, the
 // buffer-descriptor row I/O and the store keep-alive).  One launch replaces LayerNorm + GEMM (forward) or
 // GEMM + LayerNorm backward (backward) and the (tokens x 192) round trip through HBM between them.
+#include <cstdlib>
+
 #include "common.h"
 #include "fused_epilogue.h"
 
@@ -244,12 +246,12 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_fwd_kernel(LnGemmParams p) {
 // through the same ring: as register loads it would sit in the in-order vmcnt queue between the DMA pieces and force
 // every older piece home with it.
 constexpr int LG_BWD_SLOTS = 4;
-template <int TG>
+template <int TG, int TT = 2>
 __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
-  constexpr int D = LG_D, BLK = 32 * TG, NW = 2 * TG;
+  constexpr int D = LG_D, BLK = 16 * TT * TG, NW = 2 * TG;
   constexpr int DYB = BLK * 128;                       // dy chunk image: BLK rows x 128 B
   constexpr int SLOT = LG_WB + DYB;                    // W^T chunk (24 KB) + dy chunk
-  constexpr int NP = 24 + BLK / 8, PPW = NP / NW;      // DMA pieces per chunk (36 / 40) and per wave (6 / 5)
+  constexpr int NP = 24 + BLK / 8, PPW = NP / NW;      // DMA pieces per chunk (36 / 40) and per wave (6 / 5; 3 with 12 waves)
   static_assert(PPW * NW == NP, "pieces must divide evenly");
   constexpr int RING = LG_BWD_SLOTS * SLOT;
   constexpr int SMEM = RING > LG_SMEM_BWD ? RING : LG_SMEM_BWD;
@@ -296,11 +298,13 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
   const uint32_t aw2 = lbase + fr * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));        // + dt*2048 (+ slot)
-  const uint32_t ab0 = lbase + LG_WB + (32 * tg + fr) * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));   // token tile 0; tile 1: + 2048
+  const uint32_t ab0 = lbase + LG_WB + (16 * TT * tg + fr) * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));   // token tile 0; tile 1: + 2048
 
-  f32x4 yacc[12][2];
+  f32x4 yacc[12][TT];
 #pragma unroll
-  for (int dt = 0; dt < 12; ++dt) { yacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; yacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int dt = 0; dt < 12; ++dt)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) yacc[dt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int c = 0; c < nchunks; ++c) {
     // chunk c has landed; chunks c + 1 .. c + SLOTS - 2 (PPW instructions each) may stay in flight
@@ -312,30 +316,42 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
     if (c + LG_BWD_SLOTS - 1 < nchunks) issue(c + LG_BWD_SLOTS - 1);
     const uint32_t bo = (c % LG_BWD_SLOTS) * SLOT;
     const uint32_t a2 = aw2 + bo, b2 = ab0 + bo;
-    u32x4 x0, x1, x2, x3, y0, y1, y2, y3, pf0, pf1;
-    asm volatile("ds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:2048\n\t"
-                 "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:2048\n\t"
-                 "ds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %6 offset:6144"
-                 : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(pf0), "=&v"(pf1)
-                 : "v"(a2), "v"(b2)
-                 : "memory");
+    u32x4 x0, x1, x2, x3, y0, y1, y2, y3, pf[TT];
+    if constexpr (TT == 2)
+      asm volatile("ds_read_b128 %4, %7\n\tds_read_b128 %5, %7 offset:2048\n\t"
+                   "ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:2048\n\t"
+                   "ds_read_b128 %2, %6 offset:4096\n\tds_read_b128 %3, %6 offset:6144"
+                   : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(pf[0]), "=&v"(pf[TT - 1])
+                   : "v"(a2), "v"(b2)
+                   : "memory");
+    else
+      asm volatile("ds_read_b128 %4, %6\n\t"
+                   "ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:2048\n\t"
+                   "ds_read_b128 %2, %5 offset:4096\n\tds_read_b128 %3, %5 offset:6144"
+                   : "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3), "=&v"(pf[0])
+                   : "v"(a2), "v"(b2)
+                   : "memory");
 #define SITK_LG_MMAS2(J, f0, f1, f2, f3)                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    yacc[4 * J + 0][0] = Mma<bf16>::mma(f0, pf0, yacc[4 * J + 0][0]);                                       \
-    yacc[4 * J + 0][1] = Mma<bf16>::mma(f0, pf1, yacc[4 * J + 0][1]);                                       \
-    yacc[4 * J + 1][0] = Mma<bf16>::mma(f1, pf0, yacc[4 * J + 1][0]);                                       \
-    yacc[4 * J + 1][1] = Mma<bf16>::mma(f1, pf1, yacc[4 * J + 1][1]);                                       \
-    yacc[4 * J + 2][0] = Mma<bf16>::mma(f2, pf0, yacc[4 * J + 2][0]);                                       \
-    yacc[4 * J + 2][1] = Mma<bf16>::mma(f2, pf1, yacc[4 * J + 2][1]);                                       \
-    yacc[4 * J + 3][0] = Mma<bf16>::mma(f3, pf0, yacc[4 * J + 3][0]);                                       \
-    yacc[4 * J + 3][1] = Mma<bf16>::mma(f3, pf1, yacc[4 * J + 3][1]);                                       \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 0][t] = Mma<bf16>::mma(f0, pf[t], yacc[4 * J + 0][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 1][t] = Mma<bf16>::mma(f1, pf[t], yacc[4 * J + 1][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 2][t] = Mma<bf16>::mma(f2, pf[t], yacc[4 * J + 2][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 3][t] = Mma<bf16>::mma(f3, pf[t], yacc[4 * J + 3][t]); \
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                 "ds_read_b128 %6, %10 offset:8192\n\tds_read_b128 %7, %10 offset:10240\n\t"
-                 "ds_read_b128 %8, %10 offset:12288\n\tds_read_b128 %9, %10 offset:14336"
-                 : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(pf0), "+v"(pf1), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-                 : "v"(a2)
-                 : "memory");
+    if constexpr (TT == 2)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                   "ds_read_b128 %6, %10 offset:8192\n\tds_read_b128 %7, %10 offset:10240\n\t"
+                   "ds_read_b128 %8, %10 offset:12288\n\tds_read_b128 %9, %10 offset:14336"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(pf[0]), "+v"(pf[TT - 1]), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                   : "v"(a2)
+                   : "memory");
+    else   // (one operand per register: listing pf[0] twice would make hipcc copy it while its read is in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                   "ds_read_b128 %5, %9 offset:8192\n\tds_read_b128 %6, %9 offset:10240\n\t"
+                   "ds_read_b128 %7, %9 offset:12288\n\tds_read_b128 %8, %9 offset:14336"
+                   : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(pf[0]), "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
+                   : "v"(a2)
+                   : "memory");
     SITK_LG_MMAS2(0, y0, y1, y2, y3)
     SITK_LG_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a2, a2, 16384, 18432, 20480, 22528);
     SITK_LG_MMAS2(1, x0, x1, x2, x3)
@@ -347,27 +363,27 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
   // ---- pair exchange: wave hh finishes features [96 hh, 96 hh + 96) (12 tiles x 1 KB per wave) ----
   __syncthreads();
   {
-    char* mine = smem + wave * 12288;
+    char* mine = smem + wave * (6144 * TT);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        *reinterpret_cast<f32x4*>(mine + ((i * 2 + t) * 64 + lane) * 16) = hh ? yacc[i][t] : yacc[6 + i][t];
+      for (int t = 0; t < TT; ++t)
+        *reinterpret_cast<f32x4*>(mine + ((i * TT + t) * 64 + lane) * 16) = hh ? yacc[i][t] : yacc[6 + i][t];
   }
   __syncthreads();
-  f32x4 v[6][2];
+  f32x4 v[6][TT];
   {
-    const char* theirs = smem + (wave ^ 1) * 12288;
+    const char* theirs = smem + (wave ^ 1) * (6144 * TT);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + ((i * 2 + t) * 64 + lane) * 16);
+      for (int t = 0; t < TT; ++t) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + ((i * TT + t) * 64 + lane) * 16);
         v[i][t] = (hh ? yacc[6 + i][t] : yacc[i][t]) + o;
       }
   }
   // ---- LayerNorm backward on dh = v, in row layout (fused_epilogue.h) ----
-  ln_bwd_rows_epilogue<TG>(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dres, p.dx, p.dxc,
+  ln_bwd_rows_epilogue<TG, TT>(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dres, p.dx, p.dxc,
                        p.partials + (size_t)blockIdx.x * 2 * D);
 }
 
@@ -422,7 +438,9 @@ extern "C" int sitk_ln_gemm_bwd(const void* dy, const void* wt_c, const float* x
   p.dres = dres; p.dx = dx; p.dxc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.N = N;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-  if (fused_block_rows(rows) == 96) hipLaunchKernelGGL(ln_gemm_bwd_kernel<3>, dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  static const int tt1 = getenv("SITK_LG_TT1") ? atoi(getenv("SITK_LG_TT1")) : 1;   // 12 waves x 16 tokens; 0: the 6 x 32 variant (A/B)
+  if (fused_block_rows(rows) == 96 && tt1) hipLaunchKernelGGL((ln_gemm_bwd_kernel<6, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
+  else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL(ln_gemm_bwd_kernel<3>, dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL(ln_gemm_bwd_kernel<4>, dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("ln_gemm_bwd");
 }

@@ -12,7 +12,13 @@
 // launches each direction costs a LayerNorm pass and two GEMMs whose (tokens x mlp_dim) operand makes
 // an extra HBM round trip; here it never leaves the registers between the two products.
 //
-// A workgroup (8 waves, 2 per SIMD) owns 128 tokens.  Wave w = (tg, hh): token group tg = w >> 1 (32
+// A workgroup owns 16 TT TG tokens: TG token groups of TT MFMA column tiles, two waves per group.  Two
+// geometries are launched: (TG, TT) = (6, 1), 96 tokens as 12 waves of 16 tokens -- 3 waves on every SIMD --
+// whenever 96-token workgroups cover the problem in one round (fused_block_rows()), else (4, 2), 128 tokens
+// as 8 waves of 32.  [Measured at the BASELINE shape, 20 544 tokens: 6 waves of 32 tokens sit 2,2,1,1 on the
+// SIMDs and the loaded pair sets the pace; 12 x 16 re-reads every weight fragment from LDS per 16 instead of
+// per 32 tokens (LDS array 36 % -> ~60 % busy in the loop) and still wins 3.6 % of the whole training step.]
+// The text below is written for TT = 2.  Wave w = (tg, hh): token group tg = w >> 1 (32
 // tokens = 2 MFMA column tiles) and half hh = w & 1 of every 64-unit chunk of the hidden dimension.
 // The wave keeps the 32 x 192 operand of the first product (h, or dy) in registers for the whole
 // kernel (12 fragments) and walks the hidden dimension in chunks of 64 units:
@@ -72,7 +78,7 @@ struct MlpParams {
 };
 
 __device__ u32x4 g_zero_page_mlp[4];
-__device__ unsigned long long g_mlp_stamps[2 * 8 * 8];   // diagnostic build (SITK_MLP_VAR=6): [wave][phase] cycle sums of workgroup 0
+__device__ unsigned long long g_mlp_stamps[2 * 16 * 8];   // diagnostic build (SITK_MLP_VAR=6): [wave][phase] cycle sums of workgroup 0
 
 // GELU without transcendentals in the loop.  v_exp_f32 / v_rcp_f32 run at a quarter of the VALU rate (16
 // cycles per wave instruction), and with one exp + one rcp per element the elementwise phase, not the
@@ -132,13 +138,13 @@ constexpr int MLP_OFF_TAB_F = MLP_OFF_B1 + MLP_MAX_M * 4;        // forward: {Ph
 constexpr int MLP_OFF_TAB_B = MLP_OFF_B1;                        // backward (no bias): {Phi, dPhi, pdf, dpdf} x 768 = 12 KB
 constexpr int MLP_SMEM = MLP_OFF_B1 + 12288;
 
-// TG = token groups (of 32 rows = 2 waves) per workgroup: 4 (128 rows, 8 waves) or 3 (96 rows, 6 waves);
-// see fused_block_rows() in fused_epilogue.h.
-template <bool BWD, int VAR = 0, int TG = 4, bool PROJ = false, bool NEXT = false>
+// TG = token groups (of 16 TT rows = 2 waves) per workgroup; (TG, TT) = (4, 2): 128 rows, 8 waves; (6, 1): 96 rows,
+// 12 waves; (3, 2): 96 rows, 6 waves (A/B only).  See fused_block_rows() in fused_epilogue.h.
+template <bool BWD, int VAR = 0, int TG = 4, bool PROJ = false, bool NEXT = false, int TT = 2>
 __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   static_assert(!NEXT || PROJ, "the appended LayerNorm + to_qkv shares the 96-row LDS plan of the projection prologue");
-  constexpr int D = MLP_D, BLK = 32 * TG, NT = 128 * TG, PPW = 24 / TG;   // rows, threads, DMA pieces per wave and chunk
-  static_assert(!PROJ || (!BWD && TG == 3), "the projection prologue needs Wo (72 KB) + a 96-row fp32 row buffer in LDS");
+  constexpr int D = MLP_D, BLK = 16 * TT * TG, NT = 128 * TG, PPW = 24 / TG;   // rows, threads, DMA pieces per wave and chunk
+  static_assert(!PROJ || (!BWD && BLK == 96), "the projection prologue needs Wo (72 KB) + a 96-row fp32 row buffer in LDS");
   constexpr int PAR = PROJ ? 1 : 0;                                      // ring slot of chunk 0
   constexpr int W1B = MLP_W1B, W2B = MLP_W2B;
   __shared__ __attribute__((aligned(256))) char smem[MLP_SMEM];
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   };
   if constexpr (!PROJ) issue(0, 0);
 
-  if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 0] = __builtin_amdgcn_s_memtime() - t_kernel0; }
+  if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 0] = __builtin_amdgcn_s_memtime() - t_kernel0; }
   // ---- GELU tables (see above): entry i = {f(x_i), f(x_i+1) - f(x_i)}; visible to everybody after the
   //      first barrier of the loop.  Two entries per thread.  The global loads are issued here, the LDS stores
   //      (in front of which hipcc drains every outstanding load: LDS-DMA aliasing) after the LayerNorm rows
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   // ---- operand strip: forward = LayerNorm of the block's rows (wave: 16 rows; 16 lanes per row, 4 rows
   //      per pass, all 12 loads in flight together); backward = the compute-dtype copy of dy ----
   char* sH = smem + MLP_OFF_H;
-  u32x4 hf[2][6];
+  u32x4 hf[TT][6];
   if constexpr (PROJ) {
     // ---- attention output projection + residual + LayerNorm (layers.i.0.fn.to_out.0, layers.i.1.norm) ----
     // LDS: Wo [0, 72 KB) as [k-panel][192 rows][128 B]; fp32 row buffer [72 KB, 145.5 KB); afterwards the operand
@@ -244,17 +250,19 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
                                        (__attribute__((address_space(3))) void*)(smem + kt * 24576 + (q % 24) * 1024), 16, 0, 0);
     }
     const __amdgpu_buffer_rsrc_t r_o = make_rsrc(p.o + oD, RD * 2);
-    u32x4 of[2][6];
+    u32x4 of[TT][6];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TT; ++t)
 #pragma unroll
       for (int k = 0; k < 6; ++k)
-        of[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_o, ((32 * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
+        of[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_o, ((16 * TT * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    f32x4 pacc[6][2];
+    f32x4 pacc[6][TT];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { pacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int t = 0; t < TT; ++t) pacc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int keyp = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
 #pragma unroll
     for (int k = 0; k < 6; ++k)
@@ -262,17 +270,17 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       for (int i = 0; i < 6; ++i) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(smem + (k >> 1) * 24576 + (96 * hh + 16 * i + fr) * 128 +
                                                         (((k & 1) * 64 + fq * 16) ^ (keyp << 5)));
-        pacc[i][0] = Mma<bf16>::mma(a, of[0][k], pacc[i][0]);
-        pacc[i][1] = Mma<bf16>::mma(a, of[1][k], pacc[i][1]);
+#pragma unroll
+        for (int t = 0; t < TT; ++t) pacc[i][t] = Mma<bf16>::mma(a, of[t][k], pacc[i][t]);
       }
-    proj_residual_ln_rows<TG>(smem + 73728, smem, pacc, tid, blk0, p.R, p.x, p.bo, p.gamma, p.beta, p.xmid, p.h, p.mean, p.rstd);
+    proj_residual_ln_rows<TG, TT>(smem + 73728, smem, pacc, tid, blk0, p.R, p.x, p.bo, p.gamma, p.beta, p.xmid, p.h, p.mean, p.rstd);
     issue(0, 1);                                               // the row buffer is dead: ring slot 1 takes chunk 0
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TT; ++t)
 #pragma unroll
       for (int k = 0; k < 6; ++k)
         hf[t][k] = *reinterpret_cast<const u32x4*>(smem + (k >> 1) * (BLK * 128) +
-                                                   lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
+                                                   lds_off(16 * TT * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
     store_tables();
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -288,21 +296,21 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     f32x4 gm[3], bt[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) { gm[i] = load4(p.gamma + 4 * (j + 16 * i)); bt[i] = load4(p.beta + 4 * (j + 16 * i)); }
-    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 1] = __builtin_amdgcn_s_memtime() - t_kernel0; }
-    f32x4 v[4][3];
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 1] = __builtin_amdgcn_s_memtime() - t_kernel0; }
+    f32x4 v[2 * TT][3];
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass)
+    for (int pass = 0; pass < 2 * TT; ++pass)
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         v[pass][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            r_x, ((wave * 16 + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
+            r_x, ((wave * (8 * TT) + pass * 4 + sub) * D + 4 * (j + 16 * i)) * 4, 0, 0));
     store_tables();
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (tid + NT * k < MLP_MAX_M) reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid + NT * k] = bvals[k];
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int r = wave * 16 + pass * 4 + sub, row = blk0 + r;
+    for (int pass = 0; pass < 2 * TT; ++pass) {
+      const int r = wave * (8 * TT) + pass * 4 + sub, row = blk0 + r;
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 3; ++i) s += v[pass][i][0] + v[pass][i][1] + v[pass][i][2] + v[pass][i][3];
@@ -331,26 +339,26 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       }
       if (ok && j == 0 && p.mean) { p.mean[row] = mu; p.rstd[row] = rs; }
     }
-    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 2] = __builtin_amdgcn_s_memtime() - t_kernel0; }
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 2] = __builtin_amdgcn_s_memtime() - t_kernel0; }
     __syncthreads();
-    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 3] = __builtin_amdgcn_s_memtime() - t_kernel0; }
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 3] = __builtin_amdgcn_s_memtime() - t_kernel0; }
     // this wave's operand fragments: token tile t, k-step k <-> 16 B of row 32 tg + 16 t + fr
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TT; ++t)
 #pragma unroll
       for (int k = 0; k < 6; ++k)
         hf[t][k] = *reinterpret_cast<const u32x4*>(sH + (k >> 1) * (BLK * 128) +
-                                                   lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
+                                                   lds_off(16 * TT * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
   } else {
     const __amdgpu_buffer_rsrc_t r_dyc = make_rsrc(p.dyc + oD, RD * 2);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TT; ++t)
 #pragma unroll
       for (int k = 0; k < 6; ++k)
-        hf[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_dyc, ((32 * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
+        hf[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_dyc, ((16 * TT * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
   }
 
-  if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[64 + wave * 8 + 4] = __builtin_amdgcn_s_memtime() - t_kernel0; }
+  if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 4] = __builtin_amdgcn_s_memtime() - t_kernel0; }
   // ---- per-lane LDS byte addresses ----
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int keyl = ((fr >> 1) & 1) | (((fr >> 3) & 1) << 1);
@@ -362,19 +370,24 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   const uint32_t ab1 = lbase + MLP_OFF_B1 + (32 * hh + 8 * fq) * 4;                   // + c*256
   const uint32_t ltabf = lbase + MLP_OFF_TAB_F, ltabb = lbase + MLP_OFF_TAB_B;
 
-  f32x4 yacc[12][2];                                          // accumulators of the second product
+  f32x4 yacc[12][TT];                                         // accumulators of the second product
 #pragma unroll
-  for (int dt = 0; dt < 12; ++dt) { yacc[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; yacc[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int dt = 0; dt < 12; ++dt)
+#pragma unroll
+    for (int t = 0; t < TT; ++t) yacc[dt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // (rows x M) operands: lane's 16 bytes of token tile t sit at vo[t] + (block, chunk) scalar offset
-  const int trow0 = blk0 + 32 * tg + fr, trow1 = trow0 + 16;
-  const int vo[2] = {((32 * tg + fr) * M + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * M + 32 * hh + 8 * fq) * 2};
+  int vo[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) vo[t] = ((16 * TT * tg + 16 * t + fr) * M + 32 * hh + 8 * fq) * 2;
   const int so0 = 0;                                           // scalar offset: chunk only (c * 128 bytes)
   // backward: the saved pre-activations u of chunk c + 1 are fetched as soon as chunk c's have been consumed,
   // by buffer loads the COMPILER DOES NOT SEE (inline asm): a compiler-visible load that is live across the
   // loop edge makes hipcc drain vmcnt to 0 -- every store of the chunk included -- twice per iteration.  The
   // counted waits below cover them instead.
-  u32x4 uc[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+  u32x4 uc[TT];
+#pragma unroll
+  for (int t = 0; t < TT; ++t) uc[t] = u32x4{0u, 0u, 0u, 0u};
   u32x4 srd_u = {0u, 0u, 0u, 0u};
   if constexpr (BWD) {
     const uint64_t ua = reinterpret_cast<uint64_t>(p.u + oM);
@@ -383,8 +396,11 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(RM * 2)), 0x00020000u};
   }
 #define SITK_MLP_LOAD_U(SOFF)                                                                              \
-  asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen"       \
-               : "=&v"(uc[0]), "=&v"(uc[1]) : "v"(vo[0]), "v"(vo[1]), "s"(srd_u), "s"(SOFF) : "memory")
+  if constexpr (TT == 2)                                                                                   \
+    asm volatile("buffer_load_dwordx4 %0, %2, %4, %5 offen\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen"     \
+                 : "=&v"(uc[0]), "=&v"(uc[TT - 1]) : "v"(vo[0]), "v"(vo[TT - 1]), "s"(srd_u), "s"(SOFF) : "memory"); \
+  else                                                                                                     \
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(uc[0]) : "v"(vo[0]), "s"(srd_u), "s"(SOFF) : "memory")
   if constexpr (BWD) { const int so_first = 0; SITK_MLP_LOAD_U(so_first); }
 
   // Waves w and w + 4 share a SIMD and the per-chunk barrier keeps them in lock step, so left alone they
@@ -394,7 +410,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   if (wave < TG) __builtin_amdgcn_s_setprio(2);
   // global stores each wave issues per chunk after the next chunk's DMA
   // backward adds the 2 u loads issued at the end of the elementwise phase
-  const int nstores = BWD ? (p.g ? 6 : 4) : (p.u ? 2 : 0) + (p.g ? 2 : 0);
+  const int nstores = TT * (BWD ? (p.g ? 3 : 2) : (p.u ? 1 : 0) + (p.g ? 1 : 0));
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define SITK_STAMP(i)                                                                    \
   if constexpr (VAR == 6) {                                                              \
@@ -409,7 +425,9 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     // chunk c's DMA (and, backward, its u loads) were issued before the previous iteration's stores
     // (pinned there by the "memory" clobbers of the fragment-read blocks), so only those stores may stay in flight
     if (c == 0 || nstores == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (nstores == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if (nstores == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (nstores == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if (nstores == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     SITK_STAMP(0)
@@ -425,28 +443,26 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 
     // ---- first product: uacc[i][t], hidden tile i (slot rows 32 hh + 16 i ..), token tile t; forward
     //      starts the accumulators at the bias ----
-    f32x4 uacc[2][2];
+    f32x4 uacc[2][TT];
     if constexpr (!BWD) {
       u32x4 t0, t1;
       const uint32_t ab = ab1 + c * 256;
       asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(t0), "=&v"(t1) : "v"(ab) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0), "+v"(t1), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : : "memory");
-      uacc[0][0] = uacc[0][1] = __builtin_bit_cast(f32x4, t0);
-      uacc[1][0] = uacc[1][1] = __builtin_bit_cast(f32x4, t1);
+#pragma unroll
+      for (int t = 0; t < TT; ++t) { uacc[0][t] = __builtin_bit_cast(f32x4, t0); uacc[1][t] = __builtin_bit_cast(f32x4, t1); }
     } else {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { uacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; uacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < TT; ++t) uacc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #define SITK_MLP_FC1_MMAS(KT, f0, f1, f2, f3)                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    uacc[0][0] = Mma<bf16>::mma(f0, hf[0][2 * KT], uacc[0][0]);                                             \
-    uacc[0][1] = Mma<bf16>::mma(f0, hf[1][2 * KT], uacc[0][1]);                                             \
-    uacc[1][0] = Mma<bf16>::mma(f1, hf[0][2 * KT], uacc[1][0]);                                             \
-    uacc[1][1] = Mma<bf16>::mma(f1, hf[1][2 * KT], uacc[1][1]);                                             \
-    uacc[0][0] = Mma<bf16>::mma(f2, hf[0][2 * KT + 1], uacc[0][0]);                                         \
-    uacc[0][1] = Mma<bf16>::mma(f2, hf[1][2 * KT + 1], uacc[0][1]);                                         \
-    uacc[1][0] = Mma<bf16>::mma(f3, hf[0][2 * KT + 1], uacc[1][0]);                                         \
-    uacc[1][1] = Mma<bf16>::mma(f3, hf[1][2 * KT + 1], uacc[1][1]);                                         \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[0][t] = Mma<bf16>::mma(f0, hf[t][2 * KT], uacc[0][t]);     \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[1][t] = Mma<bf16>::mma(f1, hf[t][2 * KT], uacc[1][t]);     \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[0][t] = Mma<bf16>::mma(f2, hf[t][2 * KT + 1], uacc[0][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[1][t] = Mma<bf16>::mma(f3, hf[t][2 * KT + 1], uacc[1][t]); \
     __builtin_amdgcn_sched_barrier(0);
     SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a0, a1, 8192, 10240, 8192, 10240);
     SITK_MLP_FC1_MMAS(0, x0, x1, x2, x3)
@@ -458,12 +474,12 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     SITK_STAMP(2)
 
     // ---- elementwise; lane holds hidden c*64 + 32 hh + 8 fq + 4 i + e of token 32 tg + 16 t + fr ----
-    u32x4 pf[2];                                               // B fragments of the second product
-    u32x4 sd[2];                                               // the other stored vector (u forward, g backward)
+    u32x4 pf[TT];                                              // B fragments of the second product
+    u32x4 sd[TT];                                              // the other stored vector (u forward, g backward)
     const int so = so0 + c * 128;
     if constexpr (!BWD) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < TT; ++t) {
         const f32x4 v0 = uacc[0][t], v1 = uacc[1][t];
         float xs[8], fw[8];
         uint32_t ad[8];
@@ -497,17 +513,19 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       // younger (chunk 0's were drained by the vmcnt(0) at the top of the first iteration)
       if (c > 0) {
         if (c + 1 < nchunks) {                                  // younger: this iteration's PPW DMA pieces
-          if constexpr (TG == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else if constexpr (PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       // The registers become "defined" for the compiler only HERE, in one unconditional statement behind the
       // waits: tying them to the conditional wait statements themselves made hipcc merge the two branches
       // through register copies placed in front of a wait, i.e. copies of registers whose loads were in flight.
-      asm volatile("" : "+v"(uc[0]), "+v"(uc[1]) : : "memory");
+      if constexpr (TT == 2) asm volatile("" : "+v"(uc[0]), "+v"(uc[TT - 1]) : : "memory");
+      else asm volatile("" : "+v"(uc[0]) : : "memory");
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < TT; ++t) {
         float dv[8], gv[8];
 #pragma unroll
         for (int hf4 = 0; hf4 < 2; ++hf4) {                     // 4 elements at a time (register budget)
@@ -548,14 +566,10 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     // ---- second product: yacc[dt][t] += Wb[16 dt .., chunk half] . pf[t] ----
 #define SITK_MLP_FC2_MMAS(J, f0, f1, f2, f3)                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    yacc[4 * J + 0][0] = Mma<bf16>::mma(f0, pf[0], yacc[4 * J + 0][0]);                                     \
-    yacc[4 * J + 0][1] = Mma<bf16>::mma(f0, pf[1], yacc[4 * J + 0][1]);                                     \
-    yacc[4 * J + 1][0] = Mma<bf16>::mma(f1, pf[0], yacc[4 * J + 1][0]);                                     \
-    yacc[4 * J + 1][1] = Mma<bf16>::mma(f1, pf[1], yacc[4 * J + 1][1]);                                     \
-    yacc[4 * J + 2][0] = Mma<bf16>::mma(f2, pf[0], yacc[4 * J + 2][0]);                                     \
-    yacc[4 * J + 2][1] = Mma<bf16>::mma(f2, pf[1], yacc[4 * J + 2][1]);                                     \
-    yacc[4 * J + 3][0] = Mma<bf16>::mma(f3, pf[0], yacc[4 * J + 3][0]);                                     \
-    yacc[4 * J + 3][1] = Mma<bf16>::mma(f3, pf[1], yacc[4 * J + 3][1]);                                     \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 0][t] = Mma<bf16>::mma(f0, pf[t], yacc[4 * J + 0][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 1][t] = Mma<bf16>::mma(f1, pf[t], yacc[4 * J + 1][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 2][t] = Mma<bf16>::mma(f2, pf[t], yacc[4 * J + 2][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 3][t] = Mma<bf16>::mma(f3, pf[t], yacc[4 * J + 3][t]); \
     __builtin_amdgcn_sched_barrier(0);
     SITK_MLP_WAIT_ISSUE4(y0, y1, y2, y3, x0, x1, x2, x3, a2, a2, 8192, 10240, 12288, 14336);
     SITK_MLP_FC2_MMAS(0, y0, y1, y2, y3)
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     // issues when stores queue back to back (observed on gfx950: a VALU result written three instructions
     // after the second store of a pair reached memory).  Holding the stored vectors live across the first
     // MFMA group keeps the allocator from recycling their registers while the stores may still be reading.
-    asm volatile("" : : "v"(sd[0]), "v"(sd[1]), "v"(pf[0]), "v"(pf[1]));
+    asm volatile("" : : "v"(sd[0]), "v"(sd[TT - 1]), "v"(pf[0]), "v"(pf[TT - 1]));
     SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a2, a2, 16384, 18432, 20480, 22528);
     SITK_MLP_FC2_MMAS(1, x0, x1, x2, x3)
     SITK_MLP_WAIT4(y0, y1, y2, y3);
@@ -577,22 +591,22 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   //      cross through LDS (12 tiles x 1 KB per wave, in the W buffers that nobody reads any more) ----
   __syncthreads();
   {
-    char* mine = smem + wave * 12288;
+    char* mine = smem + wave * (6144 * TT);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)   // the half this wave does NOT finish (register indices stay compile-time constants)
-        *reinterpret_cast<f32x4*>(mine + ((i * 2 + t) * 64 + lane) * 16) = hh ? yacc[i][t] : yacc[6 + i][t];
+      for (int t = 0; t < TT; ++t)   // the half this wave does NOT finish (register indices stay compile-time constants)
+        *reinterpret_cast<f32x4*>(mine + ((i * TT + t) * 64 + lane) * 16) = hh ? yacc[i][t] : yacc[6 + i][t];
   }
   __syncthreads();
-  f32x4 v[6][2];
+  f32x4 v[6][TT];
   {
-    const char* theirs = smem + (wave ^ 1) * 12288;
+    const char* theirs = smem + (wave ^ 1) * (6144 * TT);
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + ((i * 2 + t) * 64 + lane) * 16);
+      for (int t = 0; t < TT; ++t) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(theirs + ((i * TT + t) * 64 + lane) * 16);
         // yacc index must be a compile-time constant: select by hh without dynamic indexing
         v[i][t] = (hh ? yacc[6 + i][t] : yacc[i][t]) + o;
       }
@@ -602,14 +616,14 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   if constexpr (!BWD) {
     if constexpr (!NEXT) {
       // out = v + b2 + x, in row layout (fused_epilogue.h)
-      residual_rows_epilogue<TG>(smem, v, tid, blk0, p.R, PROJ ? p.xmid : p.x, p.b2, p.out);
+      residual_rows_epilogue<TG, TT>(smem, v, tid, blk0, p.R, PROJ ? p.xmid : p.x, p.b2, p.out);
     } else {
       // ---- out = v + b2 + x_mid (stored), then the NEXT block's attention input: h1 = LN(out), qkv = h1 Wqkv^T.
       //      The finished rows never leave the chip between the two blocks' kernels: rows -> fp32 row buffer
       //      [72 KB ..) -> LayerNorm -> bf16 operand strip [0, 36 KB) -> 12 register fragments per wave; Wqkv
       //      streams in 24-KB chunks through a 2-slot ring at [48 KB, 96 KB) exactly as in ln_gemm_fused.hip. ----
       constexpr int NW = 2 * TG, QPW = 24 / NW;
-      proj_residual_ln_rows<TG>(smem + 73728, smem, v, tid, blk0, p.R, p.xmid, p.b2, p.n_gamma, p.n_beta, p.out, p.n_h,
+      proj_residual_ln_rows<TG, TT>(smem + 73728, smem, v, tid, blk0, p.R, p.xmid, p.b2, p.n_gamma, p.n_beta, p.out, p.n_h,
                                 p.n_mean, p.n_rstd);
       // Lane-derived addresses of this phase are rebuilt from an opaque copy of the lane id: derived from `lane`
       // itself, hipcc computes them at kernel entry and carries them through the main loop, whose register budget
@@ -638,40 +652,41 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
                                            (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
       };
       qissue(0, 0);
-      u32x4 qf[2][6];
+      u32x4 qf[TT][6];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < TT; ++t)
 #pragma unroll
         for (int k = 0; k < 6; ++k)
           qf[t][k] = *reinterpret_cast<const u32x4*>(smem + (k >> 1) * (BLK * 128) +
-                                                     lds_off(32 * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
+                                                     lds_off(16 * TT * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
       const __amdgpu_buffer_rsrc_t r_y = make_rsrc(p.n_y + (size_t)blk0 * N3, nrows * N3 * 2);
-      const int qvo[2] = {((32 * tg + fr) * N3 + 32 * hh + 8 * fq) * 2, ((32 * tg + 16 + fr) * N3 + 32 * hh + 8 * fq) * 2};
+      int qvo[TT];
+#pragma unroll
+      for (int t = 0; t < TT; ++t) qvo[t] = ((16 * TT * tg + 16 * t + fr) * N3 + 32 * hh + 8 * fq) * 2;
       uint32_t qa[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) qa[ks] = lbase + 49152 + (32 * hh + fr) * 128 + ((ks * 64 + fq * 16) ^ (keyl << 5));
       for (int c = 0; c < nq; ++c) {
         if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // chunk c's DMA precedes the previous iteration's 2 stores
+        else if constexpr (TT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // chunk c's DMA precedes the previous iteration's TT stores
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const uint32_t qbo = (c & 1) * 24576;
         const uint32_t a0 = qa[0] + qbo, a1 = qa[1] + qbo;
         u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
         SITK_MLP_ISSUE4(x0, x1, x2, x3, a0, a1, 0, 2048, 0, 2048);
         if (c + 1 < nq) qissue(c + 1, (c + 1) & 1);
-        f32x4 qacc[2][2];
+        f32x4 qacc[2][TT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { qacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; qacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int t = 0; t < TT; ++t) qacc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define SITK_MLP_Q_MMAS(KT, f0, f1, f2, f3)                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        qacc[0][0] = Mma<bf16>::mma(f0, qf[0][2 * KT], qacc[0][0]);                                         \
-        qacc[0][1] = Mma<bf16>::mma(f0, qf[1][2 * KT], qacc[0][1]);                                         \
-        qacc[1][0] = Mma<bf16>::mma(f1, qf[0][2 * KT], qacc[1][0]);                                         \
-        qacc[1][1] = Mma<bf16>::mma(f1, qf[1][2 * KT], qacc[1][1]);                                         \
-        qacc[0][0] = Mma<bf16>::mma(f2, qf[0][2 * KT + 1], qacc[0][0]);                                     \
-        qacc[0][1] = Mma<bf16>::mma(f2, qf[1][2 * KT + 1], qacc[0][1]);                                     \
-        qacc[1][0] = Mma<bf16>::mma(f3, qf[0][2 * KT + 1], qacc[1][0]);                                     \
-        qacc[1][1] = Mma<bf16>::mma(f3, qf[1][2 * KT + 1], qacc[1][1]);                                     \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[0][t] = Mma<bf16>::mma(f0, qf[t][2 * KT], qacc[0][t]);     \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[1][t] = Mma<bf16>::mma(f1, qf[t][2 * KT], qacc[1][t]);     \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[0][t] = Mma<bf16>::mma(f2, qf[t][2 * KT + 1], qacc[0][t]); \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[1][t] = Mma<bf16>::mma(f3, qf[t][2 * KT + 1], qacc[1][t]); \
         __builtin_amdgcn_sched_barrier(0);
         SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a0, a1, 8192, 10240, 8192, 10240);
         SITK_MLP_Q_MMAS(0, x0, x1, x2, x3)
@@ -680,19 +695,19 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
         SITK_MLP_WAIT4(x0, x1, x2, x3);
         SITK_MLP_Q_MMAS(2, x0, x1, x2, x3)
 #undef SITK_MLP_Q_MMAS
-        u32x4 qsd[2];
+        u32x4 qsd[TT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < TT; ++t) {
           const f32x4 v0 = qacc[0][t], v1 = qacc[1][t];
           qsd[t] = u32x4{pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
           __builtin_amdgcn_raw_buffer_store_b128(qsd[t], r_y, qvo[t], c * 128, 0);
         }
-        asm volatile("" : : "v"(qsd[0]), "v"(qsd[1]));         // store keep-alive (see the main loop)
+        asm volatile("" : : "v"(qsd[0]), "v"(qsd[TT - 1]));         // store keep-alive (see the main loop)
       }
     }
   } else {
     // LayerNorm backward on dh = v, in row layout (fused_epilogue.h)
-    ln_bwd_rows_epilogue<TG>(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dy, p.out, p.outc,
+    ln_bwd_rows_epilogue<TG, TT>(smem, v, tid, blk0, p.R, p.x, p.mean, p.rstd, p.gamma, p.dy, p.out, p.outc,
                          p.partials + (size_t)blockIdx.x * 2 * D);
   }
   if constexpr (VAR == 6) {
@@ -701,6 +716,13 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     if (blockIdx.x == 80 && lane == 0)
       for (int i = 0; i < 8; ++i) g_mlp_stamps[wave * 8 + i] = st[i];
   }
+}
+
+// 96-row workgroups run as 12 waves of 16 tokens (3 per SIMD); SITK_MLP_TT1=0 selects the 6 x 32-token
+// variant they replaced (2,2,1,1 waves per SIMD), kept for A/B measurements
+static bool mlp_tt1() {
+  static const int v = getenv("SITK_MLP_TT1") ? atoi(getenv("SITK_MLP_TT1")) : 1;
+  return v != 0;
 }
 
 static int mlp_check(const char* what, int64_t rows, int D, int M, int dtype) {
@@ -732,7 +754,9 @@ extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b
   p.R = (int)rows; p.M = M;
   static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;   // 6: stamped build (tools/mlp_stamps.py)
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-  if (var == 6) hipLaunchKernelGGL((mlp_kernel<false, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
+  if (var == 6 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<false, 6, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
+  else if (var == 6) hipLaunchKernelGGL((mlp_kernel<false, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
+  else if (fused_block_rows(rows) == 96 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<false, 0, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<false, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL((mlp_kernel<false, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_fwd");
@@ -766,9 +790,9 @@ static int attn_out_mlp_launch(const void* o_c, const void* wo_c, const float* b
                  "%s: bad next-block arguments (N3 %d)", what, N3);
     p.n_gamma = n_ln_w; p.n_beta = n_ln_b; p.n_w = reinterpret_cast<const bf16*>(n_wqkv_c);
     p.n_h = reinterpret_cast<bf16*>(n_h); p.n_mean = n_mean; p.n_rstd = n_rstd; p.n_y = reinterpret_cast<bf16*>(n_qkv); p.N3 = N3;
-    hipLaunchKernelGGL((mlp_kernel<false, 0, 3, true, true>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+    hipLaunchKernelGGL((mlp_kernel<false, 0, 6, true, true, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   } else {
-    hipLaunchKernelGGL((mlp_kernel<false, 0, 3, true, false>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+    hipLaunchKernelGGL((mlp_kernel<false, 0, 6, true, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   }
   return check_launch(what);
 }
@@ -794,7 +818,7 @@ extern "C" int sitk_attn_out_mlp_next_fwd(const void* o_c, const void* wo_c, con
 
 // diagnostic: per-phase cycle sums of workgroup 0 written by the SITK_MLP_VAR=6 build (not part of the ABI header)
 extern "C" int sitk_mlp_debug_stamps(unsigned long long* out64) {
-  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
 }
 
 extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) {
@@ -817,7 +841,9 @@ extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, c
   p.R = (int)rows; p.M = M;
   static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-  if (var == 6) hipLaunchKernelGGL((mlp_kernel<true, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
+  if (var == 6 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<true, 6, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
+  else if (var == 6) hipLaunchKernelGGL((mlp_kernel<true, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
+  else if (fused_block_rows(rows) == 96 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<true, 0, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<true, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL((mlp_kernel<true, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_bwd");

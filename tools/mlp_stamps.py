@@ -29,16 +29,17 @@ for _ in range(5):
     else:
         ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, "bf16")
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 128)()
+buf = (C.c_ulonglong * 256)()
+NWAVES = 12 if os.environ.get("SITK_MLP_TT1", "0") != "0" else 8
 fn = rt.lib.sitk_mlp_debug_stamps
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p]
 assert fn(buf) == 0
 names = ["vmcnt wait", "barrier", "product 1", "elementwise", "product 2", "PROLOGUE", "EPILOGUE", "loop back"]
 print("cycles (loop phases summed over the 12 chunks), workgroup 80 (s_memtime ticks):")
-for w in range(8):
+for w in range(NWAVES):
     print(f"wave {w}: " + "  ".join(f"{names[i]}={buf[w * 8 + i]}" for i in (5, 7, 0, 1, 2, 3, 4, 6)) +
           f"  total={sum(buf[w * 8 + i] for i in range(8))}")
 if not bwd:
     print("forward prologue timeline (cycles since kernel start): before tables / before x loads / LN done / after barrier / fragments loaded")
-    for w in range(8):
-        print(f"wave {w}: " + "  ".join(str(buf[64 + w * 8 + i]) for i in range(5)))
+    for w in range(NWAVES):
+        print(f"wave {w}: " + "  ".join(str(buf[128 + w * 8 + i]) for i in range(5)))
