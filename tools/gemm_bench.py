@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=32 * 1281)
     ap.add_argument("--sets", type=int, default=4)
     ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--lib", action="store_true", help="reference point: the same products (no epilogue) by torch.mm = the ROCm GEMM library")
     a = ap.parse_args()
     D, H = DIMS[a.model]
     M, I, R = 4 * D, H * 64, a.tokens
@@ -48,6 +49,11 @@ def main():
          2.0 * R * D * I, R * (D + I) * 2),
         ("d to_qkv      (N=D, K=3I, store)", lambda s: ops.gemm_nt(s["qkv"], s["wqkv_t"], s["oh"], dt), 2.0 * R * 3 * I * D, R * (3 * I + D) * 2),
     ]
+    if a.lib:
+        ops_lib = [("h", "wqkv", "oq"), ("o", "wo", "oh"), ("h", "w1", "ou"), ("u", "w2", "oh"), ("h", "w2_t", "ou"), ("u", "w1_t", "oh"),
+                   ("h", "wo", "oh"), ("qkv", "wqkv_t", "oh")]
+        rows = [(name + " [torch.mm]", (lambda s, k=k: torch.mm(s[k[0]], s[k[1]].t(), out=s[k[2]])), fl, nb)
+                for (name, _, fl, nb), k in zip(rows, ops_lib)]
     tot = 0.0
     for name, fn, flops, nbytes in rows:
         for s in S:
