@@ -186,15 +186,12 @@ SITK_DEV void residual_rows_epilogue(char* smem, const f32x4 (&v)[6][TT], int ti
 // above).  Rows take the trip through LDS, then per row: x_mid = v + bias + x (stored whole), LayerNorm
 // statistics, h = LN(x_mid) into the operand strip `strip` ([k-panel][32 TG rows][128 B], swizzled with lds_off)
 // and, when asked for, to global memory.  Ends with a workgroup barrier (the strip is complete).
-// after_sync() runs right behind the first barrier, when every wave has left whatever the callers did in LDS before
-// (the block-tail kernel starts the DMA of its next phase's first weight chunk there).
-struct FeNoop { SITK_DEV void operator()() const {} };
-template <int TG, int TT = 2, typename F = FeNoop>
+template <int TG, int TT = 2>
 SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4 (&v)[6][TT], int tid, int blk0, int R,
                                     const float* __restrict__ x, const float* __restrict__ bias,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     float* __restrict__ xmid, bf16* __restrict__ h, float* __restrict__ mean,
-                                    float* __restrict__ rstd, F&& after_sync = F{}) {
+                                    float* __restrict__ rstd) {
   constexpr int D = FE_D, BLK = 16 * TT * TG;
   const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4, tg = wave >> 1, hh = wave & 1;
@@ -225,7 +222,6 @@ SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4
     for (int i = 0; i < 6; ++i)
       *reinterpret_cast<f32x4*>(rowbuf + (16 * TT * tg + 16 * t + fr) * FE_PITCH + 96 * hh + 16 * i + 4 * fq) = v[i][t];
   __syncthreads();
-  after_sync();
 #pragma unroll
   for (int pass = 0; pass < 2 * TT; ++pass) {
     const int r = wave * (8 * TT) + pass * 4 + sub, row = blk0 + r;

@@ -621,9 +621,10 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       // ---- out = v + b2 + x_mid (stored), then the NEXT block's attention input: h1 = LN(out), qkv = h1 Wqkv^T.
       //      The finished rows never leave the chip between the two blocks' kernels: rows -> fp32 row buffer
       //      [72 KB ..) -> LayerNorm -> bf16 operand strip [0, 36 KB) -> 12 register fragments per wave; Wqkv
-      //      streams in 24-KB chunks through a 4-slot ring at [48 KB, 144 KB): a chunk is 12 - 24 MFMAs per wave, so
-      //      the loop runs at the speed of its prefetch and three chunks are kept in flight. ----
-      constexpr int NW = 2 * TG, QPW = 24 / NW, QSLOTS = 4;
+      //      streams in 24-KB chunks through a 2-slot ring at [48 KB, 96 KB) exactly as in ln_gemm_fused.hip. ----
+      constexpr int NW = 2 * TG, QPW = 24 / NW;
+      proj_residual_ln_rows<TG, TT>(smem + 73728, smem, v, tid, blk0, p.R, p.xmid, p.b2, p.n_gamma, p.n_beta, p.out, p.n_h,
+                                p.n_mean, p.n_rstd);
       // Lane-derived addresses of this phase are rebuilt from an opaque copy of the lane id: derived from `lane`
       // itself, hipcc computes them at kernel entry and carries them through the main loop, whose register budget
       // (254 of 256) has no room for them.
@@ -650,12 +651,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + qoff[i]),
                                            (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
       };
-      // chunk 0 starts as soon as every wave has left the exchange area (its slot [48 KB, 72 KB) lies below the row
-      // buffer); chunks 1 and 2 follow when the row buffer is dead
-      proj_residual_ln_rows<TG, TT>(smem + 73728, smem, v, tid, blk0, p.R, p.xmid, p.b2, p.n_gamma, p.n_beta, p.out, p.n_h,
-                                    p.n_mean, p.n_rstd, [&]() { qissue(0, 0); });
-      if (1 < nq) qissue(1, 1);
-      if (2 < nq) qissue(2, 2);
+      qissue(0, 0);
       u32x4 qf[TT][6];
 #pragma unroll
       for (int t = 0; t < TT; ++t)
@@ -671,24 +667,15 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) qa[ks] = lbase + 49152 + (32 * hh + fr) * 128 + ((ks * 64 + fq * 16) ^ (keyl << 5));
       for (int c = 0; c < nq; ++c) {
-        // chunk c has landed.  Younger entries of the vmcnt queue may stay in flight: the DMA of the (up to two) chunks
-        // behind it and the stores of the (up to three) iterations that ran since its DMA was issued.
-        {
-          const int na = min(2, nq - 1 - c), nb = min(c, QSLOTS - 1);
-#define SITK_Q_WAIT(A, B) case (A) * 4 + (B): asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * QPW + (B) * TT) : "memory"); break;
-          switch (na * 4 + nb) {
-            SITK_Q_WAIT(0, 0) SITK_Q_WAIT(0, 1) SITK_Q_WAIT(0, 2) SITK_Q_WAIT(0, 3)
-            SITK_Q_WAIT(1, 0) SITK_Q_WAIT(1, 1) SITK_Q_WAIT(1, 2) SITK_Q_WAIT(1, 3)
-            SITK_Q_WAIT(2, 0) SITK_Q_WAIT(2, 1) SITK_Q_WAIT(2, 2) SITK_Q_WAIT(2, 3)
-          }
-#undef SITK_Q_WAIT
-        }
+        if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (TT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // chunk c's DMA precedes the previous iteration's TT stores
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const uint32_t qbo = (c & (QSLOTS - 1)) * 24576;
+        const uint32_t qbo = (c & 1) * 24576;
         const uint32_t a0 = qa[0] + qbo, a1 = qa[1] + qbo;
         u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
         SITK_MLP_ISSUE4(x0, x1, x2, x3, a0, a1, 0, 2048, 0, 2048);
-        if (c + QSLOTS - 1 < nq) qissue(c + QSLOTS - 1, (c + QSLOTS - 1) & (QSLOTS - 1));   // slot of chunk c - 1: every wave is past its reads
+        if (c + 1 < nq) qissue(c + 1, (c + 1) & 1);
         f32x4 qacc[2][TT];
 #pragma unroll
         for (int i = 0; i < 2; ++i)

@@ -7,8 +7,8 @@ if [ -n "$tests" ]; then
   tail -3 gpurun_out/ab_tests.log
   if [ $rc -ne 0 ]; then echo "TESTS FAILED rc=$rc"; exit $rc; fi
 fi
-for rep in 1 2; do
+for rep in ${AB_REPS:-1 2}; do
   for v in $vals; do
-    echo -n "$var=$v: "; env $var=$v timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-probe "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])" || exit 1
+    echo -n "$var=$v: "; env $var=$v timeout -k 10 200 python bench.py --steps ${AB_STEPS:-30} --warmup 5 --no-cpu-baseline --no-probe "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])" || exit 1
   done
 done
