@@ -437,9 +437,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_nt_wres_kernel(GemmParams p, 
 
 // WM = waves along the token dimension (4: 128-token tiles, 3: 96-token tiles for grids that would
 // otherwise leave a third of the CUs idle); 2 waves along the 192 features.
+#ifdef SITK_N192_STAMPS
+__device__ unsigned long long g_n192_stamps[16 * 8];      // diagnostic build: [wave][phase] cycle sums of one workgroup
+#define SITK_NST(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); nst[i] += tn - ntp; ntp = tn; }
+#else
+#define SITK_NST(i)
+#endif
 template <typename TO, int EPI, int WM, int NSTG = 4, int MINW = 1>
 __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams p) {
   using T = bf16;
+#ifdef SITK_N192_STAMPS
+  unsigned long long nst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntp = __builtin_amdgcn_s_memtime();
+  const unsigned long long nt0 = ntp;
+#endif
   constexpr int BM = WM * 32;
   constexpr int APC = BM / 8;              // 8-row DMA pieces of the A tile
   constexpr int PIECES = (APC + 24) / (2 * WM);  // per wave and stage: 5 (WM 4) / 6 (WM 3)
@@ -506,13 +516,17 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams
 #pragma unroll
   for (int i = 0; i < NSTG - 1; ++i)
     if (i < KT) issue(i, i);
+  SITK_NST(0)                                                  // prologue (addresses + first DMA issue)
   for (int kt = 0; kt < KT; ++kt) {
     const int rem = min(NSTG - 2, KT - 1 - kt);
     if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
     else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SITK_NST(1)                                                // DMA wait
     __builtin_amdgcn_s_barrier();
+    SITK_NST(2)                                                // barrier
     if (kt + NSTG - 1 < KT) issue(kt + NSTG - 1, (kt + NSTG - 1) % NSTG);
+    SITK_NST(3)                                                // DMA issue
     const uint32_t bo = (kt % NSTG) * STG;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -524,8 +538,10 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = Mma<T>::mma(fw[i], fa[j], acc[i][j]);
     }
+    SITK_NST(4)                                                // fragment reads + MFMAs
   }
   __builtin_amdgcn_s_barrier();
+  SITK_NST(5)
   // epilogue through a wave-private staging area (the k-tile stages are free now)
   char* slot = smem + wave * 6656;
 #pragma unroll
@@ -542,7 +558,19 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams
     staged_rows_store<TO, 96, EPI == SITK_EPI_BIAS_RES>(slot, v1, reinterpret_cast<TO*>(p.out), p, mrow, n0 + wn * 96, lane);
     if constexpr (EPI == SITK_EPI_BIAS_GELU) staged_rows_store<T, 96>(slot, v2, reinterpret_cast<T*>(p.out2), p, mrow, n0 + wn * 96, lane);
   }
+#ifdef SITK_N192_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  SITK_NST(6)                                                  // epilogue incl. store drain
+  nst[7] = ntp - nt0;
+  if (blockIdx.x == gridDim.x / 2 + 3 && lane == 0)
+    for (int i = 0; i < 8; ++i) g_n192_stamps[wave * 8 + i] = nst[i];
+#endif
 }
+#ifdef SITK_N192_STAMPS
+extern "C" int sitk_n192_debug_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_n192_stamps), sizeof(g_n192_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <typename TO, int EPI>
 static int launch_gemm_nt_n192(const GemmParams& p, hipStream_t s) {
