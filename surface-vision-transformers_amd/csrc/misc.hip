@@ -423,17 +423,32 @@ __global__ __launch_bounds__(256) void mpp_loss_ld_kernel(const float* __restric
                                                           T* __restrict__ dout, int lddo, int64_t rows, int K, float inv_count) {
   __shared__ float red[4];
   const int nvec = K >> 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float s = 0.f;
-  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+  // one row per wave at a time (a row is 2-3 float4 per lane: every load of the row is in flight before the first use);
+  // few workgroups, many rows each: the launch ends in ONE atomic per workgroup on the same address
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
     const bool m = masked[row] != 0;
-    for (int c = threadIdx.x; c < nvec; c += 256) {
-      f32x4 g = {0.f, 0.f, 0.f, 0.f};
-      if (m) {
-        const f32x4 d = load4(out + (size_t)row * ldo + 4 * c) - load4(tokens + (size_t)row * ldt + 4 * c);
-        s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
-        g = d * (2.f * inv_count);
+    const float* po = out + (size_t)row * ldo;
+    const float* pt = tokens + (size_t)row * ldt;
+    T* pd = dout + (size_t)row * lddo;
+    for (int c0 = 0; c0 < nvec; c0 += 256) {
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + lane + 64 * j;
+        a[j] = b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m && c < nvec) { a[j] = load4(po + 4 * c); b[j] = load4(pt + 4 * c); }
       }
-      store4(dout + (size_t)row * lddo + 4 * c, g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c0 + lane + 64 * j;
+        if (c < nvec) {
+          const f32x4 d = a[j] - b[j];                         // 0 for unmasked rows
+          s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+          store4(pd + 4 * c, d * (2.f * inv_count));
+        }
+      }
     }
   }
   s = wave_sum(s);
@@ -749,7 +764,7 @@ extern "C" int sitk_mpp_loss_fwd_bwd_ld(const float* out, int ldo, const float* 
                ldt % 4 == 0 && lddo % 4 == 0, "mpp_loss_ld: bad shape");
   const float inv = 1.0f / ((float)n_masked_total * (float)K);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int grid = grid_for(rows, 1, 4096);
+  const int grid = grid_for(rows, 4, 1024);
   if (dout_dtype == SITK_BF16)
     hipLaunchKernelGGL((mpp_loss_ld_kernel<bf16>), dim3(grid), dim3(256), 0, s, out, ldo, tokens, ldt, masked, loss,
                        reinterpret_cast<bf16*>(dout), lddo, rows, K, inv);

@@ -190,9 +190,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ in, 
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = std::min<int64_t>(rows, r0 + rows_per_block);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (c4 < cols && tr < nr)
-    for (int64_t r = r0 + tr; r < r1; r += nr) {
-      if (fa && !(fa[r] && (!fb || fb[r]))) continue;
-      s += load4(in + r * ld + c4);
+    for (int64_t r = r0 + tr; r < r1; r += 4 * nr) {          // four rows in flight per thread (flag-dependent loads)
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t rr = r + (int64_t)j * nr;
+        const bool ok = rr < r1 && (!fa || (fa[rr] && (!fb || fb[rr])));
+        v[j] = ok ? load4(in + rr * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      s += (v[0] + v[1]) + (v[2] + v[3]);
     }
   red[threadIdx.x] = s;
   __syncthreads();
