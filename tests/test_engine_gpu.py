@@ -157,6 +157,67 @@ def test_engine_bench_config_matches_autograd_path(pk):
     assert eng.fp.still_flat()
 
 
+def test_engine_config3_width_bf16_against_f32_mode(pk):
+    """BASELINE config 3 at its full width -- SiT-small, 1280 patches (N = 1281), B = 32 -- through the long-sequence ring
+    attention and the two-per-CU N % 192 GEMMs, depth 2: the bf16 engine step against the SAME engine in f32 compute
+    mode (which the goldens pin to 1e-6 at B = 1; models/sit.py:57-80, tools/train.py:280-291).  Loss and the parameter
+    update of every tensor after one step."""
+    sit, _, engine = pk
+    B, lr = 32, 0.01
+    kw = dict(sit_oracle.MODEL_SIZES["small"], num_patches=1280, num_vertices=45, num_channels=4)
+    kw["depth"] = 2
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn((B, 4, 1280, 45), device=DEV, generator=g)
+    y = torch.randn((B,), device=DEV, generator=g) * 2 + 40
+    res = {}
+    for dtype in ("f32", "bf16"):
+        m = sit.SiT(**kw, compute_dtype=dtype)
+        _load(m, 33)
+        before = {k: p.detach().clone() for k, p in m.named_parameters()}
+        eng = engine.TrainEngine(m, B, input_layout="patched", lr=lr, momentum=0.9, use_graph=False)
+        loss = float(eng.step(x, y))
+        res[dtype] = (loss, {k: p.detach().cpu() - before[k] for k, p in m.named_parameters()})
+    l32, u32 = res["f32"]
+    l16, u16 = res["bf16"]
+    check("engine/cfg3_b32_d2", "loss", "bf16", abs(l16 - l32) / abs(l32), "out")
+    worst = max((rel(u16[k], u32[k]), k) for k in u32)
+    print("worst parameter update:", worst)
+    check("engine/cfg3_b32_d2", "update_rel", "bf16", worst[0], "grad")
+
+
+def test_mpp_engine_config5_width_bf16_against_f32_mode(pk):
+    """BASELINE config 5's per-GPU share at its full width -- SiT-base MPP, 1280 patches x 45 vertices, 32 samples --
+    depth 1: the bf16 MPP engine step (device draws, fused gather + corruption, padded to_original, masked loss, weight
+    gradients in the batched launch, mask_token gradient) against the same engine in f32 compute mode on the SAME draws
+    (models/mpp.py:77-134).  Loss and every gradient."""
+    sit, mpp, engine = pk
+    B, P, V = 32, 1280, 45
+    kw = dict(sit_oracle.MODEL_SIZES["base"], depth=1, num_patches=P, num_vertices=V, num_channels=4)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn((B, 4, P, V), device=DEV, generator=g)
+    res = {}
+    for dtype in ("f32", "bf16"):
+        model = sit.SiT(**kw, compute_dtype=dtype)
+        model.allow_synthetic_table = True
+        ssl = mpp.masked_patch_pretraining(model, 768, 4 * V, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
+                                           channels=4, num_vertices=V)
+        _load(ssl, 9)
+        eng = engine.TrainEngine(ssl, B, task="mpp", input_layout="patched", lr=0.0, momentum=0.0, use_graph=False,
+                                 keep_grads=True)
+        loss = float(eng.step(x))
+        rnd = eng.last_randoms
+        res[dtype] = (loss, {k: p.grad.detach().cpu().clone() for k, p in ssl.named_parameters()}, rnd)
+    l32, g32, r32 = res["f32"]
+    l16, g16, r16 = res["bf16"]
+    for k in r32:
+        assert torch.equal(r32[k], r16[k]), k                  # same Philox stream in both modes
+    assert int(r32["corrupted_sequence"].sum()) == B * 960
+    check("engine/cfg5_mpp_b32_d1", "loss", "bf16", abs(l16 - l32) / abs(l32), "out")
+    worst = max((rel(g16[k], g32[k]), k) for k in g32 if float(g32[k].abs().max()) > 0)
+    print("worst gradient:", worst)
+    check("engine/cfg5_mpp_b32_d1", "grad_rel", "bf16", worst[0], "grad")
+
+
 @pytest.mark.parametrize("optimizer", ["sgd", "adam", "adamw"])
 def test_graph_follows_lr_schedule_and_step_count(pk, optimizer):
     """tools/pretrain.py:42-50 change the learning rate between steps and tools/train.py:228-241 use Adam / AdamW: the
