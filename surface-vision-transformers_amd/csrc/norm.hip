@@ -179,13 +179,13 @@ __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restric
 // A workgroup covers a group of 4 * CG columns (CG threads across) with 256 / CG row lanes, sums its row range, folds
 // the row lanes through LDS and issues ONE atomic per column: few workgroups per column group, because float atomics
 // of many workgroups on the same few addresses serialise (2 048 workgroups on 192 addresses took 184 us for 15.8 MB).
-template <typename TI>
-__global__ __launch_bounds__(256) void colsum_kernel(const TI* __restrict__ in, int ld, const uint8_t* __restrict__ fa,
+template <typename TI, int NT = 256>
+__global__ __launch_bounds__(NT) void colsum_kernel(const TI* __restrict__ in, int ld, const uint8_t* __restrict__ fa,
                                                      const uint8_t* __restrict__ fb, int64_t rows, int cols,
                                                      int64_t rows_per_block, float* __restrict__ out,
                                                      float* __restrict__ out2, int cols2, int cg) {
-  __shared__ f32x4 red[256];
-  const int tc = threadIdx.x % cg, tr = threadIdx.x / cg, nr = 256 / cg;
+  __shared__ f32x4 red[NT];
+  const int tc = threadIdx.x % cg, tr = threadIdx.x / cg, nr = NT / cg;
   const int c4 = (blockIdx.x * cg + tc) * 4;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = std::min<int64_t>(rows, r0 + rows_per_block);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -224,7 +224,12 @@ static int launch_colsum(const TI* in, int ld, const uint8_t* fa, const uint8_t*
   int64_t gy = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(cdiv64(rows, 256 / cg), 64), std::max(1, 512 / gx)));
   const int64_t rpb = cdiv64(rows, gy);
   gy = cdiv64(rows, rpb);
-  hipLaunchKernelGGL((colsum_kernel<TI>), dim3(gx, (unsigned)gy), dim3(256), 0, s, in, ld, fa, fb, rows, cols, rpb, out, out2, cols2, cg);
+  // narrow and tall (the encoder-width sums over all tokens: 64 workgroups for 15.8 MB): 1 024 threads per workgroup, so
+  // that the few workgroups the atomics allow still keep 64 rows each in flight
+  if (cg <= 64 && rpb >= 256)
+    hipLaunchKernelGGL((colsum_kernel<TI, 1024>), dim3(gx, (unsigned)gy), dim3(1024), 0, s, in, ld, fa, fb, rows, cols, rpb, out, out2, cols2, cg);
+  else
+    hipLaunchKernelGGL((colsum_kernel<TI>), dim3(gx, (unsigned)gy), dim3(256), 0, s, in, ld, fa, fb, rows, cols, rpb, out, out2, cols2, cg);
   return check_launch("colsum");
 }
 
