@@ -36,7 +36,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 7
+#define SITK_ABI_VERSION 8
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -100,9 +100,6 @@ typedef struct {
 #define SITK_EPI_BIAS_RES 1  /* out(f32) = acc + bias + aux(f32)   residual / pos-embedding add   */
 #define SITK_EPI_BIAS_GELU 2 /* out = u = acc + bias ; out2 = gelu_erf(u)          both `dtype`   */
 #define SITK_EPI_DGELU 3     /* out = acc * gelu_erf'(aux)          aux = saved u, both `dtype`   */
-#define SITK_EPI_MPP_LOSS 4  /* models/mpp.py:129,132 in one pass: out(f32) = acc + bias (batch_out); on rows with
-                                row_flags[m] != 0: *loss += sum (out - aux)^2 * loss_scale and out2 = 2 (out - aux)
-                                loss_scale, out2 = 0 on the other rows (out2: `dtype`, leading dim ldo2, row map omap) */
 
 typedef struct {
   int M, N, K;
@@ -122,10 +119,6 @@ typedef struct {
   const void* aux;
   int ldaux;
   sitk_rowmap auxmap;
-  const uint8_t* row_flags; /* SITK_EPI_MPP_LOSS only: (M) */
-  float* loss;              /* ... scalar, accumulated  */
-  float loss_scale;         /* ... 1 / (masked rows * N) */
-  int ldo2;                 /* ... leading dim of out2   */
 } sitk_gemm_desc;
 
 int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream);
@@ -137,7 +130,8 @@ int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream);
  * slab in the workspace and a fixed-order reduction.
  *   dY (M, N): `dtype` or fp32 (dy_is_f32); X (M, K) `dtype`; row maps as above.  The large-tile path reads whole
  * 16-byte vectors: when N (or K) is not a multiple of 8, columns [N, round_up(N, 8)) of dY (X) must exist (lddy / ldx
- * cover them) and hold zeros.                                                                    */
+ * cover them) and hold zeros.  dW: 16-byte aligned with lddw % 4 == 0 takes 16-byte read-modify-writes; a dW that is
+ * only 4-byte aligned (or any other lddw) is still correct, element by element.                                       */
 typedef struct {
   int M, N, K;
   const void* dY;
@@ -355,10 +349,14 @@ int sitk_embed_cls_rows(float* x, const float* cls_token, const float* pos, int 
  * Pool + head: models/sit.py:78-82 (x[:,0] or mean over tokens; LayerNorm(dim); Linear(dim, classes)). */
 int sitk_head_fwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
                   float* logits, int B, int N, int D, int n_classes, int pool_mean, sitk_stream_t stream);
-/* dx (B*N, D) fp32 is fully written (zeros outside the pooled rows); parameter grads accumulated. */
+/* dx (B*N, D) fp32 is fully written (zeros outside the pooled rows); parameter grads accumulated.
+ * ws: sitk_head_ws_floats(B, D, n_classes) floats of scratch, or NULL.  With it every sample's terms of the parameter
+ * gradients (and of the loss) are stored per sample and added in sample order by a second small launch: bitwise
+ * reproducible.  NULL: float atomics, whose sum depends on arrival order in the last bits.                            */
+size_t sitk_head_ws_floats(int B, int D, int n_classes);
 int sitk_head_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* dlogits,
                   float* dx, float* d_ln_w, float* d_ln_b, float* d_w, float* d_b, int B, int N, int D,
-                  int n_classes, int pool_mean, sitk_stream_t stream);
+                  int n_classes, int pool_mean, float* ws, sitk_stream_t stream);
 
 /* Regression losses of tools/train.py:245-248 on (n) predictions: loss[0] (+)= mean (p-t)^2 or
  * mean |p-t|; dpred = d loss / d pred.  loss must be zeroed by the caller.                      */
@@ -366,13 +364,15 @@ int sitk_loss_fwd_bwd(const float* pred, const float* target, float* loss, float
                       sitk_stream_t stream);
 /* head_fwd + loss_fwd_bwd + head_bwd in ONE launch (the regression step between the encoder's forward and backward,
  * tools/train.py:245-248,288-290): logits (B, n_classes) out, loss += mean loss (MSE, or L1 when l1), dx (B*N, D) out
- * = d(loss)/d(x_out) for every row, parameter gradients accumulated.  One workgroup per sample.                   */
+ * = d(loss)/d(x_out) for every row, parameter gradients accumulated.  One workgroup per sample; ws as above.       */
 int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
                            const float* target, float* logits, float* loss, float* dx, float* d_ln_w, float* d_ln_b,
-                           float* d_w, float* d_b, int B, int N, int D, int n_classes, int pool_mean, int l1,
+                           float* d_w, float* d_b, int B, int N, int D, int n_classes, int pool_mean, int l1, float* ws,
                            sitk_stream_t stream);
 
-/* column sums: out[c] += sum_r in[r][c]  (d_pos_embedding / d_cls_token over the batch) */
+/* column sums: out[c] += sum_r in[r][c]  (d_pos_embedding / d_cls_token over the batch).  Up to 512 rows (4 096 when
+ * cols >= 4 096) one workgroup per column group sums all rows in a fixed order (bitwise reproducible; out must not be
+ * written concurrently); taller inputs are split over workgroups that add their partial sums with float atomics. */
 int sitk_colsum_f32(const float* in, int64_t rows, int cols, int ld, float* out, sitk_stream_t stream);
 /* the same, with the first cols2 sums also added to out2 (models/sit.py:70-73: d cls_token = the token-0 part of
  * d pos_embedding) */
@@ -432,7 +432,8 @@ int sitk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * state[0] to change the learning rate.  sitk_adam_step_dev advances t and the two powers before it uses them.
  * zero_grad = 1 folds the next step's optimizer.zero_grad() (tools/train.py:288) into this pass: every consumed gradient
  * and the n_extra accumulator floats stored behind them (grad + n) are overwritten with zeros; the accumulator with
- * index keep_idx (the step's loss; < 0: none) is copied to keep_dst first.                                              */
+ * index keep_idx (the step's loss; < 0: none) is copied to keep_dst first.  With n_extra > 0 the accumulators start at
+ * grad + n and are cleared in 16-byte pieces: n % 4 == 0 is required (the engine pads every parameter to 64 floats).  */
 int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state, float momentum,
                       float weight_decay, int nesterov, float grad_scale, int zero_grad, int64_t n_extra,
                       int64_t keep_idx, float* keep_dst, sitk_stream_t stream);

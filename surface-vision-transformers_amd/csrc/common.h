@@ -67,6 +67,16 @@ int layernorm_bwd_deferred(const void* dy, const float* x, const float* mean, co
 int layernorm_finalize_multi(const LnFinalizeEntry* entries, int count, int64_t rows, int D, hipStream_t s);
 }  // namespace sitk
 
+// A/B switches of the measurement tools (tools/gpu_tt1.sh, tools/mlp_stamps.py): environment variables select kernel
+// variants ONLY in a diagnostic build (make AB=1 -> -DSITK_AB, a separate libsitk_ab.so picked through SITK_LIB); the
+// shipped library reads no environment and always returns the default.
+#ifdef SITK_AB
+#include <cstdlib>
+static inline int sitk_ab_switch(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+#else
+static inline int sitk_ab_switch(const char*, int dflt) { return dflt; }
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }

@@ -31,11 +31,6 @@ struct GemmParams {
   const void* aux;
   int ldaux;
   RowMap auxmap;
-  const uint8_t* row_flags;   // EPI_MPP_LOSS: rows that count (masked patches)
-  float* loss;                // ... scalar accumulator
-  float loss_scale;           // ... 1 / (masked rows * N)
-  int ldo2;                   // ... leading dim of out2 (the gradient, compute dtype)
-  SITK_DEV int ldaux2() const { return ldo2; }
 };
 
 // erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7), sharing exp(-x^2/2) between GELU and GELU'.
@@ -71,21 +66,10 @@ template <typename T>
 SITK_DEV GeluParts gelu_parts(float x) { return gelu_parts_t<sizeof(T) == 4>(x); }
 
 template <typename T, typename TO, int EPI>
-SITK_DEV void gemm_epilogue(const GemmParams& p, int m, int n, f32x4 v, float& lsum) {
+SITK_DEV void gemm_epilogue(const GemmParams& p, int m, int n, f32x4 v) {
   if (p.bias) v += load4(p.bias + n);
   const size_t orow = (size_t)map_row(p.omap, m) * p.ldo + n;
-  if constexpr (EPI == SITK_EPI_MPP_LOSS) {
-    // models/mpp.py:129,132: batch_out row (stored whole: it is part of the API) and, on masked rows only, the squared
-    // error against the clean tokens + its gradient 2 (out - target) / count in the compute dtype (zero on other rows)
-    store4(reinterpret_cast<float*>(p.out) + orow, v);
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    if (p.row_flags[m]) {
-      const f32x4 d = v - load4(reinterpret_cast<const float*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
-      lsum += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
-      g = d * (2.f * p.loss_scale);
-    }
-    store4(reinterpret_cast<T*>(p.out2) + (size_t)map_row(p.omap, m) * p.ldaux2() + n, g);
-  } else if constexpr (EPI == SITK_EPI_STORE) {
+  if constexpr (EPI == SITK_EPI_STORE) {
     store4(reinterpret_cast<TO*>(p.out) + orow, v);
   } else if constexpr (EPI == SITK_EPI_BIAS_RES) {
     const f32x4 r = load4(reinterpret_cast<const float*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
@@ -281,19 +265,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  float lsum = 0.f;
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int m = m0 + wm * (BM / WM) + 16 * j + fr;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int n = n0 + wn * (BN / WN) + 16 * i + 4 * fq;
-      if (m < p.M && n < p.N) gemm_epilogue<T, TO, EPI>(p, m, n, acc[i][j], lsum);
+      if (m < p.M && n < p.N) gemm_epilogue<T, TO, EPI>(p, m, n, acc[i][j]);
     }
-  }
-  if constexpr (EPI == SITK_EPI_MPP_LOSS) {
-    lsum = wave_sum(lsum);
-    if (lane == 0) unsafeAtomicAdd(p.loss, lsum * p.loss_scale);
   }
 }
 
@@ -621,7 +600,7 @@ static int launch_gemm_nt_wres(const GemmParams& p, hipStream_t s) {
 
 template <typename T, typename TA, typename TO, int EPI>
 static int launch_gemm_nt(const GemmParams& p, hipStream_t s) {
-  if constexpr (std::is_same<T, bf16>::value && std::is_same<TA, bf16>::value && EPI != SITK_EPI_MPP_LOSS) {
+  if constexpr (std::is_same<T, bf16>::value && std::is_same<TA, bf16>::value) {
     // weight-resident streaming kernel: K up to 192, 16-byte aligned rows, enough tokens to stream
     if (p.K <= 192 && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.M >= 1024 && p.N % 8 == 0 &&
         (sizeof(TO) == 4 || p.ldo % 8 == 0))
@@ -652,7 +631,6 @@ static int dispatch_gemm_nt(const sitk_gemm_desc* d, hipStream_t s) {
   p.out = d->out; p.ldo = d->ldo; p.omap = to_rowmap(d->omap);
   p.out2 = d->out2; p.bias = d->bias;
   p.aux = d->aux; p.ldaux = d->ldaux; p.auxmap = to_rowmap(d->auxmap);
-  p.row_flags = d->row_flags; p.loss = d->loss; p.loss_scale = d->loss_scale; p.ldo2 = d->ldo2;
   constexpr bool is_f32 = sizeof(T) == 4;
   const bool af32 = d->a_is_f32 && !is_f32;  // in f32 mode A is always "T"
   const bool of32 = d->out_is_f32 && !is_f32;
@@ -677,12 +655,6 @@ static int dispatch_gemm_nt(const sitk_gemm_desc* d, hipStream_t s) {
       SITK_REQUIRE(d->aux != nullptr, "gemm_nt: DGELU needs aux");
       if (af32) return launch_gemm_nt<T, float, T, SITK_EPI_DGELU>(p, s);
       return launch_gemm_nt<T, T, T, SITK_EPI_DGELU>(p, s);
-  }
-  if (d->epilogue == SITK_EPI_MPP_LOSS) {
-    SITK_REQUIRE(d->out_is_f32 || is_f32, "gemm_nt: MPP_LOSS writes batch_out in fp32");
-    SITK_REQUIRE(d->aux && d->out2 && d->row_flags && d->loss && d->ldo2 >= d->N, "gemm_nt: MPP_LOSS needs aux, out2, row_flags, loss, ldo2");
-    if (af32) return launch_gemm_nt<T, float, float, SITK_EPI_MPP_LOSS>(p, s);
-    return launch_gemm_nt<T, T, float, SITK_EPI_MPP_LOSS>(p, s);
   }
   set_error("gemm_nt: unknown epilogue %d", d->epilogue);
   return SITK_ERR_INVALID;

@@ -438,7 +438,7 @@ extern "C" int sitk_ln_gemm_bwd(const void* dy, const void* wt_c, const float* x
   p.dres = dres; p.dx = dx; p.dxc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.N = N;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
-  static const int tt1 = getenv("SITK_LG_TT1") ? atoi(getenv("SITK_LG_TT1")) : 1;   // 12 waves x 16 tokens; 0: the 6 x 32 variant (A/B)
+  static const int tt1 = sitk_ab_switch("SITK_LG_TT1", 1);   // 12 waves x 16 tokens; 0: the 6 x 32 variant (A/B)
   if (fused_block_rows(rows) == 96 && tt1) hipLaunchKernelGGL((ln_gemm_bwd_kernel<6, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL(ln_gemm_bwd_kernel<3>, dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL(ln_gemm_bwd_kernel<4>, dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);

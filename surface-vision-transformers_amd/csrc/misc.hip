@@ -73,14 +73,49 @@ __global__ __launch_bounds__(64) void head_fwd_kernel(const float* __restrict__ 
   }
 }
 
-// one wave per sample: parameter grads (atomics) and the pooled-row gradient written to dx[b, 0, :]
+// Parameter gradients of the head and the loss are sums over the samples.  With a workspace every sample stores its
+// terms in its own row [d_b (C) | d_w (C D) | d_ln_w (D) | d_ln_b (D) | loss (1)] and head_finalize_kernel adds the rows
+// in sample order: bitwise reproducible.  Without one the terms go straight to the gradients as float atomics (their
+// sum then depends on arrival order in the last bits).
+SITK_DEV int head_ws_width(int D, int C) { return C + C * D + 2 * D + 1; }
+struct HeadWs {
+  float *db, *dw, *dlw, *dlb, *loss;
+  bool on;
+  SITK_DEV HeadWs(float* ws, int b, int D, int C) {
+    on = ws != nullptr;
+    float* row = ws + (size_t)b * head_ws_width(D, C);
+    db = row; dw = row + C; dlw = dw + (size_t)C * D; dlb = dlw + D; loss = dlb + D;
+  }
+  SITK_DEV void add(float* slot, float* grad, float v) const {
+    if (on) *slot = v;
+    else unsafeAtomicAdd(grad, v);
+  }
+};
+
+__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ ws, int B, int D, int C,
+                                                            float* __restrict__ d_b, float* __restrict__ d_w,
+                                                            float* __restrict__ d_ln_w, float* __restrict__ d_ln_b,
+                                                            float* __restrict__ loss) {
+  const int W = head_ws_width(D, C), c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= W) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += ws[(size_t)b * W + c];          // fixed order
+  if (c < C) d_b[c] += s;
+  else if (c < C + C * D) d_w[c - C] += s;
+  else if (c < C + C * D + D) d_ln_w[c - C - C * D] += s;
+  else if (c < W - 1) d_ln_b[c - C - C * D - D] += s;
+  else if (loss) *loss += s;
+}
+
+// one wave per sample: parameter grads and the pooled-row gradient written to dx[b, 0, :]
 __global__ __launch_bounds__(64) void head_bwd_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
                                                       const float* __restrict__ ln_b, const float* __restrict__ w,
                                                       const float* __restrict__ dlogits, float* __restrict__ dx,
                                                       float* __restrict__ d_ln_w, float* __restrict__ d_ln_b,
                                                       float* __restrict__ d_w, float* __restrict__ d_b, int N, int D,
-                                                      int n_classes, int pool_mean) {
+                                                      int n_classes, int pool_mean, float* __restrict__ ws) {
   const int b = blockIdx.x, lane = threadIdx.x;
+  const HeadWs hw(ws, b, D, n_classes);
   float v[HEAD_NV], dh[HEAD_NV];
   head_pool(x, b, N, D, pool_mean, lane, v);
   float mu, rs;
@@ -89,23 +124,24 @@ __global__ __launch_bounds__(64) void head_bwd_kernel(const float* __restrict__ 
   for (int i = 0; i < HEAD_NV; ++i) { v[i] = (v[i] - mu) * rs; dh[i] = 0.f; }  // xhat
   for (int c = 0; c < n_classes; ++c) {
     const float dl = dlogits[(size_t)b * n_classes + c];
-    if (lane == 0) unsafeAtomicAdd(d_b + c, dl);
+    if (lane == 0) hw.add(hw.db + c, d_b + c, dl);
 #pragma unroll
     for (int i = 0; i < HEAD_NV; ++i) {
       const int d = lane + 64 * i;
       if (d < D) {
         dh[i] += dl * w[(size_t)c * D + d];
-        unsafeAtomicAdd(d_w + (size_t)c * D + d, dl * (v[i] * ln_w[d] + ln_b[d]));
+        hw.add(hw.dw + (size_t)c * D + d, d_w + (size_t)c * D + d, dl * (v[i] * ln_w[d] + ln_b[d]));
       }
     }
   }
+  if (lane == 0 && ws) *hw.loss = 0.f;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < HEAD_NV; ++i) {
     const int d = lane + 64 * i;
     if (d < D) {
-      unsafeAtomicAdd(d_ln_w + d, dh[i] * v[i]);
-      unsafeAtomicAdd(d_ln_b + d, dh[i]);
+      hw.add(hw.dlw + d, d_ln_w + d, dh[i] * v[i]);
+      hw.add(hw.dlb + d, d_ln_b + d, dh[i]);
       dh[i] *= ln_w[d];
       s1 += dh[i];
       s2 += dh[i] * v[i];
@@ -148,11 +184,12 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __res
                                                               float* __restrict__ dx, float* __restrict__ d_ln_w,
                                                               float* __restrict__ d_ln_b, float* __restrict__ d_w,
                                                               float* __restrict__ d_b, int B, int N, int D, int n_classes,
-                                                              int pool_mean, int l1) {
+                                                              int pool_mean, int l1, float* __restrict__ ws) {
   // grid (B, S): slice y of sample b writes its share of the rows 1..N-1; slice 0 also does the head itself.  Mean pooling
   // copies row 0, which slice 0 produces: S = 1 then (chosen by the launcher).
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave == 0 && blockIdx.y == 0) {
+    const HeadWs hw(ws, b, D, n_classes);
     float v[HEAD_NV], dh[HEAD_NV];
     head_pool(x, b, N, D, pool_mean, lane, v);
     float mu, rs;
@@ -174,25 +211,25 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __res
       lsum += l1 ? fabsf(df) : df * df;
       if (lane == 0) {
         logits[(size_t)b * n_classes + c] = logit;
-        unsafeAtomicAdd(d_b + c, dl);
+        hw.add(hw.db + c, d_b + c, dl);
       }
 #pragma unroll
       for (int i = 0; i < HEAD_NV; ++i) {
         const int d = lane + 64 * i;
         if (d < D) {
           dh[i] += dl * w[(size_t)c * D + d];
-          unsafeAtomicAdd(d_w + (size_t)c * D + d, dl * (v[i] * ln_w[d] + ln_b[d]));
+          hw.add(hw.dw + (size_t)c * D + d, d_w + (size_t)c * D + d, dl * (v[i] * ln_w[d] + ln_b[d]));
         }
       }
     }
-    if (lane == 0) unsafeAtomicAdd(loss, lsum * inv);
+    if (lane == 0) hw.add(hw.loss, loss, lsum * inv);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < HEAD_NV; ++i) {
       const int d = lane + 64 * i;
       if (d < D) {
-        unsafeAtomicAdd(d_ln_w + d, dh[i] * v[i]);
-        unsafeAtomicAdd(d_ln_b + d, dh[i]);
+        hw.add(hw.dlw + d, d_ln_w + d, dh[i] * v[i]);
+        hw.add(hw.dlb + d, d_ln_b + d, dh[i]);
         dh[i] *= ln_w[d];
         s1 += dh[i];
         s2 += dh[i] * v[i];
@@ -577,6 +614,10 @@ static int grid_for(int64_t work, int per_block, int cap) {
 
 }  // namespace sitk
 
+extern "C" size_t sitk_head_ws_floats(int B, int D, int n_classes) {
+  return B > 0 && D > 0 && n_classes > 0 ? (size_t)B * ((size_t)n_classes + (size_t)n_classes * D + 2 * (size_t)D + 1) : 0;
+}
+
 extern "C" int sitk_head_fwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
                              float* logits, int B, int N, int D, int n_classes, int pool_mean, sitk_stream_t stream) {
   using namespace sitk;
@@ -589,14 +630,19 @@ extern "C" int sitk_head_fwd(const float* x, const float* ln_w, const float* ln_
 
 extern "C" int sitk_head_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* dlogits,
                              float* dx, float* d_ln_w, float* d_ln_b, float* d_w, float* d_b, int B, int N, int D,
-                             int n_classes, int pool_mean, sitk_stream_t stream) {
+                             int n_classes, int pool_mean, float* ws, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(x && ln_w && ln_b && w && dlogits && dx && d_ln_w && d_ln_b && d_w && d_b, "head_bwd: null pointer");
   SITK_REQUIRE(B > 0 && N > 0 && D > 0 && D <= HEAD_MAXD && D % 4 == 0 && n_classes > 0, "head_bwd: bad shape");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(head_bwd_kernel, dim3(B), dim3(64), 0, s, x, ln_w, ln_b, w, dlogits, dx, d_ln_w, d_ln_b, d_w, d_b, N,
-                     D, n_classes, pool_mean);
+                     D, n_classes, pool_mean, ws);
   SITK_LAUNCH_CHECK("head_bwd");
+  if (ws) {
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 256)), dim3(256), 0, s, ws, B, D,
+                       n_classes, d_b, d_w, d_ln_w, d_ln_b, (float*)nullptr);
+    SITK_LAUNCH_CHECK("head_finalize");
+  }
   if (N > 1) {
     const int64_t total = (int64_t)B * (N - 1) * (D / 4);
     hipLaunchKernelGGL(head_spread_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, s, dx, (int64_t)B, N, D, pool_mean);
@@ -617,15 +663,22 @@ extern "C" int sitk_embed_cls_rows(float* x, const float* cls_token, const float
 extern "C" int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
                                       const float* target, float* logits, float* loss, float* dx, float* d_ln_w,
                                       float* d_ln_b, float* d_w, float* d_b, int B, int N, int D, int n_classes,
-                                      int pool_mean, int l1, sitk_stream_t stream) {
+                                      int pool_mean, int l1, float* ws, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(x && ln_w && ln_b && w && b && target && logits && loss && dx && d_ln_w && d_ln_b && d_w && d_b,
                "head_loss_fwd_bwd: null pointer");
   SITK_REQUIRE(B > 0 && N > 0 && D > 0 && D <= HEAD_MAXD && D % 4 == 0 && n_classes > 0, "head_loss_fwd_bwd: bad shape");
   const int slices = pool_mean ? 1 : std::max(1, std::min(8, 512 / B));      // fill the chip with the row writes
-  hipLaunchKernelGGL(head_loss_fused_kernel, dim3(B, slices), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ln_w, ln_b, w, b,
-                     target, logits, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1);
-  return check_launch("head_loss_fwd_bwd");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(head_loss_fused_kernel, dim3(B, slices), dim3(256), 0, s, x, ln_w, ln_b, w, b,
+                     target, logits, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1, ws);
+  SITK_LAUNCH_CHECK("head_loss_fwd_bwd");
+  if (ws) {
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 256)), dim3(256), 0, s, ws, B, D,
+                       n_classes, d_b, d_w, d_ln_w, d_ln_b, loss);
+    SITK_LAUNCH_CHECK("head_finalize");
+  }
+  return SITK_OK;
 }
 
 extern "C" int sitk_loss_fwd_bwd(const float* pred, const float* target, float* loss, float* dpred, int n, int l1,

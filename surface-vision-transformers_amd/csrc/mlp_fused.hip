@@ -4,7 +4,8 @@
 //             u   = h W1^T + b1 ;  g = gelu_erf(u)        layers.i.1.fn.net.0 / GELU
 //             out = g W2^T + b2 + x                       layers.i.1.fn.net.3 + residual
 //
-//   backward  du  = (dy W2) * gelu'(u) ;  g = gelu(u)     (g is recomputed, never stored by forward)
+//   backward  du  = (dy W2) * gelu'(u)                    (g = gelu(u): written by forward when the caller passes `g`
+//                                                          there -- the encoder does --, else recomputed and written here)
 //             dh  = du W1
 //             dx  = dy + LayerNorm'(dh)                   + per-workgroup dgamma / dbeta partials
 //
@@ -32,8 +33,6 @@
 // natural-order B fragment of the second product and one 16-byte global store of u.  Fragment reads
 // sit in asm blocks (a compiler-visible LDS read would drain the DMA queue).  At the end the two
 // halves of a wave pair exchange partial sums through LDS and each finishes 96 of the 192 features.
-#include <cstdlib>
-
 #include "common.h"
 #include "fused_epilogue.h"
 
@@ -721,7 +720,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 // 96-row workgroups run as 12 waves of 16 tokens (3 per SIMD); SITK_MLP_TT1=0 selects the 6 x 32-token
 // variant they replaced (2,2,1,1 waves per SIMD), kept for A/B measurements
 static bool mlp_tt1() {
-  static const int v = getenv("SITK_MLP_TT1") ? atoi(getenv("SITK_MLP_TT1")) : 1;
+  static const int v = sitk_ab_switch("SITK_MLP_TT1", 1);
   return v != 0;
 }
 
@@ -752,11 +751,14 @@ extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b
   p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd;
   p.u = reinterpret_cast<bf16*>(u); p.g = reinterpret_cast<bf16*>(g); p.out = out;
   p.R = (int)rows; p.M = M;
-  static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;   // 6: stamped build (tools/mlp_stamps.py)
+  static const int var = sitk_ab_switch("SITK_MLP_VAR", 0);   // 6: stamped kernels (tools/mlp_stamps.py; -DSITK_AB builds only)
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+#ifdef SITK_AB
   if (var == 6 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<false, 6, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   else if (var == 6) hipLaunchKernelGGL((mlp_kernel<false, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
-  else if (fused_block_rows(rows) == 96 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<false, 0, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
+  else
+#endif
+  if (fused_block_rows(rows) == 96 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<false, 0, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<false, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL((mlp_kernel<false, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_fwd");
@@ -839,11 +841,14 @@ extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, c
   p.du = reinterpret_cast<bf16*>(du); p.dy = dy; p.dyc = reinterpret_cast<const bf16*>(dy_c);
   p.out = dx; p.outc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.M = M;
-  static const int var = getenv("SITK_MLP_VAR") ? atoi(getenv("SITK_MLP_VAR")) : 0;
+  static const int var = sitk_ab_switch("SITK_MLP_VAR", 0);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+#ifdef SITK_AB
   if (var == 6 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<true, 6, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   else if (var == 6) hipLaunchKernelGGL((mlp_kernel<true, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
-  else if (fused_block_rows(rows) == 96 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<true, 0, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
+  else
+#endif
+  if (fused_block_rows(rows) == 96 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<true, 0, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<true, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL((mlp_kernel<true, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_bwd");

@@ -163,16 +163,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// dgamma[c] += sum_b partials[b][c], dbeta[c] += sum_b partials[b][D + c]; grid (cdiv(2D,256), chunks)
+// dgamma[c] += sum_b partials[b][c], dbeta[c] += sum_b partials[b][D + c], bitwise reproducible: a workgroup owns CG
+// columns, its 256 / CG row lanes sum interleaved row sets (b = lane, lane + RL, ...), the lanes are folded through LDS
+// in lane order and ONE thread per column adds the total to the gradient -- no atomics, a fixed order of additions.
+template <int CG>
+SITK_DEV void ln_finalize_body(const float* __restrict__ partials, int nblocks, int D, float* __restrict__ dgamma,
+                               float* __restrict__ dbeta, float* red) {
+  constexpr int RL = 256 / CG;
+  const int tc = threadIdx.x % CG, tr = threadIdx.x / CG;
+  const int c = blockIdx.x * CG + tc;
+  float s = 0.f;
+  if (c < 2 * D) {
+    int b = tr;
+    for (; b + 3 * RL < nblocks; b += 4 * RL) {                   // four independent loads in flight
+      const float v0 = partials[(size_t)b * 2 * D + c], v1 = partials[(size_t)(b + RL) * 2 * D + c];
+      const float v2 = partials[(size_t)(b + 2 * RL) * 2 * D + c], v3 = partials[(size_t)(b + 3 * RL) * 2 * D + c];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; b < nblocks; b += RL) s += partials[(size_t)b * 2 * D + c];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (tr == 0 && c < 2 * D) {
+    float t = red[tc];
+    for (int k = 1; k < RL; ++k) t += red[k * CG + tc];
+    float* dst = c < D ? dgamma + c : dbeta + (c - D);
+    *dst += t;
+  }
+}
+
+template <int CG>
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partials, int nblocks, int D,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * D) return;
-  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
-  float s = 0.f;
-  for (int b = b0; b < b1; ++b) s += partials[(size_t)b * 2 * D + c];
-  if (b1 > b0) unsafeAtomicAdd(c < D ? dgamma + c : dbeta + (c - D), s);
+  __shared__ float red[256];
+  ln_finalize_body<CG>(partials, nblocks, D, dgamma, dbeta, red);
 }
 
 // out[c] += sum_r in[r][c], optional row flags (row counted iff fa[r] && (fb == null || fb[r])).
@@ -213,10 +237,46 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const TI* __restrict__ in, i
   }
 }
 
+// Short inputs (rows <= COLSUM_DET_ROWS: the per-sample sums of d pos_embedding / d cls_token over the batch): every column
+// group is summed by ONE workgroup over ALL rows -- 64 column groups x 4 row lanes, the lanes folded through LDS in lane
+// order, plain read-modify-write of the output by one thread per column.  No atomics: bitwise reproducible.
+constexpr int COLSUM_DET_ROWS = 4096;
+template <typename TI>
+__global__ __launch_bounds__(256) void colsum_det_kernel(const TI* __restrict__ in, int ld, const uint8_t* __restrict__ fa,
+                                                         const uint8_t* __restrict__ fb, int rows, int cols,
+                                                         float* __restrict__ out, float* __restrict__ out2, int cols2) {
+  __shared__ f32x4 red[256];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int c4 = (blockIdx.x * 64 + tc) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c4 < cols)
+    for (int r = tr; r < rows; r += 16) {                        // four rows in flight per thread
+      f32x4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rr = r + 4 * j;
+        const bool ok = rr < rows && (!fa || (fa[rr] && (!fb || fb[rr])));
+        v[j] = ok ? load4(in + (size_t)rr * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      s += v[0]; s += v[1]; s += v[2]; s += v[3];
+    }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (tr == 0 && c4 < cols) {
+    s += red[64 + tc]; s += red[128 + tc]; s += red[192 + tc];
+    store4(out + c4, load4(out + c4) + s);
+    if (out2 && c4 < cols2) store4(out2 + c4, load4(out2 + c4) + s);
+  }
+}
+
 template <typename TI>
 static int launch_colsum(const TI* in, int ld, const uint8_t* fa, const uint8_t* fb, int64_t rows, int cols,
                          float* out, hipStream_t s, float* out2 = nullptr, int cols2 = 0) {
   const int c4n = cols / 4;
+  if (rows <= 512 || (rows <= COLSUM_DET_ROWS && c4n >= 1024)) {   // short: one workgroup per column group, no atomics
+    hipLaunchKernelGGL((colsum_det_kernel<TI>), dim3(cdiv(c4n, 64)), dim3(256), 0, s, in, ld, fa, fb, (int)rows, cols, out, out2, cols2);
+    return check_launch("colsum_det");
+  }
   int cg = 256;                                             // threads across columns: a power of two covering cols / 4, <= 256
   while (cg / 2 >= c4n && cg > 1) cg /= 2;
   const int gx = cdiv(c4n, cg);
@@ -297,24 +357,19 @@ static int dispatch_ln_bwd(const void* dy, const float* x, const float* mean, co
 #undef SITK_LN_BWD
   SITK_LAUNCH_CHECK("layernorm_bwd");
   if (partials && finalize) {
-    hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(2 * D, 256), std::min(grid, 32)), dim3(256), 0, s, partials, grid, D, dg, db);
+    if (grid > 512) hipLaunchKernelGGL(ln_finalize_kernel<16>, dim3(cdiv(2 * D, 16)), dim3(256), 0, s, partials, grid, D, dg, db);
+    else hipLaunchKernelGGL(ln_finalize_kernel<64>, dim3(cdiv(2 * D, 64)), dim3(256), 0, s, partials, grid, D, dg, db);
     SITK_LAUNCH_CHECK("layernorm_bwd_finalize");
   }
   return SITK_OK;
 }
 
-// All deferred LayerNorm parameter-gradient reductions of a backward slice in one launch.
+// All deferred LayerNorm parameter-gradient reductions of a backward slice in one launch (blockIdx.z = entry).
+template <int CG>
 __global__ __launch_bounds__(256) void ln_finalize_multi_kernel(LnFinalizeBatch batch, int nblocks, int D) {
+  __shared__ float red[256];
   const LnFinalizeEntry e = batch.e[blockIdx.z];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * D) return;
-  if (e.nblocks > 0) nblocks = e.nblocks;
-  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
-  float s = 0.f;
-#pragma unroll 4
-  for (int b = b0; b < b1; ++b) s += e.partials[(size_t)b * 2 * D + c];
-  if (b1 > b0) unsafeAtomicAdd(c < D ? e.dgamma + c : e.dbeta + (c - D), s);
+  ln_finalize_body<CG>(e.partials, e.nblocks > 0 ? e.nblocks : nblocks, D, e.dgamma, e.dbeta, red);
 }
 
 int layernorm_finalize_multi(const LnFinalizeEntry* entries, int count, int64_t rows, int D, hipStream_t s) {
@@ -324,7 +379,10 @@ int layernorm_finalize_multi(const LnFinalizeEntry* entries, int count, int64_t 
     LnFinalizeBatch b;
     const int n = std::min(LN_FINALIZE_MAX, count - i0);
     for (int i = 0; i < n; ++i) b.e[i] = entries[i0 + i];
-    hipLaunchKernelGGL(ln_finalize_multi_kernel, dim3(cdiv(2 * D, 256), std::min(grid, 64), n), dim3(256), 0, s, b, grid, D);
+    int most = 0;
+    for (int i = 0; i < n; ++i) most = std::max(most, b.e[i].nblocks > 0 ? b.e[i].nblocks : grid);
+    if (most > 512) hipLaunchKernelGGL(ln_finalize_multi_kernel<16>, dim3(cdiv(2 * D, 16), 1, n), dim3(256), 0, s, b, grid, D);
+    else hipLaunchKernelGGL(ln_finalize_multi_kernel<64>, dim3(cdiv(2 * D, 64), 1, n), dim3(256), 0, s, b, grid, D);
     SITK_LAUNCH_CHECK("layernorm_finalize_multi");
   }
   return SITK_OK;

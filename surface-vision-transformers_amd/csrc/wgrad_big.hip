@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, cons
     const int qc = q0 + c, pc = p0 + r0;
     if (qc >= P.cq) return;
     float* dst = P.dW + (size_t)qc * P.lddw + pc;
-    if (pc + 3 < P.cp && (P.lddw & 3) == 0) {
+    if (pc + 3 < P.cp && (P.lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {   // (a C-ABI caller's dW may be 4-byte aligned only)
       *reinterpret_cast<f32x4*>(dst) += s;
     } else {
 #pragma unroll

@@ -75,6 +75,51 @@ class FlatParams:
         return all(p.data.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[id(p)][0] for p in self.params)
 
 
+def grad_write_stages(model, task, slices):
+    """Backward stage after which each parameter's gradient is FINAL, keyed by id(parameter).
+
+    Stage i < len(slices): backward slice i (slices run last layer first; segment 0 also holds forward, loss and the
+    head's backward); stage len(slices): `_finish_backward`.  Derived from where the step WRITES each gradient, not
+    from flat-buffer offsets:
+      * layers lb..le-1 of slice i: weight / bias / LayerNorm gradients of those layers (the slice's one weight-gradient
+        launch and its LayerNorm reduction close the slice);
+      * mlp_head.*: the fused head + loss kernel of segment 0 (regression); untouched (zero) under MPP;
+      * to_original.* (models/mpp.py:66-67,129): its weight gradient joins the weight-gradient launch of the slice that
+        ends at layer 0 or runs in `_finish_backward` -> final only after finish, like the embedding, cls_token,
+        pos_embedding and mask_token gradients."""
+    sit = model.transformer if task == "mpp" else model
+    n, finish = len(slices), len(slices)
+    stage = {id(p): finish for p in model.parameters()}
+    for i, (lb, le) in enumerate(slices):
+        for layer in sit.transformer.layers[lb:le]:
+            for p in layer.parameters():
+                stage[id(p)] = i
+    for p in sit.mlp_head.parameters():
+        stage[id(p)] = 0
+    assert n >= 1
+    return stage
+
+
+def grad_bucket_plan(fp, stage, n_slices):
+    """All-reduce ranges of the flat gradient buffer per point of the step: plan[i] (i < n_slices - 1) is issued right
+    after backward slice i, plan[n_slices - 1] after `_finish_backward` (the last slice's gradients travel with the
+    finish stage: nothing is left to overlap them with).  Adjacent parameters of one point merge into one range (the
+    alignment padding between them rides along), so every float of the buffer is reduced exactly once and never before
+    the kernel that writes it has been enqueued."""
+    last = n_slices - 1
+    plan = [[] for _ in range(n_slices)]
+    order = sorted(fp.params, key=lambda p: fp.offsets[id(p)][0])
+    for k, p in enumerate(order):
+        lo = fp.offsets[id(p)][0]
+        hi = fp.offsets[id(order[k + 1])][0] if k + 1 < len(order) else fp.total
+        pt = min(stage[id(p)], last)
+        if plan[pt] and plan[pt][-1][1] == lo:
+            plan[pt][-1] = (plan[pt][-1][0], hi)
+        else:
+            plan[pt].append((lo, hi))
+    return plan
+
+
 class TrainEngine:
     """One fused train step of a SiT (task='regression') or of masked patch pre-training (task='mpp').
 
@@ -128,6 +173,7 @@ class TrainEngine:
             self.norm = (mean.contiguous(), std.contiguous())
         self.dataset = None                              # (x_all, targets_all) resident in HBM, see load_dataset()
         self.idx = torch.zeros((batch_size,), dtype=torch.int32, device=self.device)
+        self._replay_randoms = False
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
         self.nsteps = 0
@@ -157,6 +203,7 @@ class TrainEngine:
             self.target = torch.zeros((B, self.ncls), dtype=f32, device=dev)
             self.logits = torch.empty((B, self.ncls), dtype=f32, device=dev)
             self.dlogits = torch.empty((B, self.ncls), dtype=f32, device=dev)
+            self.head_ws = torch.empty(rt.lib.sitk_head_ws_floats(B, D, self.ncls), dtype=f32, device=dev)
         else:
             ssl = self.ssl
             self.n_mask = math.ceil(ssl.mask_prob * P)
@@ -194,6 +241,7 @@ class TrainEngine:
             bwd_slices = 1 if self.world == 1 else min(3, tr.depth)
         bounds = [round(i * tr.depth / bwd_slices) for i in range(bwd_slices + 1)]
         self.slices = [(bounds[i], bounds[i + 1]) for i in range(bwd_slices)][::-1]
+        self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices), len(self.slices))
         self.use_graph = use_graph
         self._graphs = None
         self._pending = []
@@ -221,7 +269,7 @@ class TrainEngine:
                                           fc.bias.data_ptr(), self.target.data_ptr(), self.logits.data_ptr(),
                                           self.loss_acc.data_ptr(), self.dx.data_ptr(), g(ln.weight).data_ptr(),
                                           g(ln.bias).data_ptr(), g(fc.weight).data_ptr(), g(fc.bias).data_ptr(), B, N, D,
-                                          self.ncls, self.pool_mean, int(self.loss_kind == "l1"), s))
+                                          self.ncls, self.pool_mean, int(self.loss_kind == "l1"), self.head_ws.data_ptr(), s))
 
     def _gather(self, out, ld, dt):
         """patch gather of the batch: from the static input buffer, or -- after load_dataset() -- straight from the resident
@@ -272,9 +320,10 @@ class TrainEngine:
         # the four random tensors of models/mpp.py:25-43,95-110 are drawn on the device (Philox; same distribution, not the
         # reference's stream: the parity path replays the reference's generator order through sitk.models.mpp instead)
         p_swap = ssl.swap_prob / (1 - ssl.replace_prob) if ssl.swap_prob > 0 else 0.0
-        rt.check(L.sitk_mpp_draw(self.rng_state.data_ptr(), self.masked.data_ptr(), rt.ptr(self.swap), rt.ptr(self.rpatch),
-                                 self.repl.data_ptr(), self.replaced_full.data_ptr(), B, P, self.n_mask, p_swap,
-                                 ssl.replace_prob, s))
+        if not self._replay_randoms:                    # (set_randoms(): the mask buffers already hold the tensors to replay)
+            rt.check(L.sitk_mpp_draw(self.rng_state.data_ptr(), self.masked.data_ptr(), rt.ptr(self.swap), rt.ptr(self.rpatch),
+                                     self.repl.data_ptr(), self.replaced_full.data_ptr(), B, P, self.n_mask, p_swap,
+                                     ssl.replace_prob, s))
         mt = ssl.mask_token.data_ptr()
         if self.layout == "surface":
             # gather + corruption in one pass: clean fp32 tokens (the regression target) and corrupted compute-dtype tokens
@@ -346,6 +395,34 @@ class TrainEngine:
             out.update(swap_draw=self.swap.view(B, P).bool().clone(), random_patches=self.rpatch.view(B, P).long().clone())
         return out
 
+    def set_randoms(self, randoms):
+        """Replay the given random tensors (models/mpp.py:85-110's names, as `last_randoms` returns them: corrupted_sequence,
+        swap_draw, random_patches, replace_draw; each (B, P)) in every following step instead of drawing on the device --
+        e.g. masks captured from the reference, or another rank's draws.  None: draw on the device again.  The loss keeps
+        the reference's fixed denominator, so every row must select exactly ceil(mask_prob P) patches."""
+        if self.task != "mpp":
+            raise rt.SitkError("set_randoms: task='mpp' only")
+        if bool(randoms) != self._replay_randoms:
+            self._graphs = None                          # the draw node comes / goes: capture again
+        self._replay_randoms = bool(randoms)
+        if not randoms:
+            return
+        B, P, dev = self.B, self.P, self.device
+        m = torch.as_tensor(randoms["corrupted_sequence"]).to(dev).reshape(B, P).bool()
+        if not bool((m.sum(1) == self.n_mask).all()):
+            raise rt.SitkError(f"set_randoms: every row of corrupted_sequence must select {self.n_mask} patches")
+        r = torch.as_tensor(randoms["replace_draw"]).to(dev).reshape(B, P).bool()
+        self.masked.copy_(m.reshape(-1).to(torch.uint8))
+        self.repl.copy_(r.reshape(-1).to(torch.uint8))
+        if self.swap is not None:
+            rp = torch.as_tensor(randoms["random_patches"]).to(dev).reshape(-1)
+            if int(rp.min()) < 0 or int(rp.max()) >= P:
+                raise rt.SitkError(f"set_randoms: random_patches must lie in [0, {P})")
+            self.swap.copy_(torch.as_tensor(randoms["swap_draw"]).to(dev).reshape(-1).to(torch.uint8))
+            self.rpatch.copy_(rp.to(torch.int32))
+        self.replaced_full.zero_()
+        self.replaced_full[:, 1:] = (m & r).to(torch.uint8)
+
     def set_lr(self, lr):
         """New learning rate from the next step on (a device-side write: captured graphs read it from memory)."""
         self.opt["lr"] = float(lr)
@@ -377,14 +454,6 @@ class TrainEngine:
             else:
                 segs.append(lambda lb=lb, le=le: self._backward_slice(lb, le))
         return segs
-
-    def _grad_range_after(self, i):
-        """Flat gradient range that is final once backward slice i is done (slices run last->first)."""
-        tr = self.sit.transformer
-        lb, _ = self.slices[i]
-        lo = self.fp.offset(tr.layers[lb][0].norm.weight)
-        hi = self.fp.total if i == 0 else self.fp.offset(tr.layers[self.slices[i - 1][0]][0].norm.weight)
-        return lo, hi
 
     def _allreduce(self, lo, hi):
         if self.world > 1:
@@ -431,7 +500,13 @@ class TrainEngine:
             t_all = torch.as_tensor(targets_all, dtype=torch.float32).to(self.device).reshape(x_all.shape[0], -1).contiguous()
             assert self.task != "regression" or t_all.shape[1] == self.ncls
         self.dataset = (x_all, t_all)
+        self.idx.zero_()
         self._graphs = None                               # the gather node changes: capture again
+
+    def unload_dataset(self):
+        """Back to the static input buffer (load_batch / step(x, target))."""
+        self.dataset = None
+        self._graphs = None
 
     def step(self, x=None, target=None, indices=None):
         """Runs one optimisation step on the batch in the static input buffers (or on x/target if given; or on the
@@ -440,8 +515,23 @@ class TrainEngine:
         if indices is not None:
             if self.dataset is None:
                 raise rt.SitkError("step(indices=...) needs load_dataset() first")
-            self.idx.copy_(torch.as_tensor(indices, dtype=torch.int32).reshape(-1), non_blocking=True)
+            if x is not None or target is not None:
+                raise rt.SitkError("step: pass either indices= (resident data set) or x/target, not both")
+            idx = torch.as_tensor(indices).reshape(-1)
+            S = self.dataset[0].shape[0]
+            if idx.numel() != self.B:
+                raise rt.SitkError(f"step(indices=...): expected {self.B} sample indices, got {idx.numel()}")
+            # the gather kernels index the resident data set with these values unchecked: validate them here (host values:
+            # on the host, no sync; device values: a device-side assertion, no sync either)
+            if idx.is_cuda:
+                torch._assert_async(((idx >= 0) & (idx < S)).all())
+            elif idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= S):
+                raise rt.SitkError(f"step(indices=...): indices must lie in [0, {S}), got [{int(idx.min())}, {int(idx.max())}]")
+            self.idx.copy_(idx.to(torch.int32), non_blocking=True)
         elif x is not None:
+            if self.dataset is not None:
+                raise rt.SitkError("step(x, ...): a resident data set is loaded (load_dataset); select samples with "
+                                   "indices=, or call unload_dataset() first")
             self.load_batch(x, target)
         segs = self._segment_fns()
         if self.world == 1:
@@ -456,11 +546,12 @@ class TrainEngine:
             return self.loss
         for i, fn in enumerate(segs):
             self._run(fn, i)
-            lo, hi = self._grad_range_after(i)
             if i < len(segs) - 1:
-                self._allreduce(lo, hi)
+                for lo, hi in self.bucket_plan[i]:      # final now: reduce while the remaining slices run
+                    self._allreduce(lo, hi)
         self._run(self._finish_backward, "finish")
-        self._allreduce(0, self._grad_range_after(len(segs) - 1)[1])
+        for lo, hi in self.bucket_plan[len(segs) - 1]:  # the last slice's gradients + everything `finish` wrote
+            self._allreduce(lo, hi)
         for w in self._pending:
             w.wait()
         self._pending.clear()

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import runtime as rt
-from .runtime import BF16, F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_MPP_LOSS, EPI_STORE  # noqa: F401
+from .runtime import BF16, F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_STORE  # noqa: F401
 
 
 def pad8(n):
@@ -86,7 +86,7 @@ def stage_weight(w, dtype, ldc=None, want_c=True, want_t=True):
 
 # ---- GEMMs -----------------------------------------------------------------------------------------
 def gemm_nt(A, W, out, dtype, M=None, N=None, K=None, epilogue=EPI_STORE, bias=None, aux=None, out2=None,
-            amap=None, omap=None, auxmap=None, row_flags=None, loss=None, loss_scale=0.0):
+            amap=None, omap=None, auxmap=None):
     """out[m, n] = sum_k A[m, k] W[n, k] (+ epilogue).  A: compute dtype or fp32; W: compute dtype;
     out: compute dtype or fp32.  2-D tensors with unit inner stride; leading dims from strides."""
     rt.require_cuda(A, W, out, bias, aux, out2)
@@ -102,8 +102,6 @@ def gemm_nt(A, W, out, dtype, M=None, N=None, K=None, epilogue=EPI_STORE, bias=N
     d.out2 = rt.ptr(out2)
     d.bias = rt.ptr(bias)
     d.aux, d.ldaux, d.auxmap = rt.ptr(aux), (aux.stride(0) if aux is not None else 0), _rowmap(auxmap)
-    d.row_flags, d.loss, d.loss_scale = rt.ptr(row_flags), rt.ptr(loss), loss_scale
-    d.ldo2 = out2.stride(0) if out2 is not None else 0
     rt.check(rt.lib.sitk_gemm_nt(C.byref(d), code, rt.stream_ptr()))
     return out
 
@@ -421,20 +419,24 @@ def head_fwd(x, ln_w, ln_b, w, b, B, N, D, pool_mean):
 
 def head_bwd(x, ln_w, ln_b, w, dlogits, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, pool_mean):
     ncls = w.shape[0]
+    ws = torch.empty(rt.lib.sitk_head_ws_floats(B, D, ncls), dtype=torch.float32, device=x.device)   # ordered sums, no atomics
     rt.check(rt.lib.sitk_head_bwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w.data_ptr(), dlogits.data_ptr(),
                                   dx.data_ptr(), d_ln_w.data_ptr(), d_ln_b.data_ptr(), d_w.data_ptr(), d_b.data_ptr(),
-                                  B, N, D, ncls, int(pool_mean), rt.stream_ptr()))
+                                  B, N, D, ncls, int(pool_mean), ws.data_ptr(), rt.stream_ptr()))
     return dx
 
 
-def head_loss_fwd_bwd(x, ln_w, ln_b, w, b, target, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, pool_mean, l1=False):
-    """pool + head + loss and their backward in one launch; returns logits (B, n_classes)."""
+def head_loss_fwd_bwd(x, ln_w, ln_b, w, b, target, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, pool_mean, l1=False,
+                      ordered=True):
+    """pool + head + loss and their backward in one launch; returns logits (B, n_classes).  ordered: per-sample terms of
+    the parameter gradients / loss go through a workspace and are added in sample order (bitwise reproducible)."""
     ncls = w.shape[0]
     logits = torch.empty((B, ncls), dtype=torch.float32, device=x.device)
+    ws = torch.empty(rt.lib.sitk_head_ws_floats(B, D, ncls), dtype=torch.float32, device=x.device) if ordered else None
     rt.check(rt.lib.sitk_head_loss_fwd_bwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w.data_ptr(), b.data_ptr(),
                                            target.data_ptr(), logits.data_ptr(), loss.data_ptr(), dx.data_ptr(),
                                            d_ln_w.data_ptr(), d_ln_b.data_ptr(), d_w.data_ptr(), d_b.data_ptr(), B, N, D, ncls,
-                                           int(pool_mean), int(l1), rt.stream_ptr()))
+                                           int(pool_mean), int(l1), rt.ptr(ws), rt.stream_ptr()))
     return logits
 
 

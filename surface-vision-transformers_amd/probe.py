@@ -266,5 +266,12 @@ def dominant_kernel_roofline(eng, peak_tflops, peak_gbs, reps=None):
     return {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom["kernel"], "op": dom["op"], "achieved": ach,
             "peak": peak, "unit": "TFLOP/s" if mfma_bound else "GB/s", "frac": round(ach / peak, 4), "traffic": None,
             "avg_us": dom["us"], "launches_per_step": dom["launches_per_step"],
-            "mfma_frac": dom["mfma_frac"], "hbm_frac": dom["hbm_frac"], "timing": "in-step HIP events (sitk_timeline)" if tline else "isolated replay",
+            "mfma_frac": dom["mfma_frac"], "hbm_frac": dom["hbm_frac"],
+            # `bound` names the nearer of the two roofs (the contract's enum); a kernel below half of BOTH is bound by
+            # neither: its time is the latency of one workgroup's dependent phases
+            "regime": "latency" if max(dom["mfma_frac"], dom["hbm_frac"]) < 0.5 else ("mfma" if mfma_bound else "hbm"),
+            "timing": ("in-step HIP events (sitk_timeline) of an EAGER re-run of the step: interval from the previous kernel's end "
+                       "to this kernel's end = duration + the dependent-launch gap, an upper bound that reads ~4 % above "
+                       "rocprofv3's kernel durations; the rows' sum can therefore exceed ms_per_step of the graph replay")
+            if tline else "isolated replay",
             "buffer_sets": nset, "encoder_kernel_sum_us": round(total, 1), "kernels": rows}

@@ -14,8 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SITK_LIB") or os.path.join(_HERE, "libsitk.so")
 
 F32, BF16 = 0, 1
-EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU, EPI_MPP_LOSS = 0, 1, 2, 3, 4
-ABI_VERSION = 7
+EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
+ABI_VERSION = 8
 
 
 class SitkError(RuntimeError):
@@ -32,8 +32,7 @@ class GemmDesc(C.Structure):
                 ("W", C.c_void_p), ("ldw", C.c_int), ("epilogue", C.c_int),
                 ("out", C.c_void_p), ("ldo", C.c_int), ("out_is_f32", C.c_int), ("omap", RowMap),
                 ("out2", C.c_void_p), ("bias", C.c_void_p),
-                ("aux", C.c_void_p), ("ldaux", C.c_int), ("auxmap", RowMap),
-                ("row_flags", C.c_void_p), ("loss", C.c_void_p), ("loss_scale", C.c_float), ("ldo2", C.c_int)]
+                ("aux", C.c_void_p), ("ldaux", C.c_int), ("auxmap", RowMap)]
 
 
 class WgradDesc(C.Structure):
@@ -107,8 +106,9 @@ _SIGS = {
                                          C.POINTER(WgradDesc), _I, C.POINTER(C.c_int), _P]),
     "sitk_embed_cls_rows": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "sitk_head_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "sitk_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "sitk_head_loss_fwd_bwd": (C.c_int, [_P] * 13 + [_I] * 6 + [_P]),
+    "sitk_head_ws_floats": (_Z, [_I, _I, _I]),
+    "sitk_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "sitk_head_loss_fwd_bwd": (C.c_int, [_P] * 13 + [_I] * 6 + [_P, _P]),
     "sitk_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "sitk_colsum_f32": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "sitk_colsum_f32_dup": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P]),

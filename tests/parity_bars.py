@@ -3,10 +3,11 @@
 f32 compute mode (v_mfma_f32_16x16x4_f32, exact fp32) is held to north_star's bar with margin: 2e-4 on
 outputs and losses, 1e-3 on every gradient.
 
-bf16 mode (the benchmarked dtype) cannot meet 1e-3 (one 2^-9 rounding per MFMA operand over up to 12
-layers); its bar per case and metric is 2 x THE ERROR MEASURED ON AN MI355X (the largest of eight recording runs: float atomics
-reorder the gradient sums, and one flipped bf16 rounding of a weight moves the multi-step engine metrics by up to 10 x
-from run to run), recorded in
+bf16 mode cannot meet 1e-3 (one 2^-9 rounding per MFMA operand over up to 12 layers); its bar per case and metric is
+2 x THE ERROR MEASURED ON AN MI355X by ONE recording run (the bench path has no float atomics any more: two runs give
+the same bits, tests/test_engine_gpu.py::test_engine_bench_config_is_bitwise_reproducible), and NEVER above the fixed
+ceiling of its metric class (BF16_CEILING below): a recording run that measures more than the ceiling FAILS instead of
+being absorbed, so re-recording cannot hide a numerical regression.  Measured values live in
 tests/golden/parity_measured_bf16.json (written by a GPU run of these tests: every `check()` call records
 its value, tests/conftest.py dumps the records to gpurun_out/parity_measured.json at the end of the
 session, and tools/update_parity_bars.py copies the bf16 entries into the committed file).  A case without
@@ -20,7 +21,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 MEASURED_PATH = os.path.join(_HERE, "golden", "parity_measured_bf16.json")
 F32_BARS = {"out": 2e-4, "loss": 2e-4, "grad": 1e-3, "param": 1e-5}
 FLOOR = 2e-4          # bars never go below this (measured errors of ~0 would make the bar meaningless)
-ENGINE_FLOOR = 5e-4   # multi-step engine metrics: heavy-tailed from run to run (median 5e-5, 2e-4 once in eight runs)
+ENGINE_FLOOR = 2e-4   # (5e-4 while float atomics reordered the multi-step engine metrics from run to run: round 2)
+# Fixed ceilings of the bf16 bars per metric (relative errors).  "ghead" compares the first 8 ELEMENTS of every gradient
+# tensor with the golden's (element-wise on values that can sit far below the tensor's RMS): loose by construction.
+BF16_CEILING = {"out": 1e-2, "out_abs": 1e-3, "out_head": 1e-2, "loss": 3e-3, "gnorm": 1e-2, "grad_rel": 1e-2,
+                "update_rel": 1e-2, "param": 5e-3, "ghead": 0.25}
 RECORDS = {}
 
 try:
@@ -36,7 +41,7 @@ def bar(case, metric, dtype, kind):
     m = _MEASURED.get(f"{case}/{metric}")
     if m is None:
         return None
-    return max(2.0 * m, ENGINE_FLOOR if case.startswith("engine/") else FLOOR)
+    return min(max(2.0 * m, ENGINE_FLOOR if case.startswith("engine/") else FLOOR), BF16_CEILING[metric])
 
 
 def check(case, metric, dtype, value, kind):
@@ -46,6 +51,9 @@ def check(case, metric, dtype, value, kind):
     b = bar(case, metric, dtype, kind)
     recording = os.environ.get("SITK_PARITY_RECORD") == "1"
     print(f"parity {dtype} {case} {metric}: measured {value:.3e} / bar {b if b is None else format(b, '.3e')}")
+    if dtype == "bf16":
+        assert value <= BF16_CEILING[metric], (f"bf16 {case} {metric}: {value:.3e} exceeds the fixed ceiling "
+                                               f"{BF16_CEILING[metric]:.1e} of its metric class (recording does not lift it)")
     if b is None:
         assert recording, (f"no measured bf16 error recorded for {case}/{metric}: run the GPU tests with "
                            f"SITK_PARITY_RECORD=1 and tools/update_parity_bars.py")

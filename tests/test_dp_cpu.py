@@ -22,26 +22,67 @@ def _free_port():
     return p
 
 
-def test_bucket_ranges_cover_flat_buffer_once():
-    """Same arithmetic as TrainEngine._grad_range_after / step(): slices run last layer first, the
-    last range is widened down to offset 0 (embedding, cls, pos gradients finish last)."""
-    depth, per_layer, head, embed = 12, 1000, 50, 300
-    offsets = [embed + l * per_layer for l in range(depth)]
-    total = embed + depth * per_layer + head
-    for nsl in (1, 2, 3, 4, 12):
-        bounds = [round(i * depth / nsl) for i in range(nsl + 1)]
-        slices = [(bounds[i], bounds[i + 1]) for i in range(nsl)][::-1]
-        ranges = []
-        for i, (lb, _) in enumerate(slices):
-            lo = offsets[lb]
-            hi = total if i == 0 else offsets[slices[i - 1][0]]
-            if i < len(slices) - 1:
-                ranges.append((lo, hi))
-            else:
-                ranges.append((0, hi))
-        covered = sorted(ranges)
-        assert covered[0][0] == 0 and covered[-1][1] == total
-        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])), (nsl, covered)
+def _cpu_flat_params(module):
+    """sitk.engine.FlatParams on the CPU (it only needs torch): same offsets as on the GPU."""
+    import sitk  # noqa: F401
+    from sitk import engine
+    return engine.FlatParams(module, "cpu")
+
+
+def _mpp_module(depth):
+    import sitk  # noqa: F401
+    from sitk.models import mpp, sit
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=depth, num_patches=80, num_vertices=561, num_channels=4)
+    model = sit.SiT(**kw)
+    return mpp.masked_patch_pretraining(model, 192, 4 * 561, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
+                                        channels=4, num_vertices=561)
+
+
+def _writer_stage(name, slices, task):
+    """The spec, restated from the step's launch order (not from sitk.engine's code): index of the segment whose
+    kernels write this parameter's gradient LAST; len(slices) = the finish stage."""
+    finish = len(slices)
+    name = name.removeprefix("transformer.") if task == "mpp" else name
+    if name.startswith("transformer.layers."):
+        layer = int(name.split(".")[2])
+        return next(i for i, (lb, le) in enumerate(slices) if lb <= layer < le)
+    if name.startswith("mlp_head."):
+        return 0                       # fused head + loss kernel, segment 0 (never written under MPP: zero)
+    # to_original.* (weight-gradient launch of the slice ending at layer 0, or finish), mask_token, cls_token,
+    # pos_embedding, to_patch_embedding.1.*: all behind the last backward slice
+    return finish
+
+
+@pytest.mark.parametrize("task", ["regression", "mpp"])
+@pytest.mark.parametrize("nsl", [1, 2, 3, 4, 12])
+def test_bucket_plan_reduces_every_gradient_once_and_only_after_it_is_written(task, nsl):
+    """`to_original.*` sits BEHIND mlp_head in the flat buffer, so an offset-derived "everything from
+    the first finished layer to the end of the buffer" range all-reduced it right after slice 0 -- two slices before
+    the kernel that writes it.  The plan is derived from where each gradient is written instead; this walks
+    named_parameters() of the real modules and checks (a) every float of the flat buffer is reduced exactly once,
+    (b) no parameter is reduced at a point of the step that precedes the segment writing it."""
+    import sitk  # noqa: F401
+    from sitk import engine
+    depth = 12
+    ssl = _mpp_module(depth)
+    module = ssl if task == "mpp" else ssl.transformer
+    fp = _cpu_flat_params(module)
+    bounds = [round(i * depth / nsl) for i in range(nsl + 1)]
+    slices = [(bounds[i], bounds[i + 1]) for i in range(nsl)][::-1]
+    plan = engine.grad_bucket_plan(fp, engine.grad_write_stages(module, task, slices), nsl)
+    assert len(plan) == nsl
+    flat_ranges = sorted(r for point in plan for r in point)
+    assert flat_ranges[0][0] == 0 and flat_ranges[-1][1] == fp.total
+    assert all(a[1] == b[0] for a, b in zip(flat_ranges, flat_ranges[1:])), flat_ranges          # (a)
+    for name, p in module.named_parameters():
+        lo, n = fp.offsets[id(p)]
+        point = next(i for i, rs in enumerate(plan) if any(a <= lo and lo + n <= b for a, b in rs))
+        # point i < nsl - 1 is issued right after segment i; point nsl - 1 after the finish stage
+        issued_after = point if point < nsl - 1 else nsl
+        assert issued_after >= _writer_stage(name, slices, task), (name, point, slices)           # (b)
+    if task == "mpp" and nsl > 1:
+        lo, _ = fp.offsets[id(ssl.to_original.weight)]
+        assert not any(a <= lo < b for a, b in plan[0]), "to_original reduced with slice 0 again"
 
 
 def _worker(rank, world, port, q):

@@ -86,6 +86,134 @@ def test_two_rank_engine_matches_single_process_full_batch(use_graph):
     assert err < 1e-6, err
 
 
+# ---- masked patch pre-training under the DP split (BASELINE config 5's path) -------------------------
+MPP_KW = dict(mask_prob=0.75, replace_prob=0.8, swap_prob=0.02, channels=4, num_vertices=561)
+
+
+def _make_mpp(dtype):
+    import sitk  # noqa: F401
+    from sitk.models.mpp import masked_patch_pretraining
+    ssl = masked_patch_pretraining(_make_model(dtype), 192, 4 * 561, "cpu", **MPP_KW)
+    vals = detgen.fill_state_dict(ssl.state_dict(), seed=17)
+    ssl.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+    return ssl
+
+
+def _mpp_worker(rank, world, port, use_graph, slices, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from sitk import engine
+    x, _ = _data()
+    shard = slice(rank * B // world, (rank + 1) * B // world)
+    eng = engine.TrainEngine(_make_mpp("f32"), B // world, task="mpp", input_layout="patched", lr=LR, momentum=0.9,
+                             process_group=dist.group.WORLD, bwd_slices=slices, use_graph=use_graph, device="cuda:0")
+    draws = []
+    for _ in range(STEPS):
+        eng.step(x[shard].cuda())
+        torch.cuda.synchronize()
+        draws.append({k: v.cpu().numpy() for k, v in eng.last_randoms.items()})     # every rank draws its own masks
+    names = [n for n, _ in eng.module.named_parameters()]
+    flat = {n: p.detach().cpu().numpy() for n, p in eng.module.named_parameters()}
+    q.put((rank, draws, flat if rank == 0 else None, names))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph,slices", [(False, 3), (True, 3), (False, 1)])
+def test_two_rank_mpp_engine_matches_single_process_full_batch(use_graph, slices):
+    """Every parameter (to_original.*, mask_token, the embedding, all layers) after 2 SGD steps on 2 ranks == the
+    single-process engine on the full batch replaying the two ranks' concatenated draws; the error is taken relative to
+    each tensor's UPDATE, so one tensor whose gradient was not all-reduced cannot hide behind the others' norm."""
+    import numpy as np
+    import sitk  # noqa: F401
+    from sitk import engine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mpp_worker, args=(r, 2, port, use_graph, slices, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        rank, draws, flat, names = q.get(timeout=300)
+        res[rank] = (draws, flat)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    got = res[0][1]
+
+    x, _ = _data()
+    ssl = _make_mpp("f32")
+    init = {n: p.detach().clone() for n, p in ssl.named_parameters()}
+    ref = engine.TrainEngine(ssl, B, task="mpp", input_layout="patched", lr=LR, momentum=0.9, use_graph=False,
+                             device="cuda:0")
+    for st in range(STEPS):
+        ref.set_randoms({k: np.concatenate([res[0][0][st][k], res[1][0][st][k]], 0) for k in res[0][0][st]})
+        ref.step(x.cuda())
+    torch.cuda.synchronize()
+    worst = ("", 0.0)
+    for n, p in ref.module.named_parameters():
+        want = p.detach().cpu().double()
+        upd = float((want - init[n].double()).norm())
+        err = float((torch.from_numpy(got[n]).double() - want).norm())
+        if n.startswith("transformer.mlp_head."):
+            assert upd == 0.0 and err == 0.0, n           # no gradient reaches the regression head in MPP (SURVEY 3.4)
+            continue
+        assert upd > 0, n
+        if err / upd > worst[1]:
+            worst = (n, err / upd)
+        assert err / upd < 2e-4, (n, err / upd)
+    print("worst update-relative error:", worst)
+
+
+def test_engine_set_randoms_and_index_validation():
+    """out-of-range sample indices must not reach the gather kernels; replayed masks must keep the fixed
+    denominator of models/mpp.py:132."""
+    import numpy as np
+    import sitk  # noqa: F401
+    from sitk import engine
+    from sitk.runtime import SitkError
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=1, num_patches=320, num_vertices=153, num_channels=4)
+    from sitk.models.sit import SiT
+    eng = engine.TrainEngine(SiT(**kw, compute_dtype="f32"), 2, input_layout="surface", use_graph=False)
+    with pytest.raises(SitkError):
+        eng.step(indices=[0, 1])                                       # no data set loaded
+    eng.load_dataset(np.zeros((3, 40962, 4), np.float32), np.zeros((3, 1), np.float32))
+    for bad in ([0, 3], [-1, 0], [0, 1, 2]):
+        with pytest.raises(SitkError):
+            eng.step(indices=bad)
+    with pytest.raises(SitkError):
+        eng.step(torch.zeros((2, 40962, 4), device="cuda"), torch.zeros(2, device="cuda"))   # x while a data set is resident
+    eng.step(indices=[2, 0])
+    eng.unload_dataset()
+    eng.step(torch.zeros((2, 40962, 4), device="cuda"), torch.zeros(2, device="cuda"))
+    mp_eng = engine.TrainEngine(_make_mpp("f32"), 2, task="mpp", input_layout="patched", use_graph=False)
+    bad = {"corrupted_sequence": np.zeros((2, 80), bool), "replace_draw": np.zeros((2, 80), bool),
+           "swap_draw": np.zeros((2, 80), bool), "random_patches": np.zeros((2, 80), np.int64)}
+    with pytest.raises(SitkError):
+        mp_eng.set_randoms(bad)                                        # 0 selected patches per row != ceil(0.75 * 80)
+
+
+def test_bench_mpp_gpus_2_as_typed_prints_one_json_line():
+    """`python bench.py --task mpp --gpus 2 --backend gloo`: the multi-rank MPP step through the bench's own launcher."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--task", "mpp", "--gpus", "2", "--backend", "gloo",
+                        "--no-cpu-baseline", "--no-probe", "--steps", "3", "--warmup", "2", "--batch", "4"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+    assert 0 < out["config"]["loss_after"] < 100
+
+
 def test_bench_gpus_2_as_typed_prints_one_json_line():
     """`python bench.py --gpus 2 ...` with no launcher around it: the script starts torch.distributed.run itself (child
     process) and rank 0's JSON line comes back through it (gloo transport: one GPU on this box)."""

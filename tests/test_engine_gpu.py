@@ -157,6 +157,96 @@ def test_engine_bench_config_matches_autograd_path(pk):
     assert eng.fp.still_flat()
 
 
+def test_engine_bench_config_is_bitwise_reproducible(pk):
+    """no float atomics on the bench path any more (the head's parameter gradients and the loss go
+    through per-sample partial rows, d pos_embedding / d cls_token and the LayerNorm gradients through ordered sums, the
+    weight gradients of the one-launch 12-layer slice write each tile once).  Two engines from the same weights, the
+    bench configuration (tiny, depth 12, B = 64, bf16, raw surfaces, hipGraph), three steps: every float of the flat
+    parameter buffer and every loss must be BIT-equal."""
+    sit, _, engine = pk
+    B = 64
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], num_patches=320, num_vertices=153, num_channels=4)
+    base = sit.SiT(**kw, compute_dtype="bf16")
+    _load(base, 21)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((B, 40962, 4), device=DEV, generator=g)
+    y = torch.randn((B,), device=DEV, generator=g) * 2 + 40
+    runs = []
+    for _ in range(2):
+        eng = engine.TrainEngine(copy.deepcopy(base), B, input_layout="surface", lr=0.01, momentum=0.9, use_graph=True)
+        losses = [eng.step(x, y).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        runs.append((eng.fp.flat.clone(), torch.cat(losses)))
+    assert torch.equal(runs[0][1], runs[1][1]), (runs[0][1], runs[1][1])
+    diff = int((runs[0][0] != runs[1][0]).sum())
+    assert diff == 0, f"{diff} of {runs[0][0].numel()} parameters differ between two identical runs"
+
+
+def _oracle_grads_cpu(model_cpu, fwd):
+    torch.set_num_threads(max(1, min(16, (torch.get_num_threads() or 1))))
+    model_cpu.zero_grad()
+    loss = fwd(model_cpu)
+    loss.backward()
+    return float(loss), {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model_cpu.named_parameters()}
+
+
+def test_engine_config3_full_width_f32_against_oracle(pk):
+    """VERDICT r2 weak #4 / ADVICE: BASELINE config 3 at its FULL width -- SiT-small, 1280 patches (N = 1281), B = 32 --
+    depth 1, f32 compute mode, against the CPU oracle on the same batch (the goldens pin these kernels at B <= 2 only; the
+    bf16-vs-f32-mode test below is a self-comparison).  Loss <= 2e-4, every gradient <= 1e-3 (north_star's bar)."""
+    sit, _, engine = pk
+    B = 32
+    kw = dict(sit_oracle.MODEL_SIZES["small"], num_patches=1280, num_vertices=45, num_channels=4)
+    kw["depth"] = 1
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((B, 4, 1280, 45), generator=g)
+    y = torch.randn((B,), generator=g) * 2 + 40
+    m = sit.SiT(**kw, compute_dtype="f32")
+    _load(m, 33)
+    ref = sit_oracle.SiT(**kw)
+    ref.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    l_ref, g_ref = _oracle_grads_cpu(ref, lambda mod: torch.nn.functional.mse_loss(mod(x).squeeze(-1), y))
+    eng = engine.TrainEngine(m, B, input_layout="patched", lr=0.0, momentum=0.0, use_graph=False, keep_grads=True)
+    loss = float(eng.step(x.to(DEV), y.to(DEV)))
+    check("engine/cfg3_b32_d1_oracle", "loss", "f32", abs(loss - l_ref) / abs(l_ref), "loss")
+    worst = max((rel(p.grad, g_ref[k]), k) for k, p in m.named_parameters())
+    print("worst gradient:", worst)
+    check("engine/cfg3_b32_d1_oracle", "grad_rel", "f32", worst[0], "grad")
+
+
+def test_mpp_engine_config5_full_width_f32_against_oracle(pk):
+    """BASELINE config 5's per-GPU share at FULL width -- SiT-base MPP, 1280 patches x 45 vertices, 32 samples -- depth 1,
+    f32 compute mode: the engine's own device draws replayed through the CPU oracle (models/mpp.py:77-134 restated in
+    oracle/sit_oracle.py).  Loss <= 2e-4, every gradient <= 1e-3."""
+    sit, mpp, engine = pk
+    B, P, V = 32, 1280, 45
+    kw = dict(sit_oracle.MODEL_SIZES["base"], depth=1, num_patches=P, num_vertices=V, num_channels=4)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((B, 4, P, V), generator=g)
+    model = sit.SiT(**kw, compute_dtype="f32")
+    model.allow_synthetic_table = True
+    ssl = mpp.masked_patch_pretraining(model, 768, 4 * V, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
+                                       channels=4, num_vertices=V)
+    _load(ssl, 9)
+    ref = sit_oracle.MaskedPatchPretraining(sit_oracle.SiT(**kw), 768, 4 * V, "cpu", mask_prob=0.75, replace_prob=0.8,
+                                            swap_prob=0.02, channels=4, num_vertices=V)
+    ref.load_state_dict({k: v.detach().clone() for k, v in ssl.state_dict().items()})
+    eng = engine.TrainEngine(ssl, B, task="mpp", input_layout="patched", lr=0.0, momentum=0.0, use_graph=False,
+                             keep_grads=True)
+    loss = float(eng.step(x.to(DEV)))
+    rnd = {k: v.cpu() for k, v in eng.last_randoms.items()}
+    l_ref, g_ref = _oracle_grads_cpu(ref, lambda mod: mod(x, randoms=rnd)[0])
+    check("engine/cfg5_mpp_b32_d1_oracle", "loss", "f32", abs(loss - l_ref) / abs(l_ref), "loss")
+    worst = (0.0, "")
+    for k, p in ssl.named_parameters():
+        if g_ref[k] is None:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        worst = max(worst, (rel(p.grad, g_ref[k]), k))
+    print("worst gradient:", worst)
+    check("engine/cfg5_mpp_b32_d1_oracle", "grad_rel", "f32", worst[0], "grad")
+
+
 def test_engine_config3_width_bf16_against_f32_mode(pk):
     """BASELINE config 3 at its full width -- SiT-small, 1280 patches (N = 1281), B = 32 -- through the long-sequence ring
     attention and the two-per-CU N % 192 GEMMs, depth 2: the bf16 engine step against the SAME engine in f32 compute
@@ -252,7 +342,7 @@ def test_graph_follows_lr_schedule_and_step_count(pk, optimizer):
         flats[use_graph] = eng.fp.flat.clone()
         worst = max((rel(p.data, q.data), k) for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()))
         assert worst[0] < 2e-5, worst
-    assert rel(flats[True], flats[False]) < 1e-6      # (not bit-equal: float atomics in the column sums / loss)
+    assert torch.equal(flats[True], flats[False])     # ordered reductions everywhere on this path: replay == eager, bit for bit
 
 
 def test_resident_dataset_pipeline(pk):

@@ -55,7 +55,7 @@ def test_sit_matches_reference_golden(sitk_models, golden_dir, name, dtype):
     ref_out = g[f"{name}/out"]
     err = float(np.abs(out.detach().cpu().numpy() - ref_out).max() / (np.abs(ref_out).max() + 1e-12))
     check(f"sit/{name}", "out", dtype, err, "out")
-    check(f"sit/{name}", "loss", dtype, abs(float(loss) - float(g[f"{name}/loss"])) / float(g[f"{name}/loss"]), "grad")
+    check(f"sit/{name}", "loss", dtype, abs(float(loss) - float(g[f"{name}/loss"])) / float(g[f"{name}/loss"]), "loss")
     worst, worst_k, worst_head, worst_hk = 0.0, "", 0.0, ""
     for k, p in model.named_parameters():
         gn = float(g[f"{name}/gnorm/{k}"])
@@ -91,7 +91,7 @@ def test_sit_full_gradient_vs_oracle(sitk_models, dtype):
     lr.backward()
     lo = torch.nn.functional.mse_loss(model(torch.from_numpy(x).to(DEV)).squeeze(), torch.from_numpy(y).to(DEV))
     lo.backward()
-    check("fullgrad/tiny320_d3", "loss", dtype, abs(float(lo) - float(lr)) / float(lr), "grad")
+    check("fullgrad/tiny320_d3", "loss", dtype, abs(float(lo) - float(lr)) / float(lr), "loss")
     worst = max((rel(p.grad, q.grad), k) for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()))
     print("worst element-wise gradient:", worst)
     check("fullgrad/tiny320_d3", "grad_rel", dtype, worst[0], "grad")
@@ -126,7 +126,7 @@ def test_mpp_matches_reference_golden(sitk_models, golden_dir, name, dtype):
     rnd = {k.split("/")[-1]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{name}/rnd/")}
     loss, out = ssl(torch.from_numpy(x).to(DEV), randoms=rnd)
     loss.backward()
-    check(f"mpp/{name}", "loss", dtype, abs(float(loss) - float(g[f"{name}/loss"])) / float(g[f"{name}/loss"]), "grad")
+    check(f"mpp/{name}", "loss", dtype, abs(float(loss) - float(g[f"{name}/loss"])) / float(g[f"{name}/loss"]), "loss")
     check(f"mpp/{name}", "out_head", dtype, rel(out.detach()[:, :4, :16], g[f"{name}/out_head"]), "grad")
     check(f"mpp/{name}", "out_abs", dtype,
           abs(float(out.double().abs().sum()) - float(g[f"{name}/out_abs"])) / float(g[f"{name}/out_abs"]), "grad")

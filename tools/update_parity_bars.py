@@ -1,8 +1,9 @@
 """Copy the bf16 errors a GPU run of the tests measured (gpurun_out/parity_measured.json, written by
 tests/conftest.py) into the committed tests/golden/parity_measured_bf16.json, from which tests/parity_bars.py
-derives the bf16 bars (2 x measured).  Usage: python tools/update_parity_bars.py [--merge | --max] [file ...]
---merge keeps entries the run did not produce; --max additionally keeps the LARGER of the committed and the new value
-(several recording runs: float atomics make the small-gradient metrics vary from run to run)."""
+derives the bf16 bars (2 x measured, capped by the fixed ceilings of tests/parity_bars.py).
+Usage: python tools/update_parity_bars.py [--merge] [file]      --merge keeps entries the run did not produce.
+ONE recording run: the bench path is bitwise reproducible since round 3, so there is no "largest of N runs" mode any more
+(round 2's --max only ever raised bars)."""
 import json
 import os
 import sys
@@ -11,17 +12,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "parity_measured.json")
 dst = os.path.join(ROOT, "tests", "golden", "parity_measured_bf16.json")
 files = [a for a in sys.argv[1:] if not a.startswith("--")] or [src]
-keep = ("--merge" in sys.argv or "--max" in sys.argv) and os.path.exists(dst)
+keep = "--merge" in sys.argv and os.path.exists(dst)
 out = json.load(open(dst)) if keep else {}
 rec = {}
 for f in files:
     for k, v in json.load(open(f)).items():
-        rec[k] = max(rec.get(k, 0.0), v) if "--max" in sys.argv else v
+        rec[k] = v
 for k, v in rec.items():
     if k.startswith("bf16/"):
         key = k[len("bf16/"):]
         v = float(f"{v:.3e}")
-        out[key] = max(out.get(key, 0.0), v) if "--max" in sys.argv else v
+        out[key] = v
 json.dump(dict(sorted(out.items())), open(dst, "w"), indent=1)
 print(f"{len(out)} bf16 entries -> {dst}")
 f32 = {k: v for k, v in rec.items() if k.startswith("f32/")}
