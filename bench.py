@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--patches", type=int, default=320, choices=[80, 320, 1280])
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--task", default="regression", choices=["regression", "mpp"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
@@ -208,8 +208,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"SiT-{args.model} {P} patches{' (synthetic table)' if P == 1280 else ''} x {V} vertices x 4 channels, B={B}/GPU, {args.task}: "
                                f"gather(B,40962,4) + fwd + {'masked MSE' if args.task == 'mpp' else 'MSE'} + bwd + "
-                               f"SGD(m=0.9), bf16 MFMA / fp32 accumulate" if args.dtype == "bf16" else
-                               f"SiT-{args.model} {P}x{V}x4 B={B}/GPU {args.task} f32 MFMA",
+                               f"SGD(m=0.9), " + {"bf16": "bf16 MFMA / fp32 accumulate", "f16": "f16 MFMA / fp32 accumulate, loss-scaled backward",
+                                                  "f32": "f32 MFMA (verification mode)"}[args.dtype],
                    "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                    "loss_after": round(loss, 6)},
         "step_gflop_per_sample": round(gf, 3),

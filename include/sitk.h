@@ -14,7 +14,10 @@
  *   - return 0 on success, <0 on error; sitk_last_error() returns a thread-local message.
  *   - `dtype` selects the COMPUTE/STORAGE type of activations and weight copies:
  *       SITK_BF16  bf16 operands, v_mfma_f32_16x16x32_bf16, fp32 accumulate   (benchmark mode)
- *       SITK_F32   f32 operands,  v_mfma_f32_16x16x4_f32 (exact fp32)          (parity mode)
+ *       SITK_F16   IEEE half operands, v_mfma_f32_16x16x32_f16, fp32 accumulate: the same rate and bytes as bf16 with 3
+ *                  more mantissa bits (meets the 1e-3 parity bar); 5 exponent bits: callers run backward on a
+ *                  loss-scaled gradient stream (the *_scale arguments below)
+ *       SITK_F32   f32 operands,  v_mfma_f32_16x16x4_f32 (exact fp32)          (verification mode)
  *     LayerNorm statistics, softmax, GELU, the residual stream, every gradient of a parameter
  *     and the optimizer state are fp32 in both modes.
  *   - all pointers 16-byte aligned; feature counts (dim, mlp_dim, heads*64, patch_dim) and leading
@@ -31,6 +34,7 @@ extern "C" {
 
 #define SITK_F32 0
 #define SITK_BF16 1
+#define SITK_F16 2
 
 #define SITK_OK 0
 #define SITK_ERR_INVALID (-1)
@@ -364,11 +368,15 @@ int sitk_loss_fwd_bwd(const float* pred, const float* target, float* loss, float
                       sitk_stream_t stream);
 /* head_fwd + loss_fwd_bwd + head_bwd in ONE launch (the regression step between the encoder's forward and backward,
  * tools/train.py:245-248,288-290): logits (B, n_classes) out, loss += mean loss (MSE, or L1 when l1), dx (B*N, D) out
- * = d(loss)/d(x_out) for every row, parameter gradients accumulated.  One workgroup per sample; ws as above.       */
+ * = d(loss)/d(x_out) for every row, parameter gradients accumulated.  One workgroup per sample; ws as above.
+ * grad_scale (2 floats in device memory, or NULL; needs ws): LOSS SCALING for the f16 compute mode.  The call then runs
+ * as two launches: forward + loss + every sample's raw d loss / d logits, then backward with every gradient (dx and the
+ * head's parameter gradients) multiplied by S = 2^k, k chosen from THIS batch so that max |d loss / d logits| * S lies in
+ * [64, 128); grad_scale[0] = S, grad_scale[1] = 1 / S are written for sitk_*_step_dev.  loss and logits are never scaled. */
 int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
                            const float* target, float* logits, float* loss, float* dx, float* d_ln_w, float* d_ln_b,
                            float* d_w, float* d_b, int B, int N, int D, int n_classes, int pool_mean, int l1, float* ws,
-                           sitk_stream_t stream);
+                           float* grad_scale, sitk_stream_t stream);
 
 /* column sums: out[c] += sum_r in[r][c]  (d_pos_embedding / d_cls_token over the batch).  Up to 512 rows (4 096 when
  * cols >= 4 096) one workgroup per column group sums all rows in a fixed order (bitwise reproducible; out must not be
@@ -409,10 +417,11 @@ int sitk_mpp_gather_corrupt(const float* x, const uint16_t* table_pv, const int3
 /* loss[0] += sum_{masked rows} (out - tokens)^2 / (n_masked_total * K); dout likewise (0 elsewhere). */
 int sitk_mpp_loss_fwd_bwd(const float* out, const float* tokens, const uint8_t* masked, float* loss,
                           float* dout, int64_t rows, int K, int64_t n_masked_total, sitk_stream_t stream);
-/* the same over row-padded buffers (leading dimensions ldo / ldt / lddo) with the gradient in `dout_dtype` (engine path) */
+/* the same over row-padded buffers (leading dimensions ldo / ldt / lddo) with the gradient in `dout_dtype` (engine path),
+ * multiplied by grad_scale (loss scaling of the f16 mode: the masked mean divides by rows * K ~ 1e7; 1 otherwise)      */
 int sitk_mpp_loss_fwd_bwd_ld(const float* out, int ldo, const float* tokens, int ldt, const uint8_t* masked, float* loss,
                              void* dout, int lddo, int dout_dtype, int64_t rows, int K, int64_t n_masked_total,
-                             sitk_stream_t stream);
+                             float grad_scale, sitk_stream_t stream);
 /* out[c] += sum over rows with flag[r] != 0 of in[r][c]   (mask_token gradient, stage 1) */
 int sitk_masked_colsum(const void* in, int ld, int in_is_f32, int dtype, const uint8_t* flag_a,
                        const uint8_t* flag_b, int64_t rows, int cols, float* out, sitk_stream_t stream);
@@ -433,13 +442,16 @@ int sitk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * zero_grad = 1 folds the next step's optimizer.zero_grad() (tools/train.py:288) into this pass: every consumed gradient
  * and the n_extra accumulator floats stored behind them (grad + n) are overwritten with zeros; the accumulator with
  * index keep_idx (the step's loss; < 0: none) is copied to keep_dst first.  With n_extra > 0 the accumulators start at
- * grad + n and are cleared in 16-byte pieces: n % 4 == 0 is required (the engine pads every parameter to 64 floats).  */
+ * grad + n and are cleared in 16-byte pieces: n % 4 == 0 is required (the engine pads every parameter to 64 floats).
+ * inv_loss_scale (device pointer or NULL): the gradients are additionally multiplied by *inv_loss_scale, the 1 / S that
+ * sitk_head_loss_fwd_bwd left behind (f16 mode), read on the device so that a captured graph follows it.              */
 int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state, float momentum,
                       float weight_decay, int nesterov, float grad_scale, int zero_grad, int64_t n_extra,
-                      int64_t keep_idx, float* keep_dst, sitk_stream_t stream);
+                      int64_t keep_idx, float* keep_dst, const float* inv_loss_scale, sitk_stream_t stream);
 int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double* state,
                        float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, float grad_scale,
-                       int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst, sitk_stream_t stream);
+                       int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst, const float* inv_loss_scale,
+                       sitk_stream_t stream);
 
 #ifdef __cplusplus
 }

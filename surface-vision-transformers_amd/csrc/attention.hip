@@ -78,14 +78,14 @@ template <typename T>
 struct TrMma;
 
 template <>
-struct TrMma<bf16> {
+struct TrMma<h16> {
   static SITK_DEV void run(f32x4 (&o)[4], const f32x4 (&p)[4], const char* tile, int lane) {
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 pb;
+      h16x8 pb;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { pb[e] = (bf16)p[2 * s2][e]; pb[e + 4] = (bf16)p[2 * s2 + 1][e]; }
+      for (int e = 0; e < 4; ++e) { pb[e] = (h16)p[2 * s2][e]; pb[e + 4] = (h16)p[2 * s2 + 1][e]; }
       const u32x4 pf = __builtin_bit_cast(u32x4, pb);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -99,7 +99,7 @@ struct TrMma<bf16> {
         vf[1] = __builtin_bit_cast(u32x2, lo)[1];
         vf[2] = __builtin_bit_cast(u32x2, hi)[0];
         vf[3] = __builtin_bit_cast(u32x2, hi)[1];
-        o[dt] = Mma<bf16>::mma(vf, pf, o[dt]);
+        o[dt] = Mma<h16>::mma(vf, pf, o[dt]);
       }
     }
   }
@@ -402,7 +402,7 @@ struct LaneOffs {
   int row[2];  // row-read (ds_read_b128) offset of k-step ks for row (lane&15):  + t * 2048 per 16-row block
   int tr[4];   // transposed-read offset of column block dt for row 4*(lane>>4) + ((lane>>2)&3): + s2*4096, + 2048 (second half)
 };
-SITK_DEV LaneOffs lane_offs_bf16(int lane) {
+SITK_DEV LaneOffs lane_offs_h16(int lane) {
   LaneOffs o;
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -419,15 +419,15 @@ SITK_DEV void row_mma_o(f32x4 (&s)[4], const char* tile, const u32x4 (&frag)[2],
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
-      s[t] = Mma<bf16>::mma(*reinterpret_cast<const u32x4*>(tile + o.row[ks] + t * 2048), frag[ks], s[t]);
+      s[t] = Mma<h16>::mma(*reinterpret_cast<const u32x4*>(tile + o.row[ks] + t * 2048), frag[ks], s[t]);
 }
 template <int NS2 = 2>
 SITK_DEV void tr_mma_o(f32x4 (&acc)[4], const f32x4 (&p)[4], const char* tile, const LaneOffs& o) {
 #pragma unroll
   for (int s2 = 0; s2 < NS2; ++s2) {
-    bf16x8 pb;
+    h16x8 pb;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { pb[e] = (bf16)p[2 * s2][e]; pb[e + 4] = (bf16)p[2 * s2 + 1][e]; }
+    for (int e = 0; e < 4; ++e) { pb[e] = (h16)p[2 * s2][e]; pb[e + 4] = (h16)p[2 * s2 + 1][e]; }
     const u32x4 pf = __builtin_bit_cast(u32x4, pb);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -440,7 +440,7 @@ SITK_DEV void tr_mma_o(f32x4 (&acc)[4], const f32x4 (&p)[4], const char* tile, c
       vf[1] = __builtin_bit_cast(u32x2, lo)[1];
       vf[2] = __builtin_bit_cast(u32x2, hi)[0];
       vf[3] = __builtin_bit_cast(u32x2, hi)[1];
-      acc[dt] = Mma<bf16>::mma(vf, pf, acc[dt]);
+      acc[dt] = Mma<h16>::mma(vf, pf, acc[dt]);
     }
   }
 }
@@ -448,17 +448,21 @@ SITK_DEV void tr_mma_o(f32x4 (&acc)[4], const f32x4 (&p)[4], const char* tile, c
 // The same with the row sums of P taken by the matrix pipe: one more MFMA per 32-key half whose A operand is all ones
 // (bf16 1.0), so lsum[.] += sum_k P[k][lane & 15] in every register of lsum -- no VALU adds, no cross-lane reduction,
 // and the sum is taken over the bf16-rounded P that multiplies V.
-constexpr uint32_t kOnesBf16x2 = 0x3F803F80u;
+#ifdef SITK_TU_F16
+constexpr uint32_t kOnesH16x2 = 0x3C003C00u;   // two f16 ones
+#else
+constexpr uint32_t kOnesH16x2 = 0x3F803F80u;   // two bf16 ones
+#endif
 template <int NS2 = 2>
 SITK_DEV void tr_mma_o_sum(f32x4 (&acc)[4], f32x4& lsum, const f32x4 (&p)[4], const char* tile, const LaneOffs& o) {
-  const u32x4 ones = {kOnesBf16x2, kOnesBf16x2, kOnesBf16x2, kOnesBf16x2};
+  const u32x4 ones = {kOnesH16x2, kOnesH16x2, kOnesH16x2, kOnesH16x2};
 #pragma unroll
   for (int s2 = 0; s2 < NS2; ++s2) {
-    bf16x8 pb;
+    h16x8 pb;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { pb[e] = (bf16)p[2 * s2][e]; pb[e + 4] = (bf16)p[2 * s2 + 1][e]; }
+    for (int e = 0; e < 4; ++e) { pb[e] = (h16)p[2 * s2][e]; pb[e + 4] = (h16)p[2 * s2 + 1][e]; }
     const u32x4 pf = __builtin_bit_cast(u32x4, pb);
-    lsum = Mma<bf16>::mma(ones, pf, lsum);
+    lsum = Mma<h16>::mma(ones, pf, lsum);
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -470,7 +474,7 @@ SITK_DEV void tr_mma_o_sum(f32x4 (&acc)[4], f32x4& lsum, const f32x4 (&p)[4], co
       vf[1] = __builtin_bit_cast(u32x2, lo)[1];
       vf[2] = __builtin_bit_cast(u32x2, hi)[0];
       vf[3] = __builtin_bit_cast(u32x2, hi)[1];
-      acc[dt] = Mma<bf16>::mma(vf, pf, acc[dt]);
+      acc[dt] = Mma<h16>::mma(vf, pf, acc[dt]);
     }
   }
 }
@@ -478,9 +482,9 @@ SITK_DEV void tr_mma_o_sum(f32x4 (&acc)[4], f32x4& lsum, const f32x4 (&p)[4], co
 // one operand fragment (8 bf16) times a scalar, one rounding: the softmax scale (times log2 e) is folded into the Q (or K)
 // fragments a wave keeps in registers, so the score MFMAs deliver log2-domain scores and the elementwise part starts at exp2
 SITK_DEV u32x4 scale_frag(u32x4 f, float c) {
-  bf16x8 v = __builtin_bit_cast(bf16x8, f);
+  h16x8 v = __builtin_bit_cast(h16x8, f);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] * c);
+  for (int e = 0; e < 8; ++e) v[e] = (h16)((float)v[e] * c);
   return __builtin_bit_cast(u32x4, v);
 }
 SITK_DEV f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
@@ -493,7 +497,7 @@ SITK_DEV f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 constexpr float kRescaleThr = 8.0f;
 
 // rows [0, ntiles*64) x 64 bf16 columns of `src` (leading dim ld) -> LDS tiles [t][64][128 B]; rows >= nrows are zero
-SITK_DEV void dma_rows_bf16(char* dst, const bf16* __restrict__ src, size_t ld, int nrows, int ntiles, int wave, int lane, int nwaves) {
+SITK_DEV void dma_rows_h16(char* dst, const h16* __restrict__ src, size_t ld, int nrows, int ntiles, int wave, int lane, int nwaves) {
   const char* zero = reinterpret_cast<const char*>(g_zero_page_attn);
   for (int q = wave; q < ntiles * 8; q += nwaves) {      // one piece = 8 rows x 128 B
     const int row = q * 8 + (lane >> 3), r64 = row & 63;
@@ -515,9 +519,9 @@ SITK_DEV void tail_dispatch(int rows, F&& f) {
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+__global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const h16* __restrict__ qkv, h16* __restrict__ o,
                                                            float* __restrict__ lse, int N, int H, float scale) {
-  using T = bf16;
+  using T = h16;
   __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -526,12 +530,12 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
   const T* base = qkv + (size_t)b * N * ld;
   char* sK = smem;
   char* sV = smem + (RES_MAX_N / 64) * 8192;   // fixed distance: one address register serves both tiles
-  dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
-  dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
+  dma_rows_h16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
+  dma_rows_h16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
-  const LaneOffs lo = lane_offs_bf16(lane);
+  const LaneOffs lo = lane_offs_h16(lane);
   for (int qt = wave; qt * 16 < N; qt += WAVES) {
     const int q = qt * 16 + fr, qc = min(q, N - 1);
     u32x4 qf[2];
@@ -610,13 +614,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const bf16* __
 // key-side kernel in the same form.
 constexpr int FOLD_D = 192, FOLD_KS = FOLD_D / 32;
 template <int WAVES, bool FOLD = false>
-__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
-                                                              const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                              float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
-                                                              int H, float scale, const bf16* __restrict__ dxmid = nullptr,
-                                                              const bf16* __restrict__ wo_t = nullptr,
-                                                              bf16* __restrict__ d_o_out = nullptr) {
-  using T = bf16;
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const h16* __restrict__ qkv, const h16* __restrict__ o,
+                                                              const h16* __restrict__ d_o, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, h16* __restrict__ dqkv, int N,
+                                                              int H, float scale, const h16* __restrict__ dxmid = nullptr,
+                                                              const h16* __restrict__ wo_t = nullptr,
+                                                              h16* __restrict__ d_o_out = nullptr) {
+  using T = h16;
   __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192 + (FOLD ? 64 * FOLD_D * 2 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -627,13 +631,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const bf16*
   const T* base = qkv + (size_t)b * N * ld;
   char* sK = smem;
   char* sV = smem + (RES_MAX_N / 64) * 8192;   // fixed distance: one address register serves both tiles
-  dma_rows_bf16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
-  dma_rows_bf16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
+  dma_rows_h16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
+  dma_rows_h16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
   char* sW = smem + 2 * (RES_MAX_N / 64) * 8192;   // FOLD: [k-step panel 0..5][64 rows][64 B], 16-B slots XOR (row >> 2) & 3
   if constexpr (FOLD) {
     for (int pc = wave; pc < 4 * FOLD_KS; pc += WAVES) {     // one piece = 16 rows x 64 B of one panel
       const int panel = pc >> 2, row = (pc & 3) * 16 + (lane >> 2), kq = (lane & 3) ^ ((row >> 2) & 3);
-      const bf16* g = wo_t + (size_t)(h * 64 + row) * FOLD_D + panel * 32 + kq * 8;
+      const h16* g = wo_t + (size_t)(h * 64 + row) * FOLD_D + panel * 32 + kq * 8;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(sW + pc * 1024), 16, 0, 0);
     }
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const bf16*
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
-  const LaneOffs lo = lane_offs_bf16(lane);
+  const LaneOffs lo = lane_offs_h16(lane);
   // FOLD: A-fragment offsets of blocks ct = 0 / 1 (+ 2048 for ct = 2 / 3, + 4096 per k-step): row c(ct, m), chunk fq
   int wofs[2];
 #pragma unroll
@@ -664,18 +668,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const bf16*
         acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < FOLD_KS; ++ks)
-          acc[ct] = Mma<bf16>::mma(*reinterpret_cast<const u32x4*>(sW + wofs[ct & 1] + (ct >> 1) * 2048 + ks * 4096),
+          acc[ct] = Mma<h16>::mma(*reinterpret_cast<const u32x4*>(sW + wofs[ct & 1] + (ct >> 1) * 2048 + ks * 4096),
                                    dxf[ks], acc[ct]);
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 pk;
+        h16x8 pk;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { pk[e] = (bf16)acc[2 * ks][e]; pk[e + 4] = (bf16)acc[2 * ks + 1][e]; }
+        for (int e = 0; e < 4; ++e) { pk[e] = (h16)acc[2 * ks][e]; pk[e + 4] = (h16)acc[2 * ks + 1][e]; }
         dof[ks] = __builtin_bit_cast(u32x4, pk);
         const int eo = ks * 32 + fq * 8;
         qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
-        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(o + ((size_t)b * N + qc) * I + h * 64 + eo);
+        const h16x8 ov = *reinterpret_cast<const h16x8*>(o + ((size_t)b * N + qc) * I + h * 64 + eo);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dpart += (float)pk[e] * (float)ov[e];
         if (q < N) *reinterpret_cast<u32x4*>(d_o_out + ((size_t)b * N + q) * I + h * 64 + eo) = dof[ks];
@@ -734,10 +738,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const bf16*
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const h16* __restrict__ qkv, const h16* __restrict__ d_o,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               bf16* __restrict__ dqkv, int N, int H, float scale) {
-  using T = bf16;
+                                                               h16* __restrict__ dqkv, int N, int H, float scale) {
+  using T = h16;
   __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192 + 2 * RES_MAX_N * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -749,8 +753,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16
   float* sD = sL + RES_MAX_N;
   char* sQ = smem + 2 * RES_MAX_N * 4;
   char* sDO = sQ + (RES_MAX_N / 64) * 8192;    // fixed distance: one address register serves both tiles
-  dma_rows_bf16(sQ, base + h * 64, ld, N, nqt, wave, lane, WAVES);
-  dma_rows_bf16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, nqt, wave, lane, WAVES);
+  dma_rows_h16(sQ, base + h * 64, ld, N, nqt, wave, lane, WAVES);
+  dma_rows_h16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, nqt, wave, lane, WAVES);
   for (int r = tid; r < nqt * 64; r += WAVES * 64) {
     const size_t ridx = ((size_t)b * H + h) * N + min(r, N - 1);
     sL[r] = r < N ? -lse[ridx] * kLog2e : -INFINITY;   // negated (added below); exp2(x - inf) = 0 for padded query rows
@@ -759,7 +763,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const bf16
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float c = scale * kLog2e;
-  const LaneOffs lo = lane_offs_bf16(lane);
+  const LaneOffs lo = lane_offs_h16(lane);
   for (int kt = wave; kt * 16 < N; kt += WAVES) {
     const int key = kt * 16 + fr, kc = min(key, N - 1);
     u32x4 kf[2], vf[2];
@@ -838,9 +842,9 @@ constexpr int RING_STAGES = 3, RING_STAGE = 16384, RING_MAX_N = 2048;
                : "memory")
 
 SITK_DEV u32x4 pack_pair(const f32x4& a, const f32x4& b) {
-  bf16x8 pb;
+  h16x8 pb;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) { pb[e] = (bf16)a[e]; pb[e + 4] = (bf16)b[e]; }
+  for (int e = 0; e < 4; ++e) { pb[e] = (h16)a[e]; pb[e + 4] = (h16)b[e]; }
   return __builtin_bit_cast(u32x4, pb);
 }
 // transposed fragment (column block dt, row half s2) of the tile at `tile`: two compiler-visible ds_read_b64_tr_b16
@@ -862,7 +866,7 @@ struct RingLoader {
   uint32_t off[PPW];                     // lane offset of piece i (bytes, from the tile's first row)
   int prow[PPW], pdst[PPW];
   bool is_b[PPW];
-  SITK_DEV void init(const bf16* src_a, size_t ld_a, const bf16* src_b, size_t ld_b, int wave, int lane) {
+  SITK_DEV void init(const h16* src_a, size_t ld_a, const h16* src_b, size_t ld_b, int wave, int lane) {
     base_a = reinterpret_cast<const char*>(src_a);
     base_b = reinterpret_cast<const char*>(src_b);
     step_a = 128 * ld_a;
@@ -908,7 +912,7 @@ SITK_DEV RingBlock ring_block(int nxb, int H) {
 }
 
 template <int WAVES, int QT, int MINW>
-__global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ o,
+__global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const h16* __restrict__ qkv, h16* __restrict__ o,
                                                                    float* __restrict__ lse, int N, int H, float scale, int nqb) {
   __shared__ __attribute__((aligned(256))) char smem[RING_STAGES * RING_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -916,7 +920,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
   const RingBlock bc = ring_block(nqb, H);
   const int h = bc.h, b = bc.b, I = H * 64, nkt = (N + 63) / 64;
   const size_t ld = (size_t)3 * I;
-  const bf16* base = qkv + (size_t)b * N * ld;
+  const h16* base = qkv + (size_t)b * N * ld;
   RingLoader<WAVES> dma;
   dma.init(base + I + h * 64, ld, base + 2 * I + h * 64, ld, wave, lane);
   dma.issue_any(smem, 0, N);
@@ -934,9 +938,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     for (int ks = 0; ks < 2; ++ks)
       qf[j][ks] = scale_frag(*reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + ks * 32 + fq * 8), scale * kLog2e);
   }
-  const LaneOffs lo = lane_offs_bf16(lane);
+  const LaneOffs lo = lane_offs_h16(lane);
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const u32x4 ones = {kOnesBf16x2, kOnesBf16x2, kOnesBf16x2, kOnesBf16x2};
+  const u32x4 ones = {kOnesH16x2, kOnesH16x2, kOnesH16x2, kOnesH16x2};
   float m[QT];
   f32x4 negm[QT], lacc[QT];
   f32x4 oacc[QT][4];
@@ -974,7 +978,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < QT; ++j) s[j][i] = Mma<bf16>::mma(kf[i][ks], qf[j][ks], s[j][i]);
+        for (int j = 0; j < QT; ++j) s[j][i] = Mma<h16>::mma(kf[i][ks], qf[j][ks], s[j][i]);
     u32x4 pf[QT][2];
 #pragma unroll
     for (int j = 0; j < QT; ++j) {
@@ -1019,11 +1023,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
 #pragma unroll
     for (int s2 = 0; s2 < (NT + 1) / 2; ++s2) {
 #pragma unroll
-      for (int j = 0; j < QT; ++j) lacc[j] = Mma<bf16>::mma(ones, pf[j][s2], lacc[j]);    // row sums of P on the matrix pipe
+      for (int j = 0; j < QT; ++j) lacc[j] = Mma<h16>::mma(ones, pf[j][s2], lacc[j]);    // row sums of P on the matrix pipe
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int j = 0; j < QT; ++j) oacc[j][dt] = Mma<bf16>::mma(vf[s2][dt], pf[j][s2], oacc[j][dt]);
+        for (int j = 0; j < QT; ++j) oacc[j][dt] = Mma<h16>::mma(vf[s2][dt], pf[j][s2], oacc[j][dt]);
     }
   };
   const int nfull = N >> 6;                               // >= 1 (ring kernels take N >= 64)
@@ -1038,7 +1042,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
     const float inv = 1.0f / lt;
     const int q = qrow[j];
     if (q < N) {
-      bf16* orow = o + ((size_t)b * N + q) * I + h * 64;
+      h16* orow = o + ((size_t)b * N + q) * I + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt + 4 * fq, oacc[j][dt] * inv);
       if (fq == 0) lse[((size_t)b * H + h) * N + q] = (m[j] + __log2f(lt)) * kLn2;
@@ -1048,9 +1052,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_fwd_ring_kernel(const b
 
 // backward, query side: dQ, delta; same sweep as forward (K and V tiles in the ring), three products per tile
 template <int WAVES, int QT, int MINW>
-__global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ o,
-                                                                      const bf16* __restrict__ d_o, const float* __restrict__ lse,
-                                                                      float* __restrict__ delta, bf16* __restrict__ dqkv, int N,
+__global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(const h16* __restrict__ qkv, const h16* __restrict__ o,
+                                                                      const h16* __restrict__ d_o, const float* __restrict__ lse,
+                                                                      float* __restrict__ delta, h16* __restrict__ dqkv, int N,
                                                                       int H, float scale, int nqb) {
   __shared__ __attribute__((aligned(256))) char smem[RING_STAGES * RING_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1058,7 +1062,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
   const RingBlock bc = ring_block(nqb, H);
   const int h = bc.h, b = bc.b, I = H * 64, nkt = (N + 63) / 64;
   const size_t ld = (size_t)3 * I;
-  const bf16* base = qkv + (size_t)b * N * ld;
+  const h16* base = qkv + (size_t)b * N * ld;
   RingLoader<WAVES> dma;
   dma.init(base + I + h * 64, ld, base + 2 * I + h * 64, ld, wave, lane);
   dma.issue_any(smem, 0, N);
@@ -1078,11 +1082,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
     for (int ks = 0; ks < 2; ++ks) {
       const int eo = ks * 32 + fq * 8;
       qf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
-      const bf16* dop = d_o + ((size_t)b * N + qc) * I + h * 64 + eo;
-      const bf16* op = o + ((size_t)b * N + qc) * I + h * 64 + eo;
+      const h16* dop = d_o + ((size_t)b * N + qc) * I + h * 64 + eo;
+      const h16* op = o + ((size_t)b * N + qc) * I + h * 64 + eo;
       dof[j][ks] = *reinterpret_cast<const u32x4*>(dop);
-      const bf16x8 dv8 = __builtin_bit_cast(bf16x8, dof[j][ks]);
-      const bf16x8 ov8 = *reinterpret_cast<const bf16x8*>(op);
+      const h16x8 dv8 = __builtin_bit_cast(h16x8, dof[j][ks]);
+      const h16x8 ov8 = *reinterpret_cast<const h16x8*>(op);
 #pragma unroll
       for (int e = 0; e < 8; ++e) dpart += (float)dv8[e] * (float)ov8[e];
     }
@@ -1094,7 +1098,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[j][ks] = scale_frag(qf[j][ks], scale * kLog2e);
   }
-  const LaneOffs lo = lane_offs_bf16(lane);
+  const LaneOffs lo = lane_offs_h16(lane);
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   f32x4 dq[QT][4];
 #pragma unroll
@@ -1128,10 +1132,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (i >= NT) { s[i] = splat4(0.f); continue; }
-          s[i] = Mma<bf16>::mma(kf[i][0], qf[j][0], s0);
-          dp[i] = Mma<bf16>::mma(vf[i][0], dof[j][0], d0);
-          s[i] = Mma<bf16>::mma(kf[i][1], qf[j][1], s[i]);
-          dp[i] = Mma<bf16>::mma(vf[i][1], dof[j][1], dp[i]);
+          s[i] = Mma<h16>::mma(kf[i][0], qf[j][0], s0);
+          dp[i] = Mma<h16>::mma(vf[i][0], dof[j][0], d0);
+          s[i] = Mma<h16>::mma(kf[i][1], qf[j][1], s[i]);
+          dp[i] = Mma<h16>::mma(vf[i][1], dof[j][1], dp[i]);
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -1161,7 +1165,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int j = 0; j < QT; ++j) dq[j][dt] = Mma<bf16>::mma(kt[s2][dt], pf[j][s2], dq[j][dt]);
+        for (int j = 0; j < QT; ++j) dq[j][dt] = Mma<h16>::mma(kt[s2][dt], pf[j][s2], dq[j][dt]);
   };
   const int nfull = N >> 6;
   for (int t = 0; t < nfull; ++t) body(t, std::integral_constant<int, 0>{});
@@ -1170,7 +1174,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
 #pragma unroll
   for (int j = 0; j < QT; ++j)
     if (qrow[j] < N) {
-      bf16* row = dqkv + ((size_t)b * N + qrow[j]) * ld + h * 64;
+      h16* row = dqkv + ((size_t)b * N + qrow[j]) * ld + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt + 4 * fq, dq[j][dt] * scale);
     }
@@ -1181,16 +1185,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dq_ring_kernel(cons
 // S and dP products (S' = Q K^T - lse / scale, p = exp2(c S'); dP' = dO V^T - delta), so the elementwise part is one
 // multiply + exp2 and one multiply per element.  Padded query rows carry -inf there: p = 0.
 template <int WAVES, int QT, int MINW>
-__global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ d_o,
+__global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(const h16* __restrict__ qkv, const h16* __restrict__ d_o,
                                                                        const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                       bf16* __restrict__ dqkv, int N, int H, float scale, int nkb) {
+                                                                       h16* __restrict__ dqkv, int N, int H, float scale, int nkb) {
   __shared__ __attribute__((aligned(256))) char smem[RING_STAGES * RING_STAGE + 2 * RING_MAX_N * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const RingBlock bc = ring_block(nkb, H);
   const int h = bc.h, b = bc.b, I = H * 64, nqt = (N + 63) / 64;
   const size_t ld = (size_t)3 * I;
-  const bf16* base = qkv + (size_t)b * N * ld;
+  const h16* base = qkv + (size_t)b * N * ld;
   RingLoader<WAVES> dma;
   dma.init(base + h * 64, ld, d_o + (size_t)b * N * I + h * 64, (size_t)I, wave, lane);
   float* sL = reinterpret_cast<float*>(smem + RING_STAGES * RING_STAGE);
@@ -1218,7 +1222,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
       vf[j][ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + eo);
     }
   }
-  const LaneOffs lo = lane_offs_bf16(lane);
+  const LaneOffs lo = lane_offs_h16(lane);
   const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lstat = lbase + RING_STAGES * RING_STAGE + 16 * fq;      // + t * 256 + i * 64 ; sD at + RING_MAX_N * 4
   f32x4 dk[QT][4], dv[QT][4];
@@ -1261,10 +1265,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (i >= NT) { s[i] = splat4(0.f); dp[i] = splat4(0.f); continue; }
-          s[i] = Mma<bf16>::mma(qr[i][0], kf[j][0], sl[i]);
-          dp[i] = Mma<bf16>::mma(dor[i][0], vf[j][0], sd[i]);
-          s[i] = Mma<bf16>::mma(qr[i][1], kf[j][1], s[i]);
-          dp[i] = Mma<bf16>::mma(dor[i][1], vf[j][1], dp[i]);
+          s[i] = Mma<h16>::mma(qr[i][0], kf[j][0], sl[i]);
+          dp[i] = Mma<h16>::mma(dor[i][0], vf[j][0], sd[i]);
+          s[i] = Mma<h16>::mma(qr[i][1], kf[j][1], s[i]);
+          dp[i] = Mma<h16>::mma(dor[i][1], vf[j][1], dp[i]);
         }
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -1286,7 +1290,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
       for (int dt = 0; dt < 4; ++dt) {
         const u32x4 f = ring_tr_frag(tile + 8192, lo, s2, dt);          // dO^T
 #pragma unroll
-        for (int j = 0; j < QT; ++j) dv[j][dt] = Mma<bf16>::mma(f, pp[j][s2], dv[j][dt]);
+        for (int j = 0; j < QT; ++j) dv[j][dt] = Mma<h16>::mma(f, pp[j][s2], dv[j][dt]);
       }
     u32x4 qt_[2][4];
 #pragma unroll
@@ -1300,7 +1304,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int j = 0; j < QT; ++j) dk[j][dt] = Mma<bf16>::mma(qt_[s2][dt], pds[j][s2], dk[j][dt]);
+        for (int j = 0; j < QT; ++j) dk[j][dt] = Mma<h16>::mma(qt_[s2][dt], pds[j][s2], dk[j][dt]);
   };
   const int nfull = N >> 6;
   for (int t = 0; t < nfull; ++t) body(t, std::integral_constant<int, 0>{});
@@ -1309,7 +1313,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void attn_bwd_dkv_ring_kernel(con
 #pragma unroll
   for (int j = 0; j < QT; ++j)
     if (krow[j] < N) {
-      bf16* row = dqkv + ((size_t)b * N + krow[j]) * ld + h * 64;
+      h16* row = dqkv + ((size_t)b * N + krow[j]) * ld + h * 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         store4(row + I + 16 * dt + 4 * fq, dk[j][dt] * scale);
@@ -1332,14 +1336,14 @@ template <typename T>
 static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     if (N <= RES_MAX_N) {
-      hipLaunchKernelGGL(attn_fwd_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
-                         reinterpret_cast<bf16*>(o), lse, N, H, scale);
+      hipLaunchKernelGGL(attn_fwd_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
+                         reinterpret_cast<h16*>(o), lse, N, H, scale);
       return check_launch("attention_fwd_res");
     }
     if (ring_supported(N)) {
       const int nqb = ring_blocks(N);
       hipLaunchKernelGGL((attn_fwd_ring_kernel<RING_W, RING_QT, 3>), dim3(nqb * H * B), dim3(RING_W * 64), 0, s,
-                         reinterpret_cast<const bf16*>(qkv), reinterpret_cast<bf16*>(o), lse, N, H, scale, nqb);
+                         reinterpret_cast<const h16*>(qkv), reinterpret_cast<h16*>(o), lse, N, H, scale, nqb);
       return check_launch("attention_fwd_ring");
     }
   }
@@ -1349,21 +1353,21 @@ static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, fl
   return check_launch("attention_fwd");
 }
 
-static bool bwd_proj_supported(int N, int D, int dtype) { return dtype == SITK_BF16 && N <= RES_MAX_N && D == FOLD_D; }
+static bool bwd_proj_supported(int N, int D, int dtype) { return dtype == SITK_H16 && N <= RES_MAX_N && D == FOLD_D; }
 
 // phases: bit 0 = the query-side kernel (dQ, delta[, dO]), bit 1 = the key-side kernel (dK, dV); 3 = the whole backward.
 // (Single phases exist so that a profiler / bench.py can time each kernel of the pair by itself.)
 static int run_bwd_proj(const void* qkv, const void* o, const void* dxmid, const void* wo_t, void* d_o, const float* lse,
                         float* delta, void* dqkv, int B, int N, int H, float scale, hipStream_t s, int phases = 3) {
   if (phases & 1)
-  hipLaunchKernelGGL((attn_bwd_dq_res_kernel<16, true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
-                     reinterpret_cast<const bf16*>(o), (const bf16*)nullptr, lse, delta, reinterpret_cast<bf16*>(dqkv), N, H,
-                     scale, reinterpret_cast<const bf16*>(dxmid), reinterpret_cast<const bf16*>(wo_t),
-                     reinterpret_cast<bf16*>(d_o));
+  hipLaunchKernelGGL((attn_bwd_dq_res_kernel<16, true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
+                     reinterpret_cast<const h16*>(o), (const h16*)nullptr, lse, delta, reinterpret_cast<h16*>(dqkv), N, H,
+                     scale, reinterpret_cast<const h16*>(dxmid), reinterpret_cast<const h16*>(wo_t),
+                     reinterpret_cast<h16*>(d_o));
   SITK_LAUNCH_CHECK("attention_bwd_proj_dq_res");
   if (phases & 2)
-  hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
-                     reinterpret_cast<const bf16*>(d_o), lse, delta, reinterpret_cast<bf16*>(dqkv), N, H, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const h16*>(qkv),
+                     reinterpret_cast<const h16*>(d_o), lse, delta, reinterpret_cast<h16*>(dqkv), N, H, scale);
   return check_launch("attention_bwd_dkv_res");
 }
 
@@ -1373,19 +1377,19 @@ static int run_bwd(const void* qkv, const void* o, const void* d_o, const float*
   if constexpr (sizeof(T) == 2) {
     if (N <= RES_MAX_N) {
       if (phases & 1)
-      hipLaunchKernelGGL(attn_bwd_dq_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const bf16*>(qkv),
-                         reinterpret_cast<const bf16*>(o), reinterpret_cast<const bf16*>(d_o), lse, delta,
-                         reinterpret_cast<bf16*>(dqkv), N, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dq_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
+                         reinterpret_cast<const h16*>(o), reinterpret_cast<const h16*>(d_o), lse, delta,
+                         reinterpret_cast<h16*>(dqkv), N, H, scale);
       SITK_LAUNCH_CHECK("attention_bwd_dq_res");
       if (phases & 2)
-      hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const bf16*>(qkv),
-                         reinterpret_cast<const bf16*>(d_o), lse, delta, reinterpret_cast<bf16*>(dqkv), N, H, scale);
+      hipLaunchKernelGGL(attn_bwd_dkv_res_kernel<8>, dim3(B * H), dim3(512), 0, s, reinterpret_cast<const h16*>(qkv),
+                         reinterpret_cast<const h16*>(d_o), lse, delta, reinterpret_cast<h16*>(dqkv), N, H, scale);
       return check_launch("attention_bwd_dkv_res");
     }
     if (ring_supported(N)) {
       const int nb = ring_blocks(N);
-      const bf16 *q_ = reinterpret_cast<const bf16*>(qkv), *o_ = reinterpret_cast<const bf16*>(o), *do_ = reinterpret_cast<const bf16*>(d_o);
-      bf16* dq_ = reinterpret_cast<bf16*>(dqkv);
+      const h16 *q_ = reinterpret_cast<const h16*>(qkv), *o_ = reinterpret_cast<const h16*>(o), *do_ = reinterpret_cast<const h16*>(d_o);
+      h16* dq_ = reinterpret_cast<h16*>(dqkv);
       if (phases & 1)
         hipLaunchKernelGGL((attn_bwd_dq_ring_kernel<RING_W, RING_QT, 2>), dim3(nb * H * B), dim3(RING_W * 64), 0, s, q_, o_, do_, lse,
                            delta, dq_, N, H, scale, nb);
@@ -1410,46 +1414,56 @@ static int run_bwd(const void* qkv, const void* o, const void* d_o, const float*
 
 }  // namespace sitk
 
+SITK_F16_TWIN(sitk_attention_fwd)
 extern "C" int sitk_attention_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, int dtype,
                                   sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_attention_fwd, qkv, o, lse, B, N, H, scale, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(qkv && o && lse, "attention_fwd: null pointer");
   SITK_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attention_fwd: bad shape B=%d N=%d H=%d", B, N, H);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return run_fwd<bf16>(qkv, o, lse, B, N, H, scale, s);
+  if (dtype == SITK_H16) return run_fwd<h16>(qkv, o, lse, B, N, H, scale, s);
   if (dtype == SITK_F32) return run_fwd<float>(qkv, o, lse, B, N, H, scale, s);
   set_error("attention_fwd: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 
+SITK_F16_TWIN(sitk_attention_bwd)
 extern "C" int sitk_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, float* delta,
                                   void* dqkv, int B, int N, int H, float scale, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_attention_bwd, qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(qkv && o && d_o && lse && delta && dqkv, "attention_bwd: null pointer");
   SITK_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attention_bwd: bad shape B=%d N=%d H=%d", B, N, H);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return run_bwd<bf16>(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, s);
+  if (dtype == SITK_H16) return run_bwd<h16>(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, s);
   if (dtype == SITK_F32) return run_bwd<float>(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, s);
   set_error("attention_bwd: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 
-extern "C" int sitk_attention_bwd_proj_supported(int N, int D, int dtype) { return sitk::bwd_proj_supported(N, D, dtype) ? 1 : 0; }
+SITK_F16_TWIN(sitk_attention_bwd_proj_supported)
+extern "C" int sitk_attention_bwd_proj_supported(int N, int D, int dtype) {
+  SITK_FORWARD_F16(dtype, sitk_attention_bwd_proj_supported, N, D, dtype); return sitk::bwd_proj_supported(N, D, dtype) ? 1 : 0; }
 
+SITK_F16_TWIN(sitk_attention_bwd_proj)
 extern "C" int sitk_attention_bwd_proj(const void* qkv, const void* o, const void* dxmid, const void* wo_t, void* d_o,
                                        const float* lse, float* delta, void* dqkv, int B, int N, int H, int D, float scale,
                                        int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_attention_bwd_proj, qkv, o, dxmid, wo_t, d_o, lse, delta, dqkv, B, N, H, D, scale, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(qkv && o && dxmid && wo_t && d_o && lse && delta && dqkv, "attention_bwd_proj: null pointer");
   SITK_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attention_bwd_proj: bad shape B=%d N=%d H=%d", B, N, H);
-  SITK_REQUIRE(bwd_proj_supported(N, D, dtype), "attention_bwd_proj: unsupported N=%d D=%d dtype=%d (bf16, N <= %d, D == %d)", N,
+  SITK_REQUIRE(bwd_proj_supported(N, D, dtype), "attention_bwd_proj: unsupported N=%d D=%d dtype=%d (h16, N <= %d, D == %d)", N,
                D, dtype, RES_MAX_N, FOLD_D);
   return run_bwd_proj(qkv, o, dxmid, wo_t, d_o, lse, delta, dqkv, B, N, H, scale, reinterpret_cast<hipStream_t>(stream));
 }
 
+SITK_F16_TWIN(sitk_attention_bwd_phases)
 extern "C" int sitk_attention_bwd_phases(const void* qkv, const void* o, const void* d_o_in, const void* dxmid, const void* wo_t,
                                          void* d_o_out, const float* lse, float* delta, void* dqkv, int B, int N, int H, int D,
                                          float scale, int dtype, int phases, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_attention_bwd_phases, qkv, o, d_o_in, dxmid, wo_t, d_o_out, lse, delta, dqkv, B, N, H, D, scale, dtype, phases, stream);
   using namespace sitk;
   SITK_REQUIRE(qkv && o && lse && delta && dqkv && phases >= 1 && phases <= 3, "attention_bwd_phases: bad arguments");
   SITK_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 65535 && B <= 65535, "attention_bwd_phases: bad shape B=%d N=%d H=%d", B, N, H);
@@ -1459,7 +1473,7 @@ extern "C" int sitk_attention_bwd_phases(const void* qkv, const void* o, const v
     return run_bwd_proj(qkv, o, dxmid, wo_t, d_o_out, lse, delta, dqkv, B, N, H, scale, s, phases);
   }
   SITK_REQUIRE(d_o_in, "attention_bwd_phases: null d_o");
-  if (dtype == SITK_BF16) return run_bwd<bf16>(qkv, o, d_o_in, lse, delta, dqkv, B, N, H, scale, s, phases);
+  if (dtype == SITK_H16) return run_bwd<h16>(qkv, o, d_o_in, lse, delta, dqkv, B, N, H, scale, s, phases);
   if (dtype == SITK_F32) return run_bwd<float>(qkv, o, d_o_in, lse, delta, dqkv, B, N, H, scale, s, phases);
   set_error("attention_bwd_phases: bad dtype %d", dtype);
   return SITK_ERR_INVALID;

@@ -4,14 +4,33 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// ---- the 16-bit compute type of THIS translation unit ------------------------------------------------------------
+// Every kernel source except core.hip is compiled twice: once with h16 = bf16 (SITK_BF16, the default objects) and once
+// with -DSITK_TU_F16, h16 = IEEE half (SITK_F16, *.f16.o).  Same MFMA rate (v_mfma_f32_16x16x32_{bf16,f16}), same bytes,
+// three more mantissa bits -- the mode that meets north_star's 1e-3 (bf16: one 2^-9 rounding per operand) -- at the
+// price of a narrow exponent: backward runs on a loss-scaled gradient stream (engine.py, functional.py).
+// In the f16 objects every exported name carries the suffix __f16 (f16_names.h) and `namespace sitk` is sitk_f16; the
+// public entry points (the bf16 objects) forward there when called with dtype == SITK_F16 (SITK_FORWARD_F16).
+#ifdef SITK_TU_F16
+#include "f16_names.h"
+#define sitk sitk_f16
+#endif
 #include "../../include/sitk.h"
 
-typedef __bf16 bf16;
+#ifdef SITK_TU_F16
+typedef _Float16 h16;
+#define SITK_H16 SITK_F16
+#define SITK_H16_MNEMONIC "f16"
+#else
+typedef __bf16 h16;
+#define SITK_H16 SITK_BF16
+#define SITK_H16_MNEMONIC "bf16"
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) h16 h16x8;
+typedef __attribute__((ext_vector_type(4))) h16 h16x4;
+typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 typedef __attribute__((ext_vector_type(4))) short i16x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
@@ -22,10 +41,27 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 // ------------------------------------------------------------------------------------------
 // host-side error plumbing (thread-local message, negative return codes)
 // ------------------------------------------------------------------------------------------
-namespace sitk {
+namespace sitk_rt {   // core.hip (compiled once): one thread-local message for both sets of objects
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+}  // namespace sitk_rt
+namespace sitk {
+using sitk_rt::check_launch;
+using sitk_rt::set_error;
 }  // namespace sitk
+
+// Public entry point `fn` called with dtype == SITK_F16: hand over to its twin in the f16 objects (same signature).
+// SITK_F16_TWIN(fn) declares the twin at file scope; in the f16 objects both expand to nothing.
+#ifdef SITK_TU_F16
+#define SITK_F16_TWIN(fn)
+#define SITK_FORWARD_F16(dt, fn, ...)
+#else
+#define SITK_F16_TWIN(fn) extern "C" decltype(fn) fn##__f16;
+#define SITK_FORWARD_F16(dt, fn, ...) \
+  do {                                \
+    if ((dt) == SITK_F16) return fn##__f16(__VA_ARGS__); \
+  } while (0)
+#endif
 
 #define SITK_REQUIRE(cond, ...)                      \
   do {                                               \
@@ -150,7 +186,7 @@ SITK_DEV int lds_off(int row, int byte_in_row) {
 
 // ------------------------------------------------------------------------------------------
 // MFMA traits.  An "mma step" consumes one 16-byte vector per lane from each operand:
-//   bf16: v_mfma_f32_16x16x32_bf16, K = 32; lane l holds k = 8*(l>>4) + j, j = 0..7
+//   h16 : v_mfma_f32_16x16x32_{bf16,f16}, K = 32; lane l holds k = 8*(l>>4) + j, j = 0..7
 //   f32 : 4 x v_mfma_f32_16x16x4_f32, K = 16; lane l holds k = 4*(l>>4) + j and the j-th
 //         instruction contracts element j of every lane (same k on both operands, so the
 //         permuted k order is consistent).  Exact f32 (fma chain), 1/16 of the bf16 rate:
@@ -162,11 +198,15 @@ template <typename T>
 struct Mma;
 
 template <>
-struct Mma<bf16> {
+struct Mma<h16> {
   static constexpr int EPV = 8;     // elements per 16-byte vector
   static constexpr int KSTEP = 32;  // contraction elements per step
   static SITK_DEV f32x4 mma(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#ifdef SITK_TU_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+#endif
   }
 };
 
@@ -188,22 +228,22 @@ SITK_DEV T from_f32(float v);
 template <>
 SITK_DEV float from_f32<float>(float v) { return v; }
 template <>
-SITK_DEV bf16 from_f32<bf16>(float v) { return (bf16)v; }
+SITK_DEV h16 from_f32<h16>(float v) { return (h16)v; }
 
 SITK_DEV float to_f32(float v) { return v; }
-SITK_DEV float to_f32(bf16 v) { return (float)v; }
+SITK_DEV float to_f32(h16 v) { return (float)v; }
 
 // store 4 consecutive elements (8 or 16 bytes)
 SITK_DEV void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-SITK_DEV void store4(bf16* p, f32x4 v) {
-  bf16x4 o;
+SITK_DEV void store4(h16* p, f32x4 v) {
+  h16x4 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (bf16)v[i];
-  *reinterpret_cast<bf16x4*>(p) = o;
+  for (int i = 0; i < 4; ++i) o[i] = (h16)v[i];
+  *reinterpret_cast<h16x4*>(p) = o;
 }
 SITK_DEV f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-SITK_DEV f32x4 load4(const bf16* p) {
-  const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+SITK_DEV f32x4 load4(const h16* p) {
+  const h16x4 v = *reinterpret_cast<const h16x4*>(p);
   f32x4 o;
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = (float)v[i];
@@ -219,12 +259,12 @@ struct VecLoad<T, T> {
   static SITK_DEV u32x4 load(const T* p) { return *reinterpret_cast<const u32x4*>(p); }
 };
 template <>
-struct VecLoad<bf16, float> {
+struct VecLoad<h16, float> {
   static SITK_DEV u32x4 load(const float* p) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-    bf16x8 o;
+    h16x8 o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i] = (bf16)a[i]; o[i + 4] = (bf16)b[i]; }
+    for (int i = 0; i < 4; ++i) { o[i] = (h16)a[i]; o[i + 4] = (h16)b[i]; }
     return __builtin_bit_cast(u32x4, o);
   }
 };
@@ -237,4 +277,4 @@ struct Dtype;
 template <>
 struct Dtype<float> { static constexpr int code = SITK_F32; };
 template <>
-struct Dtype<bf16> { static constexpr int code = SITK_BF16; };
+struct Dtype<h16> { static constexpr int code = SITK_H16; };

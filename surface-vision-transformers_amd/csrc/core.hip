@@ -6,7 +6,7 @@
 
 #include "common.h"
 
-namespace sitk {
+namespace sitk_rt {
 
 static thread_local char g_err[512] = "";
 
@@ -27,7 +27,7 @@ int check_launch(const char* what) {
   return SITK_OK;
 }
 
-}  // namespace sitk
+}  // namespace sitk_rt
 
 // ---- timeline: HIP events between the launches of a chain (profiling aid, see sitk.h) ----
 struct sitk_timeline {
@@ -75,5 +75,5 @@ extern "C" int sitk_timeline_read(sitk_timeline* t, float* us, const char** labe
 }
 
 extern "C" int sitk_abi_version(void) { return SITK_ABI_VERSION; }
-extern "C" const char* sitk_last_error(void) { return sitk::g_err; }
-extern "C" int sitk_dtype_size(int dtype) { return dtype == SITK_BF16 ? 2 : (dtype == SITK_F32 ? 4 : 0); }
+extern "C" const char* sitk_last_error(void) { return sitk_rt::g_err; }
+extern "C" int sitk_dtype_size(int dtype) { return (dtype == SITK_BF16 || dtype == SITK_F16) ? 2 : (dtype == SITK_F32 ? 4 : 0); }

@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256) void stage_weights_vec_kernel(StageArgs a) {
   const int t = bid - M.tile_begin;
   const int r0 = (t / M.tiles_c) * 64, c0 = (t % M.tiles_c) * 64;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  bf16* dc = reinterpret_cast<bf16*>(M.dst_c);
-  bf16* dt = reinterpret_cast<bf16*>(M.dst_t);
+  h16* dc = reinterpret_cast<h16*>(M.dst_c);
+  h16* dt = reinterpret_cast<h16*>(M.dst_t);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + 16 * i, c = c0 + 4 * tx;
@@ -77,10 +77,10 @@ __global__ __launch_bounds__(256) void stage_weights_vec_kernel(StageArgs a) {
     if (r < M.rows && c < M.cols) {
       v = *reinterpret_cast<const f32x4*>(M.src + (size_t)r * M.cols + c);
       if (dc) {
-        bf16x4 o;
+        h16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-        *reinterpret_cast<bf16x4*>(dc + (size_t)r * M.cols + c) = o;
+        for (int e = 0; e < 4; ++e) o[e] = (h16)v[e];
+        *reinterpret_cast<h16x4*>(dc + (size_t)r * M.cols + c) = o;
       }
     }
 #pragma unroll
@@ -92,10 +92,10 @@ __global__ __launch_bounds__(256) void stage_weights_vec_kernel(StageArgs a) {
     for (int i = 0; i < 4; ++i) {
       const int c = c0 + ty + 16 * i, r = r0 + 4 * tx;
       if (c < M.cols && r < M.rows) {
-        bf16x4 o;
+        h16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)tile[4 * tx + e][ty + 16 * i];
-        *reinterpret_cast<bf16x4*>(dt + (size_t)c * M.rows + r) = o;
+        for (int e = 0; e < 4; ++e) o[e] = (h16)tile[4 * tx + e][ty + 16 * i];
+        *reinterpret_cast<h16x4*>(dt + (size_t)c * M.rows + r) = o;
       }
     }
   }
@@ -146,7 +146,7 @@ static bool qkv_fused(const sitk_encoder_cfg& c) { return sitk_ln_gemm_fused_sup
 
 static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) {
   Layout L;
-  const size_t es = c.dtype == SITK_BF16 ? 2 : 4;
+  const size_t es = c.dtype == SITK_H16 ? 2 : 4;
   const size_t R = (size_t)c.B * c.N, D = c.dim, I = (size_t)c.heads * 64, M = c.mlp_dim;
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = acts ? acts + off : nullptr; off += align_up(bytes, 256); return p; };
@@ -219,7 +219,7 @@ static int check_cfg(const sitk_encoder_cfg* c) {
   SITK_REQUIRE(c->B > 0 && c->N > 0 && c->depth > 0 && c->heads > 0, "encoder: bad shape");
   SITK_REQUIRE(c->dim > 0 && c->dim % 8 == 0 && c->dim <= 1024, "encoder: dim=%d must be a multiple of 8 and <= 1024", c->dim);
   SITK_REQUIRE(c->mlp_dim > 0 && c->mlp_dim % 8 == 0, "encoder: mlp_dim=%d must be a multiple of 8", c->mlp_dim);
-  SITK_REQUIRE(c->dtype == SITK_BF16 || c->dtype == SITK_F32, "encoder: bad dtype %d", c->dtype);
+  SITK_REQUIRE(c->dtype == SITK_H16 || c->dtype == SITK_F32, "encoder: bad dtype %d", c->dtype);
   return SITK_OK;
 }
 
@@ -252,7 +252,7 @@ static int stage_all(const sitk_encoder_cfg& c, const sitk_layer_params* P, cons
       hipLaunchKernelGGL(stage_weights_vec_kernel, dim3(tiles), dim3(256), 0, s, a);
       e = check_launch("stage_weights_vec");
     } else {
-      e = f32 ? launch_stage<float>(a, tiles, s) : launch_stage<bf16>(a, tiles, s);
+      e = f32 ? launch_stage<float>(a, tiles, s) : launch_stage<h16>(a, tiles, s);
     }
     a.count = 0;
     tiles = 0;
@@ -279,17 +279,23 @@ static int stage_all(const sitk_encoder_cfg& c, const sitk_layer_params* P, cons
 
 using namespace sitk;
 
+SITK_F16_TWIN(sitk_encoder_acts_bytes)
 extern "C" size_t sitk_encoder_acts_bytes(const sitk_encoder_cfg* cfg) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_acts_bytes, cfg);
   if (check_cfg(cfg)) return 0;
   return make_layout(*cfg, nullptr, nullptr).acts_bytes;
 }
+SITK_F16_TWIN(sitk_encoder_scratch_bytes)
 extern "C" size_t sitk_encoder_scratch_bytes(const sitk_encoder_cfg* cfg) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_scratch_bytes, cfg);
   if (check_cfg(cfg)) return 0;
   return make_layout(*cfg, nullptr, nullptr).scratch_bytes;
 }
 
+SITK_F16_TWIN(sitk_encoder_fwd)
 extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const float* x_in, float* x_out,
                                 void* acts, size_t acts_bytes, void* scratch, size_t scratch_bytes, int save, sitk_stream_t stream) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_fwd, cfg, P, x_in, x_out, acts, acts_bytes, scratch, scratch_bytes, save, stream);
   SITK_TRY(check_cfg(cfg));
   SITK_REQUIRE(P && x_in && x_out && acts && scratch, "encoder_fwd: null pointer");
   const sitk_encoder_cfg& c = *cfg;
@@ -375,26 +381,32 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   return SITK_OK;
 }
 
+SITK_F16_TWIN(sitk_encoder_bwd)
 extern "C" int sitk_encoder_bwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
                                 const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
                                 size_t scratch_bytes, int layer_begin, int layer_end, sitk_stream_t stream) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_bwd, cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, stream);
   return sitk_encoder_bwd_embed(cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, nullptr,
                                 nullptr, nullptr, stream);
 }
 
+SITK_F16_TWIN(sitk_encoder_bwd_embed)
 extern "C" int sitk_encoder_bwd_embed(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
                                       const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
                                       size_t scratch_bytes, int layer_begin, int layer_end, const sitk_wgrad_desc* embed,
                                       void* dx_c, int* embed_done, sitk_stream_t stream) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_bwd_embed, cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, embed, dx_c, embed_done, stream);
   return sitk_encoder_bwd_extra(cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, embed, dx_c,
                                 embed_done, nullptr, 0, nullptr, stream);
 }
 
+SITK_F16_TWIN(sitk_encoder_bwd_extra)
 extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
                                       const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
                                       size_t scratch_bytes, int layer_begin, int layer_end, const sitk_wgrad_desc* embed,
                                       void* dx_c, int* embed_done, const sitk_wgrad_desc* extra, int n_extra, int* extra_done,
                                       sitk_stream_t stream) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_bwd_extra, cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, embed, dx_c, embed_done, extra, n_extra, extra_done, stream);
   if (embed_done) *embed_done = 0;
   if (extra_done) *extra_done = 0;
   SITK_TRY(check_cfg(cfg));

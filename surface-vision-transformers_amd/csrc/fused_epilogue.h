@@ -35,7 +35,7 @@ template <int TG, int TT = 2>
 SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][TT], int tid, int blk0, int R, const float* __restrict__ x,
                                    const float* __restrict__ mean, const float* __restrict__ rstd,
                                    const float* __restrict__ gamma, const float* __restrict__ dres, float* __restrict__ dx,
-                                   bf16* __restrict__ dxc, float* __restrict__ partials_block) {
+                                   h16* __restrict__ dxc, float* __restrict__ partials_block) {
   constexpr int D = FE_D;
   const int lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4, tg = wave >> 1, hh = wave & 1;
@@ -108,7 +108,7 @@ SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][TT], int tid,
   }
   // ---- stores: whole rows ----
   const __amdgpu_buffer_rsrc_t r_o = __builtin_amdgcn_make_buffer_rsrc(dx + (size_t)blk0 * D, 0, (int)(nrows * D * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(dxc ? dxc + (size_t)blk0 * D : (bf16*)dx, 0,
+  const __amdgpu_buffer_rsrc_t r_c = __builtin_amdgcn_make_buffer_rsrc(dxc ? dxc + (size_t)blk0 * D : (h16*)dx, 0,
                                                                        dxc ? (int)(nrows * D * 2) : 0, 0x00020000);
 #pragma unroll
   for (int pass = 0; pass < 2 * TT; ++pass) {
@@ -117,9 +117,9 @@ SITK_DEV void ln_bwd_rows_epilogue(char* smem, const f32x4 (&v)[6][TT], int tid,
     for (int i = 0; i < 3; ++i) {
       const int col = 4 * (j + 16 * i);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outv[pass][i]), r_o, (r * D + col) * 4, 0, 0);
-      bf16x4 ob;
+      h16x4 ob;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ob[e] = (bf16)outv[pass][i][e];
+      for (int e = 0; e < 4; ++e) ob[e] = (h16)outv[pass][i][e];
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), r_c, (r * D + col) * 2, 0, 0);   // dropped when dxc == NULL
     }
   }
@@ -190,7 +190,7 @@ template <int TG, int TT = 2>
 SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4 (&v)[6][TT], int tid, int blk0, int R,
                                     const float* __restrict__ x, const float* __restrict__ bias,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    float* __restrict__ xmid, bf16* __restrict__ h, float* __restrict__ mean,
+                                    float* __restrict__ xmid, h16* __restrict__ h, float* __restrict__ mean,
                                     float* __restrict__ rstd) {
   constexpr int D = FE_D, BLK = 16 * TT * TG;
   const int lane = tid & 63, wave = tid >> 6;
@@ -201,7 +201,7 @@ SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4
   const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)blk0 * D, 0,
                                                                        (int)(nrows * D * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t r_m = __builtin_amdgcn_make_buffer_rsrc(xmid + (size_t)blk0 * D, 0, (int)(nrows * D * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc(h ? h + (size_t)blk0 * D : (bf16*)xmid, 0,
+  const __amdgpu_buffer_rsrc_t r_h = __builtin_amdgcn_make_buffer_rsrc(h ? h + (size_t)blk0 * D : (h16*)xmid, 0,
                                                                        h ? (int)(nrows * D * 2) : 0, 0x00020000);
   f32x4 xv[2 * TT][3], bb[3], gm[3], bt[3];
 #pragma unroll
@@ -245,11 +245,11 @@ SITK_DEV void proj_residual_ln_rows(char* rowbuf_bytes, char* strip, const f32x4
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int c4 = j + 16 * i;
-      bf16x4 ob;
+      h16x4 ob;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ob[e] = (bf16)(ok ? (xm[i][e] - mu) * rs * gm[i][e] + bt[i][e] : 0.f);
+      for (int e = 0; e < 4; ++e) ob[e] = (h16)(ok ? (xm[i][e] - mu) * rs * gm[i][e] + bt[i][e] : 0.f);
       const int byte = c4 * 8;
-      *reinterpret_cast<bf16x4*>(strip + (byte >> 7) * (BLK * 128) + lds_off(r, byte & 127)) = ob;
+      *reinterpret_cast<h16x4*>(strip + (byte >> 7) * (BLK * 128) + lds_off(r, byte & 127)) = ob;
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), r_h, (r * D + 4 * c4) * 2, 0, 0);   // dropped when h == NULL
     }
     if (ok && j == 0 && mean) { mean[row] = mu; rstd[row] = rs; }

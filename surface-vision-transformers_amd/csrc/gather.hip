@@ -156,14 +156,18 @@ static int run_stage_weight(const float* w, int rows, int cols, void* wc, int ld
 
 }  // namespace sitk
 
+SITK_F16_TWIN(sitk_gather_tokens)
 extern "C" int sitk_gather_tokens(const float* x_bvc, const uint16_t* table_pv, void* tokens, int B, int n_vertices,
                                   int C, int P, int V, int ld, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_gather_tokens, x_bvc, table_pv, tokens, B, n_vertices, C, P, V, ld, dtype, stream);
   return sitk_gather_tokens_norm(x_bvc, table_pv, nullptr, nullptr, tokens, B, n_vertices, C, P, V, ld, dtype, stream);
 }
 
+SITK_F16_TWIN(sitk_gather_tokens_norm)
 extern "C" int sitk_gather_tokens_norm(const float* x_bvc, const uint16_t* table_pv, const float* mean, const float* stdv,
                                        void* tokens, int B, int n_vertices, int C, int P, int V, int ld, int dtype,
                                        sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_gather_tokens_norm, x_bvc, table_pv, mean, stdv, tokens, B, n_vertices, C, P, V, ld, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(x_bvc && table_pv && tokens, "gather_tokens: null pointer");
   SITK_REQUIRE((mean == nullptr) == (stdv == nullptr), "gather_tokens_norm: mean and std go together");
@@ -171,16 +175,18 @@ extern "C" int sitk_gather_tokens_norm(const float* x_bvc, const uint16_t* table
   SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "gather_tokens: bad shape");
   SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "gather_tokens: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return run_gather<bf16>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
+  if (dtype == SITK_H16) return run_gather<h16>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
   if (dtype == SITK_F32) return run_gather<float>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
   set_error("gather_tokens: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 
+SITK_F16_TWIN(sitk_gather_tokens_idx)
 extern "C" int sitk_gather_tokens_idx(const float* x_all, const int32_t* sample_idx, const uint16_t* table_pv, const float* mean,
                                       const float* stdv, void* tokens, const float* targets_all, float* target_out,
                                       int n_targets, int B, int n_vertices, int C, int P, int V, int ld, int dtype,
                                       sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_gather_tokens_idx, x_all, sample_idx, table_pv, mean, stdv, tokens, targets_all, target_out, n_targets, B, n_vertices, C, P, V, ld, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(x_all && sample_idx && table_pv && tokens, "gather_tokens_idx: null pointer");
   SITK_REQUIRE((mean == nullptr) == (stdv == nullptr), "gather_tokens_idx: mean and std go together");
@@ -190,49 +196,55 @@ extern "C" int sitk_gather_tokens_idx(const float* x_all, const int32_t* sample_
   SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "gather_tokens_idx: bad shape");
   SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "gather_tokens_idx: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16)
-    return run_gather<bf16>(x_all, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
+  if (dtype == SITK_H16)
+    return run_gather<h16>(x_all, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
   if (dtype == SITK_F32)
     return run_gather<float>(x_all, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
   set_error("gather_tokens_idx: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 
+SITK_F16_TWIN(sitk_patchify)
 extern "C" int sitk_patchify(const float* x_bcpv, void* tokens, int B, int C, int P, int V, int ld, int dtype,
                              sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_patchify, x_bcpv, tokens, B, C, P, V, ld, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(x_bcpv && tokens, "patchify: null pointer");
   SITK_REQUIRE(B > 0 && P > 0 && V > 0 && C > 0, "patchify: bad shape");
   SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "patchify: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return run_patchify<bf16>(x_bcpv, tokens, B, C, P, V, ld, s);
+  if (dtype == SITK_H16) return run_patchify<h16>(x_bcpv, tokens, B, C, P, V, ld, s);
   if (dtype == SITK_F32) return run_patchify<float>(x_bcpv, tokens, B, C, P, V, ld, s);
   set_error("patchify: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 
+SITK_F16_TWIN(sitk_cast_rows)
 extern "C" int sitk_cast_rows(const float* src, int lds_, void* dst, int ldd, int64_t rows, int cols, int dtype,
                               sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_cast_rows, src, lds_, dst, ldd, rows, cols, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(src && dst && rows > 0 && cols > 0, "cast_rows: bad arguments");
   SITK_REQUIRE(ldd >= cols && ldd % 4 == 0, "cast_rows: ldd=%d must be >= cols=%d and a multiple of 4", ldd, cols);
   SITK_REQUIRE(lds_ % 4 == 0, "cast_rows: source leading dim must be a multiple of 4");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return run_cast_rows<bf16>(src, lds_, dst, ldd, rows, cols, s);
+  if (dtype == SITK_H16) return run_cast_rows<h16>(src, lds_, dst, ldd, rows, cols, s);
   if (dtype == SITK_F32) return run_cast_rows<float>(src, lds_, dst, ldd, rows, cols, s);
   set_error("cast_rows: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 
+SITK_F16_TWIN(sitk_stage_weight)
 extern "C" int sitk_stage_weight(const float* w, int rows, int cols, void* w_c, int ldc, void* w_t, int ldt, int dtype,
                                  sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_stage_weight, w, rows, cols, w_c, ldc, w_t, ldt, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(w && rows > 0 && cols > 0, "stage_weight: bad arguments");
   SITK_REQUIRE(!w_c || (ldc >= cols && ldc % 8 == 0), "stage_weight: ldc=%d", ldc);
   SITK_REQUIRE(!w_t || (ldt >= rows && ldt % 8 == 0), "stage_weight: ldt=%d", ldt);
   SITK_REQUIRE(cols % 4 == 0, "stage_weight: cols %% 4 required");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return run_stage_weight<bf16>(w, rows, cols, w_c, ldc, w_t, ldt, s);
+  if (dtype == SITK_H16) return run_stage_weight<h16>(w, rows, cols, w_c, ldc, w_t, ldt, s);
   if (dtype == SITK_F32) return run_stage_weight<float>(w, rows, cols, w_c, ldc, w_t, ldt, s);
   set_error("stage_weight: bad dtype %d", dtype);
   return SITK_ERR_INVALID;

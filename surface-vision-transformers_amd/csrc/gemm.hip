@@ -302,7 +302,7 @@ constexpr int wres_slot_bytes() {
 // budget allows: 4 waves per SIMD hide the DMA / epilogue latencies of one another).
 template <typename TO, int EPI, int BN, int KT, int WAVES, int MT>
 __global__ __launch_bounds__(WAVES * 64) void gemm_nt_wres_kernel(GemmParams p, int groups) {
-  using T = bf16;
+  using T = h16;
   constexpr int NT = BN / 16;                 // MFMA column tiles per strip
   constexpr int ROWS = 16 * MT;               // tokens per strip
   constexpr int PPP = ROWS / 8;               // 8-row DMA pieces per 128-byte panel of a strip
@@ -424,7 +424,7 @@ __device__ unsigned long long g_n192_stamps[16 * 8];      // diagnostic build: [
 #endif
 template <typename TO, int EPI, int WM, int NSTG = 4, int MINW = 1>
 __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams p) {
-  using T = bf16;
+  using T = h16;
 #ifdef SITK_N192_STAMPS
   unsigned long long nst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntp = __builtin_amdgcn_s_memtime();
   const unsigned long long nt0 = ntp;
@@ -600,7 +600,7 @@ static int launch_gemm_nt_wres(const GemmParams& p, hipStream_t s) {
 
 template <typename T, typename TA, typename TO, int EPI>
 static int launch_gemm_nt(const GemmParams& p, hipStream_t s) {
-  if constexpr (std::is_same<T, bf16>::value && std::is_same<TA, bf16>::value) {
+  if constexpr (std::is_same<T, h16>::value && std::is_same<TA, h16>::value) {
     // weight-resident streaming kernel: K up to 192, 16-byte aligned rows, enough tokens to stream
     if (p.K <= 192 && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.M >= 1024 && p.N % 8 == 0 &&
         (sizeof(TO) == 4 || p.ldo % 8 == 0))
@@ -687,7 +687,7 @@ template <typename T>
 struct TrFrag;
 
 template <>
-struct TrFrag<bf16> {
+struct TrFrag<h16> {
   // tile: [rows][128 B] image of bf16; block columns c0..c0+15 (c0 multiple of 16, < 64);
   // rows r0 + 8*(lane>>4) + {0..3} -> elements 0..3 and + {4..7} -> elements 4..7   (natural k order)
   static SITK_DEV u32x4 load_k8(const char* tile, int r0, int c0, int lane) {
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(WgGroup grp) {
 }
 
 static bool wgrad_fast_ok(const sitk_wgrad_desc* d, int dtype) {
-  const int epv = dtype == SITK_BF16 ? 8 : 4;
+  const int epv = dtype == SITK_H16 ? 8 : 4;
   return !(d->dy_is_f32 && dtype != SITK_F32) && d->N % epv == 0 && d->K % epv == 0 && d->lddy % epv == 0 &&
          d->ldx % epv == 0;
 }
@@ -1104,7 +1104,9 @@ static int launch_wgrad_group(const sitk_wgrad_desc* d, int count, hipStream_t s
 
 }  // namespace sitk
 
+SITK_F16_TWIN(sitk_gemm_wgrad_group)
 extern "C" int sitk_gemm_wgrad_group(const sitk_wgrad_desc* d, int count, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_gemm_wgrad_group, d, count, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(d != nullptr && count >= 1 && count <= WG_MAX_PROBLEMS, "gemm_wgrad_group: 1..%d problems", WG_MAX_PROBLEMS);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1117,13 +1119,15 @@ extern "C" int sitk_gemm_wgrad_group(const sitk_wgrad_desc* d, int count, int dt
     for (int i = 0; i < count; ++i) SITK_TRY(sitk_gemm_wgrad(&d[i], dtype, stream));
     return SITK_OK;
   }
-  if (dtype == SITK_BF16) return launch_wgrad_group<bf16>(d, count, s);
+  if (dtype == SITK_H16) return launch_wgrad_group<h16>(d, count, s);
   if (dtype == SITK_F32) return launch_wgrad_group<float>(d, count, s);
   set_error("gemm_wgrad_group: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 
+SITK_F16_TWIN(sitk_gemm_nt)
 extern "C" int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_gemm_nt, d, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(d != nullptr, "gemm_nt: null descriptor");
   SITK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: empty problem %d %d %d", d->M, d->N, d->K);
@@ -1135,13 +1139,15 @@ extern "C" int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t st
   }
   SITK_REQUIRE(d->A && d->W && d->out, "gemm_nt: null operand");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return dispatch_gemm_nt<bf16>(d, s);
+  if (dtype == SITK_H16) return dispatch_gemm_nt<h16>(d, s);
   if (dtype == SITK_F32) return dispatch_gemm_nt<float>(d, s);
   set_error("gemm_nt: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
 
+SITK_F16_TWIN(sitk_gemm_wgrad)
 extern "C" int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_gemm_wgrad, d, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(d != nullptr, "gemm_wgrad: null descriptor");
   SITK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gemm_wgrad: empty problem");
@@ -1150,7 +1156,7 @@ extern "C" int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_
   SITK_REQUIRE(d->dY && d->X && d->dW, "gemm_wgrad: null operand");
   if (wgrad_fast_ok(d, dtype)) return sitk_gemm_wgrad_group(d, 1, dtype, stream);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return dispatch_wgrad<bf16>(d, s);
+  if (dtype == SITK_H16) return dispatch_wgrad<h16>(d, s);
   if (dtype == SITK_F32) return dispatch_wgrad<float>(d, s);
   set_error("gemm_wgrad: bad dtype %d", dtype);
   return SITK_ERR_INVALID;

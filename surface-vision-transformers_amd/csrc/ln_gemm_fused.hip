@@ -27,14 +27,14 @@ struct LnGemmParams {
   const float* x;      // (R,192) layer input            | same (saved)
   const float* gamma;  // LayerNorm weight
   const float* beta;   // LayerNorm bias                  | unused
-  const bf16* w;       // W (N,192), N = 3 heads 64       | W^T (192,N)
-  bf16* h;             // (R,192) LN output, saved        | unused
+  const h16* w;       // W (N,192), N = 3 heads 64       | W^T (192,N)
+  h16* h;             // (R,192) LN output, saved        | unused
   float* mean;         // (R) written                     | read
   float* rstd;
-  bf16* y;             // (R,N) written                   | dy (R,N) read
+  h16* y;             // (R,N) written                   | dy (R,N) read
   const float* dres;   // -                               | (R,192) fp32 residual gradient added to LN'(dh)
   float* dx;           // -                               | (R,192) fp32
-  bf16* dxc;           // -                               | (R,192) compute-dtype copy of dx
+  h16* dxc;           // -                               | (R,192) compute-dtype copy of dx
   float* partials;     // -                               | (gridDim.x, 2, 192)
   int R, N;
 };
@@ -45,9 +45,9 @@ constexpr int LG_OFF_H = 2 * LG_WB;            // forward: operand strip 3 k-pan
 constexpr int LG_SMEM_FWD = LG_OFF_H + 3 * 128 * 128;   // (TG = 4; TG = 3 uses the first 3 x 96 rows of every panel)
 constexpr int LG_SMEM_BWD = FE_SMEM_BYTES > 8 * 12288 ? FE_SMEM_BYTES : 8 * 12288;   // exchange area / row-layout epilogue
 
-SITK_DEV uint32_t lg_pack_bf16(float a, float b) {
-  bf16x2 v;
-  v[0] = (bf16)a; v[1] = (bf16)b;
+SITK_DEV uint32_t lg_pack_h16(float a, float b) {
+  h16x2 v;
+  v[0] = (h16)a; v[1] = (h16)b;
   return __builtin_bit_cast(uint32_t, v);
 }
 SITK_DEV __amdgpu_buffer_rsrc_t lg_rsrc(const void* p, size_t bytes) {
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_fwd_kernel(LnGemmParams p) {
   }
   auto issue = [&](int c, int buf) {
     char* base = smem + buf * LG_WB + wave * PPW * 1024;
-    const bf16* src = p.w + (size_t)c * 64 * D;
+    const h16* src = p.w + (size_t)c * 64 * D;
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_fwd_kernel(LnGemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = ok ? (v[pass][i][e] - mu) * rs * gm[i][e] + bt[i][e] : 0.f;
         const int byte = c4 * 8;
-        const u32x2 ob = {lg_pack_bf16(o[0], o[1]), lg_pack_bf16(o[2], o[3])};
+        const u32x2 ob = {lg_pack_h16(o[0], o[1]), lg_pack_h16(o[2], o[3])};
         *reinterpret_cast<u32x2*>(sH + (byte >> 7) * (BLK * 128) + lds_off(r, byte & 127)) = ob;
         if (p.h) __builtin_amdgcn_raw_buffer_store_b64(ob, r_h, (r * D + 4 * c4) * 2, 0, 0);
       }
@@ -202,14 +202,14 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_fwd_kernel(LnGemmParams p) {
     for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #define SITK_LG_MMAS(KT, f0, f1, f2, f3)                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    acc[0][0] = Mma<bf16>::mma(f0, hf[0][2 * KT], acc[0][0]);                                               \
-    acc[0][1] = Mma<bf16>::mma(f0, hf[1][2 * KT], acc[0][1]);                                               \
-    acc[1][0] = Mma<bf16>::mma(f1, hf[0][2 * KT], acc[1][0]);                                               \
-    acc[1][1] = Mma<bf16>::mma(f1, hf[1][2 * KT], acc[1][1]);                                               \
-    acc[0][0] = Mma<bf16>::mma(f2, hf[0][2 * KT + 1], acc[0][0]);                                           \
-    acc[0][1] = Mma<bf16>::mma(f2, hf[1][2 * KT + 1], acc[0][1]);                                           \
-    acc[1][0] = Mma<bf16>::mma(f3, hf[0][2 * KT + 1], acc[1][0]);                                           \
-    acc[1][1] = Mma<bf16>::mma(f3, hf[1][2 * KT + 1], acc[1][1]);                                           \
+    acc[0][0] = Mma<h16>::mma(f0, hf[0][2 * KT], acc[0][0]);                                               \
+    acc[0][1] = Mma<h16>::mma(f0, hf[1][2 * KT], acc[0][1]);                                               \
+    acc[1][0] = Mma<h16>::mma(f1, hf[0][2 * KT], acc[1][0]);                                               \
+    acc[1][1] = Mma<h16>::mma(f1, hf[1][2 * KT], acc[1][1]);                                               \
+    acc[0][0] = Mma<h16>::mma(f2, hf[0][2 * KT + 1], acc[0][0]);                                           \
+    acc[0][1] = Mma<h16>::mma(f2, hf[1][2 * KT + 1], acc[0][1]);                                           \
+    acc[1][0] = Mma<h16>::mma(f3, hf[0][2 * KT + 1], acc[1][0]);                                           \
+    acc[1][1] = Mma<h16>::mma(f3, hf[1][2 * KT + 1], acc[1][1]);                                           \
     __builtin_amdgcn_sched_barrier(0);
     SITK_LG_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a0, a1, 8192, 10240, 8192, 10240);
     SITK_LG_MMAS(0, x0, x1, x2, x3)
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_fwd_kernel(LnGemmParams p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const f32x4 v0 = acc[0][t], v1 = acc[1][t];
-      sd[t] = u32x4{lg_pack_bf16(v0[0], v0[1]), lg_pack_bf16(v0[2], v0[3]), lg_pack_bf16(v1[0], v1[1]), lg_pack_bf16(v1[2], v1[3])};
+      sd[t] = u32x4{lg_pack_h16(v0[0], v0[1]), lg_pack_h16(v0[2], v0[3]), lg_pack_h16(v1[0], v1[1]), lg_pack_h16(v1[2], v1[3])};
       __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_y, vo[t], c * 128, 0);
     }
     asm volatile("" : : "v"(sd[0]), "v"(sd[1]));             // store keep-alive (mlp_fused.hip)
@@ -265,9 +265,9 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
 
   // ---- DMA pieces of one chunk: 24 of W^T (192 rows x 128 B) + BLK / 8 of dy (BLK rows x 128 B); PPW per wave ----
   const int r8 = lane >> 3;
-  const bf16* psrc[PPW];
+  const h16* psrc[PPW];
   int pdst[PPW];
-  const bf16* zerop = reinterpret_cast<const bf16*>(g_zero_page_lg);
+  const h16* zerop = reinterpret_cast<const h16*>(g_zero_page_lg);
 #pragma unroll
   for (int i = 0; i < PPW; ++i) {
     const int q = wave * PPW + i;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
     char* base = smem + (c % LG_BWD_SLOTS) * SLOT;
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-      const bf16* src = psrc[i] ? psrc[i] + (size_t)c * 64 : zerop;
+      const h16* src = psrc[i] ? psrc[i] + (size_t)c * 64 : zerop;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(base + pdst[i]), 16, 0, 0);
     }
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
                    : "memory");
 #define SITK_LG_MMAS2(J, f0, f1, f2, f3)                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 0][t] = Mma<bf16>::mma(f0, pf[t], yacc[4 * J + 0][t]); \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 1][t] = Mma<bf16>::mma(f1, pf[t], yacc[4 * J + 1][t]); \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 2][t] = Mma<bf16>::mma(f2, pf[t], yacc[4 * J + 2][t]); \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 3][t] = Mma<bf16>::mma(f3, pf[t], yacc[4 * J + 3][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 0][t] = Mma<h16>::mma(f0, pf[t], yacc[4 * J + 0][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 1][t] = Mma<h16>::mma(f1, pf[t], yacc[4 * J + 1][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 2][t] = Mma<h16>::mma(f2, pf[t], yacc[4 * J + 2][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 3][t] = Mma<h16>::mma(f3, pf[t], yacc[4 * J + 3][t]); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TT == 2)
       asm volatile("s_waitcnt lgkmcnt(0)\n\t"
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(128 * TG) void ln_gemm_bwd_kernel(LnGemmParams p) {
 }
 
 static int lg_check(const char* what, int64_t rows, int D, int N, int dtype) {
-  SITK_REQUIRE(dtype == SITK_BF16 && D == LG_D && N % 64 == 0 && N >= 64 && rows > 0 && rows * (int64_t)N < (1ll << 30),
-               "%s: the fused path is specialised for bf16, dim 192, N %% 64 == 0 (got dtype %d dim %d N %d)", what, dtype, D, N);
+  SITK_REQUIRE(dtype == SITK_H16 && D == LG_D && N % 64 == 0 && N >= 64 && rows > 0 && rows * (int64_t)N < (1ll << 30),
+               "%s: the fused path is specialised for h16, dim 192, N %% 64 == 0 (got dtype %d dim %d N %d)", what, dtype, D, N);
   return SITK_OK;
 }
 
@@ -403,18 +403,22 @@ extern "C" int sitk_lg_debug_stamps(unsigned long long* out) {
 }
 #endif
 
+SITK_F16_TWIN(sitk_ln_gemm_fused_supported)
 extern "C" int sitk_ln_gemm_fused_supported(int D, int N, int dtype) {
-  return dtype == SITK_BF16 && D == LG_D && N % 64 == 0 && N >= 64;
+  SITK_FORWARD_F16(dtype, sitk_ln_gemm_fused_supported, D, N, dtype);
+  return dtype == SITK_H16 && D == LG_D && N % 64 == 0 && N >= 64;
 }
 
+SITK_F16_TWIN(sitk_ln_gemm_fwd)
 extern "C" int sitk_ln_gemm_fwd(const float* x, const float* ln_w, const float* ln_b, const void* w_c, void* h, float* mean,
                                 float* rstd, void* y, int64_t rows, int D, int N, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_ln_gemm_fwd, x, ln_w, ln_b, w_c, h, mean, rstd, y, rows, D, N, dtype, stream);
   SITK_REQUIRE(x && ln_w && ln_b && w_c && y, "ln_gemm_fwd: null pointer");
   SITK_REQUIRE((mean == nullptr) == (rstd == nullptr), "ln_gemm_fwd: mean and rstd go together");
   SITK_TRY(lg_check("ln_gemm_fwd", rows, D, N, dtype));
   LnGemmParams p = {};
-  p.x = x; p.gamma = ln_w; p.beta = ln_b; p.w = reinterpret_cast<const bf16*>(w_c);
-  p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd; p.y = reinterpret_cast<bf16*>(y);
+  p.x = x; p.gamma = ln_w; p.beta = ln_b; p.w = reinterpret_cast<const h16*>(w_c);
+  p.h = reinterpret_cast<h16*>(h); p.mean = mean; p.rstd = rstd; p.y = reinterpret_cast<h16*>(y);
   p.R = (int)rows; p.N = N;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   if (fused_block_rows(rows) == 96) hipLaunchKernelGGL(ln_gemm_fwd_kernel<3>, dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
@@ -426,16 +430,18 @@ extern "C" size_t sitk_ln_gemm_bwd_partial_floats(int64_t rows) {
   return rows > 0 ? (size_t)cdiv64(rows, fused_block_rows(rows)) * 2 * LG_D : 0;
 }
 
+SITK_F16_TWIN(sitk_ln_gemm_bwd)
 extern "C" int sitk_ln_gemm_bwd(const void* dy, const void* wt_c, const float* x, const float* mean, const float* rstd,
                                 const float* ln_w, const float* dres, float* dx, void* dx_c, float* partials, int64_t rows,
                                 int D, int N, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_ln_gemm_bwd, dy, wt_c, x, mean, rstd, ln_w, dres, dx, dx_c, partials, rows, D, N, dtype, stream);
   SITK_REQUIRE(dy && wt_c && x && mean && rstd && ln_w && dx && partials, "ln_gemm_bwd: null pointer");
   SITK_TRY(lg_check("ln_gemm_bwd", rows, D, N, dtype));
   LnGemmParams p = {};
-  p.x = x; p.gamma = ln_w; p.w = reinterpret_cast<const bf16*>(wt_c);
+  p.x = x; p.gamma = ln_w; p.w = reinterpret_cast<const h16*>(wt_c);
   p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
-  p.y = const_cast<bf16*>(reinterpret_cast<const bf16*>(dy));
-  p.dres = dres; p.dx = dx; p.dxc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
+  p.y = const_cast<h16*>(reinterpret_cast<const h16*>(dy));
+  p.dres = dres; p.dx = dx; p.dxc = reinterpret_cast<h16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.N = N;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   static const int tt1 = sitk_ab_switch("SITK_LG_TT1", 1);   // 12 waves x 16 tokens; 0: the 6 x 32 variant (A/B)

@@ -77,14 +77,15 @@ __global__ __launch_bounds__(64) void head_fwd_kernel(const float* __restrict__ 
 // terms in its own row [d_b (C) | d_w (C D) | d_ln_w (D) | d_ln_b (D) | loss (1)] and head_finalize_kernel adds the rows
 // in sample order: bitwise reproducible.  Without one the terms go straight to the gradients as float atomics (their
 // sum then depends on arrival order in the last bits).
-SITK_DEV int head_ws_width(int D, int C) { return C + C * D + 2 * D + 1; }
+SITK_DEV int head_ws_sums(int D, int C) { return C + C * D + 2 * D + 1; }      // columns the finalize kernel adds up
+SITK_DEV int head_ws_width(int D, int C) { return head_ws_sums(D, C) + C; }   // + the sample's raw d loss / d logits
 struct HeadWs {
-  float *db, *dw, *dlw, *dlb, *loss;
+  float *db, *dw, *dlw, *dlb, *loss, *raw;
   bool on;
   SITK_DEV HeadWs(float* ws, int b, int D, int C) {
     on = ws != nullptr;
     float* row = ws + (size_t)b * head_ws_width(D, C);
-    db = row; dw = row + C; dlw = dw + (size_t)C * D; dlb = dlw + D; loss = dlb + D;
+    db = row; dw = row + C; dlw = dw + (size_t)C * D; dlb = dlw + D; loss = dlb + D; raw = loss + 1;
   }
   SITK_DEV void add(float* slot, float* grad, float v) const {
     if (on) *slot = v;
@@ -96,14 +97,14 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restr
                                                             float* __restrict__ d_b, float* __restrict__ d_w,
                                                             float* __restrict__ d_ln_w, float* __restrict__ d_ln_b,
                                                             float* __restrict__ loss) {
-  const int W = head_ws_width(D, C), c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= W) return;
+  const int W = head_ws_width(D, C), WS = head_ws_sums(D, C), c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= WS) return;
   float s = 0.f;
   for (int b = 0; b < B; ++b) s += ws[(size_t)b * W + c];          // fixed order
   if (c < C) d_b[c] += s;
   else if (c < C + C * D) d_w[c - C] += s;
   else if (c < C + C * D + D) d_ln_w[c - C - C * D] += s;
-  else if (c < W - 1) d_ln_b[c - C - C * D - D] += s;
+  else if (c < WS - 1) d_ln_b[c - C - C * D - D] += s;
   else if (loss) *loss += s;
 }
 
@@ -177,6 +178,13 @@ __global__ __launch_bounds__(256) void head_spread_kernel(float* __restrict__ dx
 // for its sample -- the loss gradient of a sample depends on no other sample, only the scalar loss is a sum (one atomic
 // per sample) -- then all four waves write the sample's rows 1..N-1 of dx (zeros, or copies of row 0 for mean pooling).
 // Replaces 4 dependent launches (head_fwd, loss, head_bwd, head_spread) of ~5-9 us each.
+// MODE 0: everything in one pass, gradients unscaled.  MODE 1 + MODE 2 (two launches) = the same with every gradient the
+// step produces multiplied by a power of two S chosen from THIS batch (f16 compute mode: the narrow exponent of the
+// 16-bit gradient operands): pass 1 = forward, loss and the raw d loss / d logits of every sample (stored in the workspace
+// rows); pass 2 = backward, where every workgroup first takes the batch maximum of |d loss / d logits| from those rows --
+// the same B x C values for everybody, no atomics --, sets S = 2^k with max * S in [64, 128) and scales its sample's loss
+// gradient by it; block (0, 0) publishes {S, 1 / S} for the optimizer.  The loss itself is never scaled.
+template <int MODE>
 __global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __restrict__ x, const float* __restrict__ ln_w,
                                                               const float* __restrict__ ln_b, const float* __restrict__ w,
                                                               const float* __restrict__ bias, const float* __restrict__ target,
@@ -184,7 +192,8 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __res
                                                               float* __restrict__ dx, float* __restrict__ d_ln_w,
                                                               float* __restrict__ d_ln_b, float* __restrict__ d_w,
                                                               float* __restrict__ d_b, int B, int N, int D, int n_classes,
-                                                              int pool_mean, int l1, float* __restrict__ ws) {
+                                                              int pool_mean, int l1, float* __restrict__ ws,
+                                                              float* __restrict__ gscale) {
   // grid (B, S): slice y of sample b writes its share of the rows 1..N-1; slice 0 also does the head itself.  Mean pooling
   // copies row 0, which slice 0 produces: S = 1 then (chosen by the launcher).
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -197,22 +206,39 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < HEAD_NV; ++i) { v[i] = (v[i] - mu) * rs; dh[i] = 0.f; }  // xhat
     const float inv = 1.0f / (float)(B * n_classes);
-    float lsum = 0.f;
+    float lsum = 0.f, gs = 1.0f;
+    if constexpr (MODE == 2) {
+      float m = 0.f;
+      const int W = head_ws_width(D, n_classes), raw0 = head_ws_sums(D, n_classes);
+      for (int i = lane; i < B * n_classes; i += 64) m = fmaxf(m, fabsf(ws[(size_t)(i / n_classes) * W + raw0 + i % n_classes]));
+      m = wave_max(m);
+      const int ef = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 0xffu);     // m = f 2^(ef - 126), f in [0.5, 1)
+      if (ef > 0 && ef < 255) gs = __builtin_bit_cast(float, (uint32_t)min(max(260 - ef, 1), 254) << 23);   // 2^(7 - (ef - 126))
+      if (b == 0 && lane == 0) { gscale[0] = gs; gscale[1] = 1.0f / gs; }
+    }
     for (int c = 0; c < n_classes; ++c) {
-      float sacc = 0.f;
+      float dl;
+      if constexpr (MODE == 2) {
+        dl = hw.raw[c] * gs;
+        if (lane == 0) hw.add(hw.db + c, d_b + c, dl);
+      } else {
+        float sacc = 0.f;
 #pragma unroll
-      for (int i = 0; i < HEAD_NV; ++i) {
-        const int d = lane + 64 * i;
-        if (d < D) sacc += (v[i] * ln_w[d] + ln_b[d]) * w[(size_t)c * D + d];
+        for (int i = 0; i < HEAD_NV; ++i) {
+          const int d = lane + 64 * i;
+          if (d < D) sacc += (v[i] * ln_w[d] + ln_b[d]) * w[(size_t)c * D + d];
+        }
+        const float logit = wave_sum(sacc) + bias[c];
+        const float df = logit - target[(size_t)b * n_classes + c];
+        dl = l1 ? (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv : 2.f * df * inv;
+        lsum += l1 ? fabsf(df) : df * df;
+        if (lane == 0) {
+          logits[(size_t)b * n_classes + c] = logit;
+          if constexpr (MODE == 1) hw.raw[c] = dl;
+          else hw.add(hw.db + c, d_b + c, dl);
+        }
       }
-      const float logit = wave_sum(sacc) + bias[c];
-      const float df = logit - target[(size_t)b * n_classes + c];
-      const float dl = l1 ? (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv : 2.f * df * inv;
-      lsum += l1 ? fabsf(df) : df * df;
-      if (lane == 0) {
-        logits[(size_t)b * n_classes + c] = logit;
-        hw.add(hw.db + c, d_b + c, dl);
-      }
+      if constexpr (MODE == 1) continue;
 #pragma unroll
       for (int i = 0; i < HEAD_NV; ++i) {
         const int d = lane + 64 * i;
@@ -222,28 +248,31 @@ __global__ __launch_bounds__(256) void head_loss_fused_kernel(const float* __res
         }
       }
     }
-    if (lane == 0) hw.add(hw.loss, loss, lsum * inv);
-    float s1 = 0.f, s2 = 0.f;
+    if constexpr (MODE != 2) { if (lane == 0) hw.add(hw.loss, loss, lsum * inv); }
+    if constexpr (MODE != 1) {
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < HEAD_NV; ++i) {
-      const int d = lane + 64 * i;
-      if (d < D) {
-        hw.add(hw.dlw + d, d_ln_w + d, dh[i] * v[i]);
-        hw.add(hw.dlb + d, d_ln_b + d, dh[i]);
-        dh[i] *= ln_w[d];
-        s1 += dh[i];
-        s2 += dh[i] * v[i];
+      for (int i = 0; i < HEAD_NV; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) {
+          hw.add(hw.dlw + d, d_ln_w + d, dh[i] * v[i]);
+          hw.add(hw.dlb + d, d_ln_b + d, dh[i]);
+          dh[i] *= ln_w[d];
+          s1 += dh[i];
+          s2 += dh[i] * v[i];
+        }
+      }
+      s1 = wave_sum(s1) / (float)D;
+      s2 = wave_sum(s2) / (float)D;
+      const float post = pool_mean ? 1.0f / (float)N : 1.0f;
+#pragma unroll
+      for (int i = 0; i < HEAD_NV; ++i) {
+        const int d = lane + 64 * i;
+        if (d < D) dx[(size_t)b * N * D + d] = rs * (dh[i] - s1 - v[i] * s2) * post;
       }
     }
-    s1 = wave_sum(s1) / (float)D;
-    s2 = wave_sum(s2) / (float)D;
-    const float post = pool_mean ? 1.0f / (float)N : 1.0f;
-#pragma unroll
-    for (int i = 0; i < HEAD_NV; ++i) {
-      const int d = lane + 64 * i;
-      if (d < D) dx[(size_t)b * N * D + d] = rs * (dh[i] - s1 - v[i] * s2) * post;
-    }
   }
+  if constexpr (MODE == 1) return;
   if (pool_mean) __syncthreads();                        // row 0 is copied below (same workgroup: visible after the barrier)
   const int nvec = D >> 2;
   float* dxb = dx + (size_t)b * N * D;
@@ -457,7 +486,8 @@ __global__ __launch_bounds__(256) void mpp_loss_kernel(const float* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void mpp_loss_ld_kernel(const float* __restrict__ out, int ldo, const float* __restrict__ tokens,
                                                           int ldt, const uint8_t* __restrict__ masked, float* __restrict__ loss,
-                                                          T* __restrict__ dout, int lddo, int64_t rows, int K, float inv_count) {
+                                                          T* __restrict__ dout, int lddo, int64_t rows, int K, float inv_count,
+                                                          float grad_scale) {
   __shared__ float red[4];
   const int nvec = K >> 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -483,7 +513,7 @@ __global__ __launch_bounds__(256) void mpp_loss_ld_kernel(const float* __restric
         if (c < nvec) {
           const f32x4 d = a[j] - b[j];                         // 0 for unmasked rows
           s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
-          store4(pd + 4 * c, d * (2.f * inv_count));
+          store4(pd + 4 * c, d * (2.f * inv_count * grad_scale));
         }
       }
     }
@@ -544,7 +574,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 __global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                                                       int64_t n, const double* __restrict__ state, float momentum, float wd,
                                                       int nesterov, float gscale, int zero, int64_t n_extra, int64_t keep_idx,
-                                                      float* __restrict__ keep_dst) {
+                                                      float* __restrict__ keep_dst, const float* __restrict__ inv_gscale) {
+  if (inv_gscale) gscale *= inv_gscale[0];               // the step's loss scale (f16 compute mode), undone here
   const float lr = (float)state[0];
   const int64_t nvec = n >> 2;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -586,7 +617,9 @@ __global__ void adam_advance_kernel(double* state, double b1, double b2) {
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, int64_t n, const double* __restrict__ state,
                                                        float b1, float b2, float eps, float wd, int decoupled, float gscale,
-                                                       int zero, int64_t n_extra, int64_t keep_idx, float* __restrict__ keep_dst) {
+                                                       int zero, int64_t n_extra, int64_t keep_idx, float* __restrict__ keep_dst,
+                                                       const float* __restrict__ inv_gscale) {
+  if (inv_gscale) gscale *= inv_gscale[0];               // the step's loss scale (f16 compute mode), undone here
   const float lr = (float)state[0];
   const float bc1 = (float)(1.0 - state[1]), bc2_sqrt = (float)sqrt(1.0 - state[2]);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -615,7 +648,7 @@ static int grid_for(int64_t work, int per_block, int cap) {
 }  // namespace sitk
 
 extern "C" size_t sitk_head_ws_floats(int B, int D, int n_classes) {
-  return B > 0 && D > 0 && n_classes > 0 ? (size_t)B * ((size_t)n_classes + (size_t)n_classes * D + 2 * (size_t)D + 1) : 0;
+  return B > 0 && D > 0 && n_classes > 0 ? (size_t)B * (2 * (size_t)n_classes + (size_t)n_classes * D + 2 * (size_t)D + 1) : 0;
 }
 
 extern "C" int sitk_head_fwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
@@ -663,15 +696,24 @@ extern "C" int sitk_embed_cls_rows(float* x, const float* cls_token, const float
 extern "C" int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
                                       const float* target, float* logits, float* loss, float* dx, float* d_ln_w,
                                       float* d_ln_b, float* d_w, float* d_b, int B, int N, int D, int n_classes,
-                                      int pool_mean, int l1, float* ws, sitk_stream_t stream) {
+                                      int pool_mean, int l1, float* ws, float* grad_scale, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(x && ln_w && ln_b && w && b && target && logits && loss && dx && d_ln_w && d_ln_b && d_w && d_b,
                "head_loss_fwd_bwd: null pointer");
   SITK_REQUIRE(B > 0 && N > 0 && D > 0 && D <= HEAD_MAXD && D % 4 == 0 && n_classes > 0, "head_loss_fwd_bwd: bad shape");
   const int slices = pool_mean ? 1 : std::max(1, std::min(8, 512 / B));      // fill the chip with the row writes
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(head_loss_fused_kernel, dim3(B, slices), dim3(256), 0, s, x, ln_w, ln_b, w, b,
-                     target, logits, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1, ws);
+  SITK_REQUIRE(!grad_scale || ws, "head_loss_fwd_bwd: the scaled form needs the workspace");
+  if (grad_scale) {
+    hipLaunchKernelGGL(head_loss_fused_kernel<1>, dim3(B, 1), dim3(64), 0, s, x, ln_w, ln_b, w, b, target, logits, loss, dx, d_ln_w,
+                       d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1, ws, grad_scale);
+    SITK_LAUNCH_CHECK("head_loss_fwd");
+    hipLaunchKernelGGL(head_loss_fused_kernel<2>, dim3(B, slices), dim3(256), 0, s, x, ln_w, ln_b, w, b, target, logits, loss, dx,
+                       d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1, ws, grad_scale);
+  } else {
+    hipLaunchKernelGGL(head_loss_fused_kernel<0>, dim3(B, slices), dim3(256), 0, s, x, ln_w, ln_b, w, b, target, logits, loss, dx,
+                       d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1, ws, grad_scale);
+  }
   SITK_LAUNCH_CHECK("head_loss_fwd_bwd");
   if (ws) {
     hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 256)), dim3(256), 0, s, ws, B, D,
@@ -689,9 +731,11 @@ extern "C" int sitk_loss_fwd_bwd(const float* pred, const float* target, float* 
   return check_launch("loss_fwd_bwd");
 }
 
+SITK_F16_TWIN(sitk_mpp_corrupt)
 extern "C" int sitk_mpp_corrupt(const float* tokens, const uint8_t* masked, const uint8_t* swap_draw,
                                 const int32_t* random_patches, const uint8_t* replace_draw, const float* mask_token,
                                 void* corrupted, int B, int P, int K, int ld, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_mpp_corrupt, tokens, masked, swap_draw, random_patches, replace_draw, mask_token, corrupted, B, P, K, ld, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(tokens && masked && replace_draw && mask_token && corrupted, "mpp_corrupt: null pointer");
   SITK_REQUIRE((swap_draw == nullptr) == (random_patches == nullptr), "mpp_corrupt: swap_draw and random_patches go together");
@@ -699,9 +743,9 @@ extern "C" int sitk_mpp_corrupt(const float* tokens, const uint8_t* masked, cons
   const int64_t rows = (int64_t)B * P;
   dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16)
-    hipLaunchKernelGGL((mpp_corrupt_kernel<bf16>), grid, dim3(256), 0, s, tokens, masked, swap_draw, random_patches,
-                       replace_draw, mask_token, reinterpret_cast<bf16*>(corrupted), rows, P, K, ld);
+  if (dtype == SITK_H16)
+    hipLaunchKernelGGL((mpp_corrupt_kernel<h16>), grid, dim3(256), 0, s, tokens, masked, swap_draw, random_patches,
+                       replace_draw, mask_token, reinterpret_cast<h16*>(corrupted), rows, P, K, ld);
   else if (dtype == SITK_F32)
     hipLaunchKernelGGL((mpp_corrupt_kernel<float>), grid, dim3(256), 0, s, tokens, masked, swap_draw, random_patches,
                        replace_draw, mask_token, reinterpret_cast<float*>(corrupted), rows, P, K, ld);
@@ -744,27 +788,30 @@ extern "C" int sitk_adam_step(float* param, const float* grad, float* exp_avg, f
 
 extern "C" int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state,
                                  float momentum, float weight_decay, int nesterov, float grad_scale, int zero_grad,
-                                 int64_t n_extra, int64_t keep_idx, float* keep_dst, sitk_stream_t stream) {
+                                 int64_t n_extra, int64_t keep_idx, float* keep_dst, const float* inv_loss_scale,
+                                 sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(param && grad && state && n > 0 && n_extra >= 0, "sgd_step_dev: bad arguments");
   SITK_REQUIRE(momentum == 0.f || momentum_buf, "sgd_step_dev: momentum needs a buffer");
   SITK_REQUIRE(n % 4 == 0 || n_extra == 0, "sgd_step_dev: accumulators behind the gradients need n %% 4 == 0");
   hipLaunchKernelGGL(sgd_dev_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      param, grad, momentum_buf, n, state, momentum, weight_decay, nesterov, grad_scale, zero_grad, n_extra,
-                     keep_idx, keep_dst);
+                     keep_idx, keep_dst, inv_loss_scale);
   return check_launch("sgd_step_dev");
 }
 
 extern "C" int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double* state,
                                   float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, float grad_scale,
-                                  int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst, sitk_stream_t stream) {
+                                  int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst,
+                                  const float* inv_loss_scale, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && n > 0 && n_extra >= 0, "adam_step_dev: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, s, state, (double)beta1, (double)beta2);
   SITK_LAUNCH_CHECK("adam_advance");
   hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, state,
-                     beta1, beta2, eps, weight_decay, decoupled_wd, grad_scale, zero_grad, n_extra, keep_idx, keep_dst);
+                     beta1, beta2, eps, weight_decay, decoupled_wd, grad_scale, zero_grad, n_extra, keep_idx, keep_dst,
+                     inv_loss_scale);
   return check_launch("adam_step_dev");
 }
 
@@ -780,11 +827,13 @@ extern "C" int sitk_mpp_draw(const uint64_t* state, uint8_t* masked, uint8_t* sw
   return check_launch("mpp_draw");
 }
 
+SITK_F16_TWIN(sitk_mpp_gather_corrupt)
 extern "C" int sitk_mpp_gather_corrupt(const float* x, const uint16_t* table_pv, const int32_t* sample_idx, const float* mean,
                                        const float* stdv, const uint8_t* masked, const uint8_t* swap_draw,
                                        const int32_t* random_patches, const uint8_t* replace_draw, const float* mask_token,
                                        float* clean, void* corrupted, uint64_t* state, int B, int n_vertices, int C, int P, int V,
                                        int ld, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_mpp_gather_corrupt, x, table_pv, sample_idx, mean, stdv, masked, swap_draw, random_patches, replace_draw, mask_token, clean, corrupted, state, B, n_vertices, C, P, V, ld, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(x && table_pv && masked && replace_draw && mask_token && clean && corrupted, "mpp_gather_corrupt: null pointer");
   SITK_REQUIRE((swap_draw == nullptr) == (random_patches == nullptr), "mpp_gather_corrupt: swap_draw and random_patches go together");
@@ -796,9 +845,9 @@ extern "C" int sitk_mpp_gather_corrupt(const float* x, const uint16_t* table_pv,
   const int64_t rows = (int64_t)B * P;
   dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16)
-    hipLaunchKernelGGL((mpp_gather_corrupt_kernel<bf16>), grid, dim3(256), 0, s, x, table_pv, sample_idx, mean, stdv, masked, swap_draw,
-                       random_patches, replace_draw, mask_token, clean, reinterpret_cast<bf16*>(corrupted), state, rows,
+  if (dtype == SITK_H16)
+    hipLaunchKernelGGL((mpp_gather_corrupt_kernel<h16>), grid, dim3(256), 0, s, x, table_pv, sample_idx, mean, stdv, masked, swap_draw,
+                       random_patches, replace_draw, mask_token, clean, reinterpret_cast<h16*>(corrupted), state, rows,
                        n_vertices, P, V, K, ld);
   else if (dtype == SITK_F32)
     hipLaunchKernelGGL((mpp_gather_corrupt_kernel<float>), grid, dim3(256), 0, s, x, table_pv, sample_idx, mean, stdv, masked, swap_draw,
@@ -808,9 +857,11 @@ extern "C" int sitk_mpp_gather_corrupt(const float* x, const uint16_t* table_pv,
   return check_launch("mpp_gather_corrupt");
 }
 
+SITK_F16_TWIN(sitk_mpp_loss_fwd_bwd_ld)
 extern "C" int sitk_mpp_loss_fwd_bwd_ld(const float* out, int ldo, const float* tokens, int ldt, const uint8_t* masked, float* loss,
                                         void* dout, int lddo, int dout_dtype, int64_t rows, int K, int64_t n_masked_total,
-                                        sitk_stream_t stream) {
+                                        float grad_scale, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dout_dtype, sitk_mpp_loss_fwd_bwd_ld, out, ldo, tokens, ldt, masked, loss, dout, lddo, dout_dtype, rows, K, n_masked_total, grad_scale, stream);
   using namespace sitk;
   SITK_REQUIRE(out && tokens && masked && loss && dout, "mpp_loss_ld: null pointer");
   SITK_REQUIRE(rows > 0 && K > 0 && K % 4 == 0 && n_masked_total > 0 && ldo >= K && ldt >= K && lddo >= K && ldo % 4 == 0 &&
@@ -818,12 +869,12 @@ extern "C" int sitk_mpp_loss_fwd_bwd_ld(const float* out, int ldo, const float* 
   const float inv = 1.0f / ((float)n_masked_total * (float)K);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const int grid = grid_for(rows, 4, 1024);
-  if (dout_dtype == SITK_BF16)
-    hipLaunchKernelGGL((mpp_loss_ld_kernel<bf16>), dim3(grid), dim3(256), 0, s, out, ldo, tokens, ldt, masked, loss,
-                       reinterpret_cast<bf16*>(dout), lddo, rows, K, inv);
+  if (dout_dtype == SITK_H16)
+    hipLaunchKernelGGL((mpp_loss_ld_kernel<h16>), dim3(grid), dim3(256), 0, s, out, ldo, tokens, ldt, masked, loss,
+                       reinterpret_cast<h16*>(dout), lddo, rows, K, inv, grad_scale);
   else if (dout_dtype == SITK_F32)
     hipLaunchKernelGGL((mpp_loss_ld_kernel<float>), dim3(grid), dim3(256), 0, s, out, ldo, tokens, ldt, masked, loss,
-                       reinterpret_cast<float*>(dout), lddo, rows, K, inv);
+                       reinterpret_cast<float*>(dout), lddo, rows, K, inv, grad_scale);
   else { set_error("mpp_loss_ld: bad dtype %d", dout_dtype); return SITK_ERR_INVALID; }
   return check_launch("mpp_loss_ld");
 }

@@ -43,35 +43,35 @@ struct MlpParams {
   const float* x;      // (R,192) residual stream in      | x_mid saved by forward
   const float* gamma;  // LayerNorm weight
   const float* beta;   // LayerNorm bias                   | unused
-  const bf16* wa;      // W1 (M,192)                       | W2^T (M,192)
-  const bf16* wb;      // W2 (192,M)                       | W1^T (192,M)
+  const h16* wa;      // W1 (M,192)                       | W2^T (M,192)
+  const h16* wb;      // W2 (192,M)                       | W1^T (192,M)
   const float* b1;     // (M)                              | unused
   const float* b2;     // (192)                            | unused
-  bf16* h;             // (R,192) LN output, saved         | unused
+  h16* h;             // (R,192) LN output, saved         | unused
   float* mean;         // (R) written                      | read
   float* rstd;
-  bf16* u;             // (R,M) pre-activation written     | read
-  bf16* g;             // (R,M) gelu(u) written (or null)  | written (scratch for the weight gradient)
+  h16* u;             // (R,M) pre-activation written     | read
+  h16* g;             // (R,M) gelu(u) written (or null)  | written (scratch for the weight gradient)
   float* out;          // (R,192) fp32                     | dx (R,192) fp32
   // backward only
-  const bf16* dyc;     // (R,192) compute-dtype copy of dy
+  const h16* dyc;     // (R,192) compute-dtype copy of dy
   const float* dy;     // (R,192) fp32 dy (residual gradient)
-  bf16* du;            // (R,M)
-  bf16* outc;          // (R,192) compute-dtype copy of dx
+  h16* du;            // (R,M)
+  h16* outc;          // (R,192) compute-dtype copy of dx
   float* partials;     // (gridDim.x, 2, 192) dgamma / dbeta partial sums
   // forward with the attention output projection folded in (PROJ): x_mid = x + o Wo^T + bo is computed here
-  const bf16* o;       // (R,192) attention output, 'b n (h d)'
-  const bf16* wo;      // (192,192) to_out weight
+  const h16* o;       // (R,192) attention output, 'b n (h d)'
+  const h16* wo;      // (192,192) to_out weight
   const float* bo;     // (192)
   float* xmid;         // (R,192) fp32, written (saved for backward); the LayerNorm input and the residual of `out`
   // forward with the NEXT block's LayerNorm + to_qkv appended (NEXT): h1 = LN(out), qkv = h1 Wqkv^T
   const float* n_gamma;  // next block's layers.{i+1}.0.norm weight / bias
   const float* n_beta;
-  const bf16* n_w;       // (N3,192) next block's to_qkv weight
-  bf16* n_h;             // (R,192) saved LN output of the next block (or null)
+  const h16* n_w;       // (N3,192) next block's to_qkv weight
+  h16* n_h;             // (R,192) saved LN output of the next block (or null)
   float* n_mean;         // (R)
   float* n_rstd;
-  bf16* n_y;             // (R,N3) qkv of the next block
+  h16* n_y;             // (R,N3) qkv of the next block
   int N3;
   int R, M;
 };
@@ -97,9 +97,9 @@ __device__ const float g_gelu_table[MLP_TAB_N + 1][2] = {
 SITK_DEV float tab_pos(float x) { return __builtin_amdgcn_fmed3f(fmaf(x, MLP_TAB_SCALE, MLP_TAB_ZERO), 0.0f, MLP_TAB_TMAX); }
 
 // two floats -> one dword of two bf16 (v_cvt_pk_bf16_f32)
-SITK_DEV uint32_t pack_bf16(float a, float b) {
-  bf16x2 v;
-  v[0] = (bf16)a; v[1] = (bf16)b;
+SITK_DEV uint32_t pack_h16(float a, float b) {
+  h16x2 v;
+  v[0] = (h16)a; v[1] = (h16)b;
   return __builtin_bit_cast(uint32_t, v);
 }
 
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   const int r8 = lane >> 3;
   const bool isA = wave < TG;
   const int wsub = isA ? wave : wave - TG;                    // index among the waves that carry the same matrix
-  const bf16* wsrc = isA ? p.wa : p.wb;
+  const h16* wsrc = isA ? p.wa : p.wb;
   const int cstep = isA ? 64 * D : 64;                         // element step per chunk
   int soff[PPW];
 #pragma unroll
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   }
   auto issue = [&](int c, int buf) {
     char* base = smem + buf * (W1B + W2B) + (isA ? 0 : W1B) + wsub * PPW * 1024;
-    const bf16* src = wsrc + (size_t)c * cstep;
+    const h16* src = wsrc + (size_t)c * cstep;
 #pragma unroll
     for (int i = 0; i < PPW; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + soff[i]),
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     for (int i = 0; i < WPW; ++i) {
       const int q = wave * WPW + i, kt = q / 24, row = (q % 24) * 8 + r8;
       const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
-      const bf16* src = p.wo + (size_t)row * D + kt * 64 + (((lane & 7) ^ (key << 1)) * 8);
+      const h16* src = p.wo + (size_t)row * D + kt * 64 + (((lane & 7) ^ (key << 1)) * 8);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(smem + kt * 24576 + (q % 24) * 1024), 16, 0, 0);
     }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
         const u32x4 a = *reinterpret_cast<const u32x4*>(smem + (k >> 1) * 24576 + (96 * hh + 16 * i + fr) * 128 +
                                                         (((k & 1) * 64 + fq * 16) ^ (keyp << 5)));
 #pragma unroll
-        for (int t = 0; t < TT; ++t) pacc[i][t] = Mma<bf16>::mma(a, of[t][k], pacc[i][t]);
+        for (int t = 0; t < TT; ++t) pacc[i][t] = Mma<h16>::mma(a, of[t][k], pacc[i][t]);
       }
     proj_residual_ln_rows<TG, TT>(smem + 73728, smem, pacc, tid, blk0, p.R, p.x, p.bo, p.gamma, p.beta, p.xmid, p.h, p.mean, p.rstd);
     issue(0, 1);                                               // the row buffer is dead: ring slot 1 takes chunk 0
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = ok ? (v[pass][i][e] - mu) * rs * gm[i][e] + bt[i][e] : 0.f;
         const int byte = c4 * 8;                         // bf16 byte offset in the 384-byte row
-        bf16x4 ob;
+        h16x4 ob;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ob[e] = (bf16)o[e];
-        *reinterpret_cast<bf16x4*>(sH + (byte >> 7) * (BLK * 128) + lds_off(r, byte & 127)) = ob;
+        for (int e = 0; e < 4; ++e) ob[e] = (h16)o[e];
+        *reinterpret_cast<h16x4*>(sH + (byte >> 7) * (BLK * 128) + lds_off(r, byte & 127)) = ob;
         if (p.h) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, ob), r_h, (r * D + 4 * c4) * 2, 0, 0);
       }
       if (ok && j == 0 && p.mean) { p.mean[row] = mu; p.rstd[row] = rs; }
@@ -458,10 +458,10 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     }
 #define SITK_MLP_FC1_MMAS(KT, f0, f1, f2, f3)                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[0][t] = Mma<bf16>::mma(f0, hf[t][2 * KT], uacc[0][t]);     \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[1][t] = Mma<bf16>::mma(f1, hf[t][2 * KT], uacc[1][t]);     \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[0][t] = Mma<bf16>::mma(f2, hf[t][2 * KT + 1], uacc[0][t]); \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[1][t] = Mma<bf16>::mma(f3, hf[t][2 * KT + 1], uacc[1][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[0][t] = Mma<h16>::mma(f0, hf[t][2 * KT], uacc[0][t]);     \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[1][t] = Mma<h16>::mma(f1, hf[t][2 * KT], uacc[1][t]);     \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[0][t] = Mma<h16>::mma(f2, hf[t][2 * KT + 1], uacc[0][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) uacc[1][t] = Mma<h16>::mma(f3, hf[t][2 * KT + 1], uacc[1][t]); \
     __builtin_amdgcn_sched_barrier(0);
     SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a0, a1, 8192, 10240, 8192, 10240);
     SITK_MLP_FC1_MMAS(0, x0, x1, x2, x3)
@@ -502,8 +502,8 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
           const f32x2 en = __builtin_bit_cast(f32x2, te[e]);
           gv[e] = xs[e] * fmaf(fw[e], en[1], en[0]);
         }
-        pf[t] = u32x4{pack_bf16(gv[0], gv[1]), pack_bf16(gv[2], gv[3]), pack_bf16(gv[4], gv[5]), pack_bf16(gv[6], gv[7])};
-        sd[t] = u32x4{pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+        pf[t] = u32x4{pack_h16(gv[0], gv[1]), pack_h16(gv[2], gv[3]), pack_h16(gv[4], gv[5]), pack_h16(gv[6], gv[7])};
+        sd[t] = u32x4{pack_h16(v0[0], v0[1]), pack_h16(v0[2], v0[3]), pack_h16(v1[0], v1[1]), pack_h16(v1[2], v1[3])};
         if (p.u) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_u, vo[t], so, 0);
         if (p.g) __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_g, vo[t], so, 0);
       }
@@ -533,9 +533,12 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
           u32x4 te[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            // bf16 -> f32 is a 16-bit shift of the packed dword
             const uint32_t w = uc[t][2 * hf4 + (e >> 1)];
-            us[e] = __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));
+#ifdef SITK_TU_F16
+            us[e] = (float)__builtin_bit_cast(h16x2, w)[e & 1];                       // v_cvt_f32_f16 (word select)
+#else
+            us[e] = __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));   // bf16 -> f32 is a 16-bit shift
+#endif
             const float tp = tab_pos(us[e]);
             fw[e] = __builtin_amdgcn_fractf(tp);
             ad[e] = ltabb + ((uint32_t)tp << 4);
@@ -553,8 +556,8 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
             gv[4 * hf4 + e] = us[e] * cdf;
           }
         }
-        pf[t] = u32x4{pack_bf16(dv[0], dv[1]), pack_bf16(dv[2], dv[3]), pack_bf16(dv[4], dv[5]), pack_bf16(dv[6], dv[7])};
-        sd[t] = u32x4{pack_bf16(gv[0], gv[1]), pack_bf16(gv[2], gv[3]), pack_bf16(gv[4], gv[5]), pack_bf16(gv[6], gv[7])};
+        pf[t] = u32x4{pack_h16(dv[0], dv[1]), pack_h16(dv[2], dv[3]), pack_h16(dv[4], dv[5]), pack_h16(dv[6], dv[7])};
+        sd[t] = u32x4{pack_h16(gv[0], gv[1]), pack_h16(gv[2], gv[3]), pack_h16(gv[4], gv[5]), pack_h16(gv[6], gv[7])};
         __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_du, vo[t], so, 0);
         if (p.g) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_g, vo[t], so, 0);
       }
@@ -565,10 +568,10 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     // ---- second product: yacc[dt][t] += Wb[16 dt .., chunk half] . pf[t] ----
 #define SITK_MLP_FC2_MMAS(J, f0, f1, f2, f3)                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 0][t] = Mma<bf16>::mma(f0, pf[t], yacc[4 * J + 0][t]); \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 1][t] = Mma<bf16>::mma(f1, pf[t], yacc[4 * J + 1][t]); \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 2][t] = Mma<bf16>::mma(f2, pf[t], yacc[4 * J + 2][t]); \
-    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 3][t] = Mma<bf16>::mma(f3, pf[t], yacc[4 * J + 3][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 0][t] = Mma<h16>::mma(f0, pf[t], yacc[4 * J + 0][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 1][t] = Mma<h16>::mma(f1, pf[t], yacc[4 * J + 1][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 2][t] = Mma<h16>::mma(f2, pf[t], yacc[4 * J + 2][t]); \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) yacc[4 * J + 3][t] = Mma<h16>::mma(f3, pf[t], yacc[4 * J + 3][t]); \
     __builtin_amdgcn_sched_barrier(0);
     SITK_MLP_WAIT_ISSUE4(y0, y1, y2, y3, x0, x1, x2, x3, a2, a2, 8192, 10240, 12288, 14336);
     SITK_MLP_FC2_MMAS(0, y0, y1, y2, y3)
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       }
       auto qissue = [&](int c, int slot) {
         char* base = smem + 49152 + slot * 24576 + wave * QPW * 1024;
-        const bf16* src = p.n_w + (size_t)c * 64 * D;
+        const h16* src = p.n_w + (size_t)c * 64 * D;
 #pragma unroll
         for (int i = 0; i < QPW; ++i)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + qoff[i]),
@@ -682,10 +685,10 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
           for (int t = 0; t < TT; ++t) qacc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define SITK_MLP_Q_MMAS(KT, f0, f1, f2, f3)                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
-        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[0][t] = Mma<bf16>::mma(f0, qf[t][2 * KT], qacc[0][t]);     \
-        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[1][t] = Mma<bf16>::mma(f1, qf[t][2 * KT], qacc[1][t]);     \
-        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[0][t] = Mma<bf16>::mma(f2, qf[t][2 * KT + 1], qacc[0][t]); \
-        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[1][t] = Mma<bf16>::mma(f3, qf[t][2 * KT + 1], qacc[1][t]); \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[0][t] = Mma<h16>::mma(f0, qf[t][2 * KT], qacc[0][t]);     \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[1][t] = Mma<h16>::mma(f1, qf[t][2 * KT], qacc[1][t]);     \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[0][t] = Mma<h16>::mma(f2, qf[t][2 * KT + 1], qacc[0][t]); \
+        _Pragma("unroll") for (int t = 0; t < TT; ++t) qacc[1][t] = Mma<h16>::mma(f3, qf[t][2 * KT + 1], qacc[1][t]); \
         __builtin_amdgcn_sched_barrier(0);
         SITK_MLP_WAIT_ISSUE4(x0, x1, x2, x3, y0, y1, y2, y3, a0, a1, 8192, 10240, 8192, 10240);
         SITK_MLP_Q_MMAS(0, x0, x1, x2, x3)
@@ -698,7 +701,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
           const f32x4 v0 = qacc[0][t], v1 = qacc[1][t];
-          qsd[t] = u32x4{pack_bf16(v0[0], v0[1]), pack_bf16(v0[2], v0[3]), pack_bf16(v1[0], v1[1]), pack_bf16(v1[2], v1[3])};
+          qsd[t] = u32x4{pack_h16(v0[0], v0[1]), pack_h16(v0[2], v0[3]), pack_h16(v1[0], v1[1]), pack_h16(v1[2], v1[3])};
           __builtin_amdgcn_raw_buffer_store_b128(qsd[t], r_y, qvo[t], c * 128, 0);
         }
         asm volatile("" : : "v"(qsd[0]), "v"(qsd[TT - 1]));         // store keep-alive (see the main loop)
@@ -725,8 +728,8 @@ static bool mlp_tt1() {
 }
 
 static int mlp_check(const char* what, int64_t rows, int D, int M, int dtype) {
-  SITK_REQUIRE(dtype == SITK_BF16 && D == MLP_D && M % 64 == 0 && M >= 64 && M <= MLP_MAX_M && rows > 0 && rows < (1ll << 31),
-               "%s: the fused path is specialised for bf16, dim 192, mlp_dim %% 64 == 0 and <= %d (got dtype %d dim %d mlp_dim %d)",
+  SITK_REQUIRE(dtype == SITK_H16 && D == MLP_D && M % 64 == 0 && M >= 64 && M <= MLP_MAX_M && rows > 0 && rows < (1ll << 31),
+               "%s: the fused path is specialised for h16, dim 192, mlp_dim %% 64 == 0 and <= %d (got dtype %d dim %d mlp_dim %d)",
                what, MLP_MAX_M, dtype, D, M);
   return SITK_OK;
 }
@@ -735,21 +738,25 @@ static int mlp_check(const char* what, int64_t rows, int D, int M, int dtype) {
 
 using namespace sitk;
 
+SITK_F16_TWIN(sitk_mlp_fused_supported)
 extern "C" int sitk_mlp_fused_supported(int D, int M, int dtype) {
-  return dtype == SITK_BF16 && D == MLP_D && M % 64 == 0 && M >= 64 && M <= MLP_MAX_M;
+  SITK_FORWARD_F16(dtype, sitk_mlp_fused_supported, D, M, dtype);
+  return dtype == SITK_H16 && D == MLP_D && M % 64 == 0 && M >= 64 && M <= MLP_MAX_M;
 }
 
+SITK_F16_TWIN(sitk_mlp_fwd)
 extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b, const void* w1_c, const float* b1,
                             const void* w2_c, const float* b2, void* h, float* mean, float* rstd, void* u, void* g,
                             float* out, int64_t rows, int D, int M, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_mlp_fwd, x, ln_w, ln_b, w1_c, b1, w2_c, b2, h, mean, rstd, u, g, out, rows, D, M, dtype, stream);
   SITK_REQUIRE(x && ln_w && ln_b && w1_c && b1 && w2_c && b2 && out, "mlp_fwd: null pointer");
   SITK_REQUIRE((mean == nullptr) == (rstd == nullptr), "mlp_fwd: mean and rstd go together");
   SITK_TRY(mlp_check("mlp_fwd", rows, D, M, dtype));
   MlpParams p = {};
   p.x = x; p.gamma = ln_w; p.beta = ln_b;
-  p.wa = reinterpret_cast<const bf16*>(w1_c); p.b1 = b1; p.wb = reinterpret_cast<const bf16*>(w2_c); p.b2 = b2;
-  p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd;
-  p.u = reinterpret_cast<bf16*>(u); p.g = reinterpret_cast<bf16*>(g); p.out = out;
+  p.wa = reinterpret_cast<const h16*>(w1_c); p.b1 = b1; p.wb = reinterpret_cast<const h16*>(w2_c); p.b2 = b2;
+  p.h = reinterpret_cast<h16*>(h); p.mean = mean; p.rstd = rstd;
+  p.u = reinterpret_cast<h16*>(u); p.g = reinterpret_cast<h16*>(g); p.out = out;
   p.R = (int)rows; p.M = M;
   static const int var = sitk_ab_switch("SITK_MLP_VAR", 0);   // 6: stamped kernels (tools/mlp_stamps.py; -DSITK_AB builds only)
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
@@ -764,7 +771,9 @@ extern "C" int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b
   return check_launch("mlp_fwd");
 }
 
+SITK_F16_TWIN(sitk_attn_out_mlp_fused_supported)
 extern "C" int sitk_attn_out_mlp_fused_supported(int64_t rows, int D, int I, int M, int dtype) {
+  SITK_FORWARD_F16(dtype, sitk_attn_out_mlp_fused_supported, rows, D, I, M, dtype);
   return sitk_mlp_fused_supported(D, M, dtype) && I == MLP_D && rows > 0 && fused_block_rows(rows) == 96;
 }
 
@@ -780,18 +789,18 @@ static int attn_out_mlp_launch(const void* o_c, const void* wo_c, const float* b
   SITK_REQUIRE(sitk_attn_out_mlp_fused_supported(rows, D, I, M, dtype),
                "%s: needs heads * 64 == 192 and at most 24576 rows (got I %d rows %lld)", what, I, (long long)rows);
   MlpParams p = {};
-  p.o = reinterpret_cast<const bf16*>(o_c); p.wo = reinterpret_cast<const bf16*>(wo_c); p.bo = bo; p.xmid = xmid;
+  p.o = reinterpret_cast<const h16*>(o_c); p.wo = reinterpret_cast<const h16*>(wo_c); p.bo = bo; p.xmid = xmid;
   p.x = x; p.gamma = ln_w; p.beta = ln_b;
-  p.wa = reinterpret_cast<const bf16*>(w1_c); p.b1 = b1; p.wb = reinterpret_cast<const bf16*>(w2_c); p.b2 = b2;
-  p.h = reinterpret_cast<bf16*>(h); p.mean = mean; p.rstd = rstd;
-  p.u = reinterpret_cast<bf16*>(u); p.g = reinterpret_cast<bf16*>(g); p.out = out;
+  p.wa = reinterpret_cast<const h16*>(w1_c); p.b1 = b1; p.wb = reinterpret_cast<const h16*>(w2_c); p.b2 = b2;
+  p.h = reinterpret_cast<h16*>(h); p.mean = mean; p.rstd = rstd;
+  p.u = reinterpret_cast<h16*>(u); p.g = reinterpret_cast<h16*>(g); p.out = out;
   p.R = (int)rows; p.M = M;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   if (n_qkv) {
     SITK_REQUIRE(n_ln_w && n_ln_b && n_wqkv_c && N3 % 64 == 0 && N3 >= 64 && (n_mean == nullptr) == (n_rstd == nullptr),
                  "%s: bad next-block arguments (N3 %d)", what, N3);
-    p.n_gamma = n_ln_w; p.n_beta = n_ln_b; p.n_w = reinterpret_cast<const bf16*>(n_wqkv_c);
-    p.n_h = reinterpret_cast<bf16*>(n_h); p.n_mean = n_mean; p.n_rstd = n_rstd; p.n_y = reinterpret_cast<bf16*>(n_qkv); p.N3 = N3;
+    p.n_gamma = n_ln_w; p.n_beta = n_ln_b; p.n_w = reinterpret_cast<const h16*>(n_wqkv_c);
+    p.n_h = reinterpret_cast<h16*>(n_h); p.n_mean = n_mean; p.n_rstd = n_rstd; p.n_y = reinterpret_cast<h16*>(n_qkv); p.N3 = N3;
     hipLaunchKernelGGL((mlp_kernel<false, 0, 6, true, true, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   } else {
     hipLaunchKernelGGL((mlp_kernel<false, 0, 6, true, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
@@ -799,20 +808,24 @@ static int attn_out_mlp_launch(const void* o_c, const void* wo_c, const float* b
   return check_launch(what);
 }
 
+SITK_F16_TWIN(sitk_attn_out_mlp_fwd)
 extern "C" int sitk_attn_out_mlp_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
                                      const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
                                      const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
                                      int64_t rows, int D, int I, int M, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_attn_out_mlp_fwd, o_c, wo_c, bo, x, xmid, ln_w, ln_b, w1_c, b1, w2_c, b2, h, mean, rstd, u, g, out, rows, D, I, M, dtype, stream);
   return attn_out_mlp_launch(o_c, wo_c, bo, x, xmid, ln_w, ln_b, w1_c, b1, w2_c, b2, h, mean, rstd, u, g, out, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, nullptr, 0, rows, D, I, M, dtype, stream, "attn_out_mlp_fwd");
 }
 
+SITK_F16_TWIN(sitk_attn_out_mlp_next_fwd)
 extern "C" int sitk_attn_out_mlp_next_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
                                           const float* ln_w, const float* ln_b, const void* w1_c, const float* b1,
                                           const void* w2_c, const float* b2, void* h, float* mean, float* rstd, void* u, void* g,
                                           float* out, const float* n_ln_w, const float* n_ln_b, const void* n_wqkv_c, void* n_h,
                                           float* n_mean, float* n_rstd, void* n_qkv, int N3, int64_t rows, int D, int I, int M,
                                           int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_attn_out_mlp_next_fwd, o_c, wo_c, bo, x, xmid, ln_w, ln_b, w1_c, b1, w2_c, b2, h, mean, rstd, u, g, out, n_ln_w, n_ln_b, n_wqkv_c, n_h, n_mean, n_rstd, n_qkv, N3, rows, D, I, M, dtype, stream);
   SITK_REQUIRE(n_qkv != nullptr, "attn_out_mlp_next_fwd: null qkv output");
   return attn_out_mlp_launch(o_c, wo_c, bo, x, xmid, ln_w, ln_b, w1_c, b1, w2_c, b2, h, mean, rstd, u, g, out, n_ln_w, n_ln_b,
                              n_wqkv_c, n_h, n_mean, n_rstd, n_qkv, N3, rows, D, I, M, dtype, stream, "attn_out_mlp_next_fwd");
@@ -827,19 +840,21 @@ extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) {
   return rows > 0 ? (size_t)cdiv64(rows, fused_block_rows(rows)) * 2 * MLP_D : 0;
 }
 
+SITK_F16_TWIN(sitk_mlp_bwd)
 extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
                             const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,
                             float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
                             sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_mlp_bwd, dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, du, g, dx, dx_c, partials, rows, D, M, dtype, stream);
   SITK_REQUIRE(dy && dy_c && x && mean && rstd && ln_w && w2t_c && w1t_c && u && du && dx && dx_c && partials,
                "mlp_bwd: null pointer");
   SITK_TRY(mlp_check("mlp_bwd", rows, D, M, dtype));
   MlpParams p = {};
   p.x = x; p.gamma = ln_w; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
-  p.wa = reinterpret_cast<const bf16*>(w2t_c); p.wb = reinterpret_cast<const bf16*>(w1t_c);
-  p.u = const_cast<bf16*>(reinterpret_cast<const bf16*>(u)); p.g = reinterpret_cast<bf16*>(g);
-  p.du = reinterpret_cast<bf16*>(du); p.dy = dy; p.dyc = reinterpret_cast<const bf16*>(dy_c);
-  p.out = dx; p.outc = reinterpret_cast<bf16*>(dx_c); p.partials = partials;
+  p.wa = reinterpret_cast<const h16*>(w2t_c); p.wb = reinterpret_cast<const h16*>(w1t_c);
+  p.u = const_cast<h16*>(reinterpret_cast<const h16*>(u)); p.g = reinterpret_cast<h16*>(g);
+  p.du = reinterpret_cast<h16*>(du); p.dy = dy; p.dyc = reinterpret_cast<const h16*>(dy_c);
+  p.out = dx; p.outc = reinterpret_cast<h16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.M = M;
   static const int var = sitk_ab_switch("SITK_MLP_VAR", 0);
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);

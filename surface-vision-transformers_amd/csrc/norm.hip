@@ -391,20 +391,22 @@ int layernorm_finalize_multi(const LnFinalizeEntry* entries, int count, int64_t 
 int layernorm_bwd_deferred(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                            const float* dres, float* dx_out, void* dx_out_c, float* partials, int64_t rows, int D, int dtype,
                            hipStream_t s) {
-  if (dtype == SITK_BF16)
-    return dispatch_ln_bwd<bf16>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, nullptr, nullptr, partials, rows, D, s, false);
+  if (dtype == SITK_H16)
+    return dispatch_ln_bwd<h16>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, nullptr, nullptr, partials, rows, D, s, false);
   return dispatch_ln_bwd<float>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, nullptr, nullptr, partials, rows, D, s, false);
 }
 
 }  // namespace sitk
 
+SITK_F16_TWIN(sitk_layernorm_fwd)
 extern "C" int sitk_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean,
                                   float* rstd, int64_t rows, int D, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_layernorm_fwd, x, gamma, beta, y, mean, rstd, rows, D, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
   SITK_REQUIRE(rows > 0 && D > 0 && D % 4 == 0, "layernorm_fwd: rows=%lld D=%d (D %% 4 == 0 required)", (long long)rows, D);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16) return dispatch_ln_fwd<bf16>(x, gamma, beta, y, mean, rstd, rows, D, s);
+  if (dtype == SITK_H16) return dispatch_ln_fwd<h16>(x, gamma, beta, y, mean, rstd, rows, D, s);
   if (dtype == SITK_F32) return dispatch_ln_fwd<float>(x, gamma, beta, y, mean, rstd, rows, D, s);
   set_error("layernorm_fwd: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
@@ -417,15 +419,17 @@ extern "C" size_t sitk_layernorm_bwd_partial_floats(int64_t rows, int D) {
   return (size_t)grid * 2 * D;
 }
 
+SITK_F16_TWIN(sitk_layernorm_bwd)
 extern "C" int sitk_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd,
                                   const float* gamma, const float* dres, float* dx_out, void* dx_out_c, float* dgamma,
                                   float* dbeta, float* partials, int64_t rows, int D, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_layernorm_bwd, dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, dgamma, dbeta, partials, rows, D, dtype, stream);
   using namespace sitk;
   SITK_REQUIRE(dy && x && mean && rstd && gamma && dx_out && dgamma && dbeta, "layernorm_bwd: null pointer");
   SITK_REQUIRE(rows > 0 && D > 0 && D % 4 == 0, "layernorm_bwd: rows=%lld D=%d", (long long)rows, D);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_BF16)
-    return dispatch_ln_bwd<bf16>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, dgamma, dbeta, partials, rows, D, s);
+  if (dtype == SITK_H16)
+    return dispatch_ln_bwd<h16>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, dgamma, dbeta, partials, rows, D, s);
   if (dtype == SITK_F32)
     return dispatch_ln_bwd<float>(dy, x, mean, rstd, gamma, dres, dx_out, dx_out_c, dgamma, dbeta, partials, rows, D, s);
   set_error("layernorm_bwd: bad dtype %d", dtype);
@@ -446,11 +450,13 @@ extern "C" int sitk_colsum_f32_dup(const float* in, int64_t rows, int cols, int 
   return launch_colsum<float>(in, ld, nullptr, nullptr, rows, cols, out, reinterpret_cast<hipStream_t>(stream), out2, cols2);
 }
 
+SITK_F16_TWIN(sitk_masked_colsum)
 extern "C" int sitk_masked_colsum(const void* in, int ld, int in_is_f32, int dtype, const uint8_t* flag_a,
                                   const uint8_t* flag_b, int64_t rows, int cols, float* out, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_masked_colsum, in, ld, in_is_f32, dtype, flag_a, flag_b, rows, cols, out, stream);
   using namespace sitk;
   SITK_REQUIRE(in && out && flag_a && rows > 0 && cols > 0 && cols % 4 == 0 && ld % 4 == 0, "masked_colsum: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (in_is_f32 || dtype == SITK_F32) return launch_colsum<float>(reinterpret_cast<const float*>(in), ld, flag_a, flag_b, rows, cols, out, s);
-  return launch_colsum<bf16>(reinterpret_cast<const bf16*>(in), ld, flag_a, flag_b, rows, cols, out, s);
+  return launch_colsum<h16>(reinterpret_cast<const h16*>(in), ld, flag_a, flag_b, rows, cols, out, s);
 }

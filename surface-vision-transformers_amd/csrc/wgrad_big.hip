@@ -30,8 +30,8 @@ namespace sitk {
 constexpr int WB_MAX_PROBLEMS = 52;   // 12 layers x 4 + the patch embedding (+ spare)
 constexpr int WB_TILE_ELEMS = 128 * 192;
 struct WbProblem {
-  const bf16* P;   // 128-column side operand (M, ldp)
-  const bf16* Q;   // 192-column side operand (M, ldq)
+  const h16* P;   // 128-column side operand (M, ldp)
+  const h16* Q;   // 192-column side operand (M, ldq)
   int ldp, ldq, cp, cq;  // leading dims and total columns of each side
   float* dW;
   int lddw;
@@ -58,11 +58,11 @@ __device__ u32x4 g_zero_page_wb[4];
 // Every tile is touched once per stage, so no two of these instructions are dependent within a stage; the
 // first compiler-visible reader comes after the barrier that ends the loop.
 SITK_DEV void mma_acc(f32x4& acc, u32x4 a, u32x4 b) {
-  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  asm("v_mfma_f32_16x16x32_" SITK_H16_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 // the same, pinned in program order (the stage loop interleaves it with asm LDS reads and DMA issues by hand)
 SITK_DEV void mma_acc_v(f32x4& acc, u32x4 a, u32x4 b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  asm volatile("v_mfma_f32_16x16x32_" SITK_H16_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
 __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __restrict__ slab) {
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   // Per-lane source pointers of the first stage are set up once; a stage costs one compare, one select and
   // one 64-bit add per piece (columns outside the matrix and rows past the split read the zero page).
   const int r8 = lane >> 3;
-  const bf16* zerop = reinterpret_cast<const bf16*>(zero);
-  const bf16* pbase[10];
+  const h16* zerop = reinterpret_cast<const h16*>(zero);
+  const h16* pbase[10];
   int prow[10], pdst[10];
   size_t pstep[10];
 #pragma unroll
@@ -115,13 +115,13 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
 #pragma unroll
   for (int i = 0; i < 10; ++i) pcur[i] = reinterpret_cast<const char*>(pbase[i]);
   // bytes per 64-row step, uniform per side (lanes on columns outside the matrix walk a pointer they never use)
-  const int pincP = __builtin_amdgcn_readfirstlane(64 * P.ldp * (int)sizeof(bf16));
-  const int pincQ = __builtin_amdgcn_readfirstlane(64 * P.ldq * (int)sizeof(bf16));
+  const int pincP = __builtin_amdgcn_readfirstlane(64 * P.ldp * (int)sizeof(h16));
+  const int pincQ = __builtin_amdgcn_readfirstlane(64 * P.ldq * (int)sizeof(h16));
   int left = rows_total;                                      // rows of this split from the next stage to issue on
   // row-mapped sides: position of the NEXT stage to issue inside its group, and the extra step at a group boundary
   int gposP = P.pgroup ? mbeg % P.pgroup : 0, gposQ = P.qgroup ? mbeg % P.qgroup : 0;
-  const int extraP = P.pgroup ? (P.pstride - P.pgroup) * P.ldp * (int)sizeof(bf16) : 0;
-  const int extraQ = P.qgroup ? (P.qstride - P.qgroup) * P.ldq * (int)sizeof(bf16) : 0;
+  const int extraP = P.pgroup ? (P.pstride - P.pgroup) * P.ldp * (int)sizeof(h16) : 0;
+  const int extraQ = P.qgroup ? (P.qstride - P.qgroup) * P.ldq * (int)sizeof(h16) : 0;
   int incP = pincP, incQ = pincQ;                             // byte step from the stage being issued to the next one
   auto next_stage_steps = [&]() __attribute__((always_inline)) {                             // call once per issued stage, before its pieces
     gposP += 64;
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   const bool biasQ = P.db != nullptr && P.swapped && p0 == 0 && wh == 0;  // dY on the Q side (12 blocks)
   u32x4 ones;
   {
-    bf16x8 o;
+    h16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16)1.0f;
+    for (int e = 0; e < 8; ++e) o[e] = (h16)1.0f;
     ones = __builtin_bit_cast(u32x4, o);
   }
 
@@ -388,8 +388,8 @@ static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks,
     const int tiles_swapped = d[i].N % 192 == 0 ? cdiv(d[i].K, 128) * (d[i].N / 192) : (1 << 30);
     const bool normal = tiles_normal <= tiles_swapped;
     p.swapped = normal ? 0 : 1;
-    p.P = reinterpret_cast<const bf16*>(normal ? d[i].dY : d[i].X);
-    p.Q = reinterpret_cast<const bf16*>(normal ? d[i].X : d[i].dY);
+    p.P = reinterpret_cast<const h16*>(normal ? d[i].dY : d[i].X);
+    p.Q = reinterpret_cast<const h16*>(normal ? d[i].X : d[i].dY);
     p.ldp = normal ? d[i].lddy : d[i].ldx;
     p.ldq = normal ? d[i].ldx : d[i].lddy;
     p.cp = normal ? d[i].N : d[i].K;
@@ -436,8 +436,10 @@ static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks,
 
 using namespace sitk;
 
+SITK_F16_TWIN(sitk_gemm_wgrad_group_ws_bytes)
 extern "C" size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int count, int dtype) {
-  if (!d || count < 1 || count > WB_MAX_PROBLEMS || dtype != SITK_BF16) return 0;
+  SITK_FORWARD_F16(dtype, sitk_gemm_wgrad_group_ws_bytes, d, count, dtype);
+  if (!d || count < 1 || count > WB_MAX_PROBLEMS || dtype != SITK_H16) return 0;
   for (int i = 0; i < count; ++i)
     if (!wb_eligible(d[i])) return 0;
   WbGroup g;
@@ -446,8 +448,10 @@ extern "C" size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int c
   return (size_t)blocks * WB_TILE_ELEMS * sizeof(float);
 }
 
+SITK_F16_TWIN(sitk_gemm_wgrad_group_ws)
 extern "C" int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int dtype, void* ws, size_t ws_bytes,
                                         sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_gemm_wgrad_group_ws, d, count, dtype, ws, ws_bytes, stream);
   SITK_REQUIRE(d != nullptr && count >= 1 && count <= WB_MAX_PROBLEMS, "gemm_wgrad_group_ws: 1..%d problems", WB_MAX_PROBLEMS);
   const size_t need = sitk_gemm_wgrad_group_ws_bytes(d, count, dtype);
   if (need == 0 || ws == nullptr || ws_bytes < need) {       // generic tiles, 4 problems per launch

@@ -153,6 +153,11 @@ class TrainEngine:
         self.N, self.D, self.K = self.P + 1, sit.dim, sit.patch_dim
         self.dtype = rt.dtype_code(sit.compute_dtype)
         self.tdt = rt.torch_dtype(self.dtype)
+        # f16 compute mode (IEEE half: 5 exponent bits): backward runs on a loss-scaled gradient stream.  {S, 1 / S} live in
+        # device memory; regression: the fused head + loss launch picks S = 2^k from the batch's largest |d loss / d logits|
+        # every step; MPP: a constant from the loss denominator (set below).  The optimizer divides S out again.
+        self.loss_scaled = self.dtype == rt.F16
+        self.gscale = torch.ones((2,), dtype=torch.float32, device=self.device)
         self.ld = ops.pad64(self.K)
         self.ncls = sit.mlp_head[1].weight.shape[0]
         self.pool_mean = int(sit.pool == "mean")
@@ -176,6 +181,7 @@ class TrainEngine:
         self._replay_randoms = False
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
+        self._unscale_in_place = keep_grads or self.world > 1
         self.nsteps = 0
 
         self.fp = FlatParams(self.module, self.device, grad_extra=self.D * self.ld + 4 * _ALIGN + self.D)
@@ -207,6 +213,10 @@ class TrainEngine:
         else:
             ssl = self.ssl
             self.n_mask = math.ceil(ssl.mask_prob * P)
+            # d loss / d batch_out = 2 (out - target) / (B n_mask K): times S = 2^floor(log2(B n_mask K / 2)) it is (out - target)
+            # times a factor in (2, 4], whatever the batch size
+            self.mpp_scale = float(2 ** math.floor(math.log2(B * self.n_mask * K / 2))) if self.loss_scaled else 1.0
+            self.gscale.copy_(torch.tensor([self.mpp_scale, 1.0 / self.mpp_scale]))
             self.tok32 = torch.zeros((B * P, K), dtype=f32, device=dev)
             self.enc_out = torch.empty((B * P, D), dtype=self.tdt, device=dev)
             self.wo_c = torch.zeros((ld, D), dtype=self.tdt, device=dev)     # to_original (K, D), zero rows up to ld: the
@@ -269,7 +279,8 @@ class TrainEngine:
                                           fc.bias.data_ptr(), self.target.data_ptr(), self.logits.data_ptr(),
                                           self.loss_acc.data_ptr(), self.dx.data_ptr(), g(ln.weight).data_ptr(),
                                           g(ln.bias).data_ptr(), g(fc.weight).data_ptr(), g(fc.bias).data_ptr(), B, N, D,
-                                          self.ncls, self.pool_mean, int(self.loss_kind == "l1"), self.head_ws.data_ptr(), s))
+                                          self.ncls, self.pool_mean, int(self.loss_kind == "l1"), self.head_ws.data_ptr(),
+                                          self.gscale.data_ptr() if self.loss_scaled else None, s))
 
     def _gather(self, out, ld, dt):
         """patch gather of the batch: from the static input buffer, or -- after load_dataset() -- straight from the resident
@@ -353,7 +364,8 @@ class TrainEngine:
         # row-layout pass for the masked squared error and its gradient in the compute dtype
         ops.gemm_nt(self.enc_out, self.wo_c, self.out_pad, dt, M=B * P, N=ld, K=D, bias=self.bo_pad)
         rt.check(L.sitk_mpp_loss_fwd_bwd_ld(self.out_pad.data_ptr(), ld, self.tok32.data_ptr(), K, self.masked.data_ptr(),
-                                            self.loss_acc.data_ptr(), self.dout_c.data_ptr(), ld, dt, B * P, K, B * self.n_mask, s))
+                                            self.loss_acc.data_ptr(), self.dout_c.data_ptr(), ld, dt, B * P, K, B * self.n_mask,
+                                            self.mpp_scale, s))
         self.dx.zero_()
         ops.gemm_nt(self.dout_c, self.wo_t, self.dx, dt, M=B * P, N=D, K=self.wo_t.shape[1], omap=(P, N, 1))
 
@@ -431,18 +443,21 @@ class TrainEngine:
     def _optimizer(self):
         o, fp, L, s = self.opt, self.fp, rt.lib, self._s()
         scale = 1.0 / self.world
+        # the loss scale S of the f16 mode: divided out by the optimizer pass itself (1 / S read from device memory), unless
+        # the gradients were already unscaled in place (kept gradients; data parallelism, where every rank has its own S)
+        inv_s = self.gscale[1:2].data_ptr() if self.loss_scaled and not self._unscale_in_place else None
         zero = int(not self.keep_grads)
         n_extra = fp.grad_all.numel() - fp.total if zero else 0
         keep_dst = self.loss.data_ptr() if zero else None
         if o["kind"] == "sgd":
             rt.check(L.sitk_sgd_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), rt.ptr(self.state[0]), fp.total,
                                          self.hyper.data_ptr(), o["momentum"], o["wd"], int(o["nesterov"]), scale, zero,
-                                         n_extra, self._loss_extra_idx, keep_dst, s))
+                                         n_extra, self._loss_extra_idx, keep_dst, inv_s, s))
         else:
             rt.check(L.sitk_adam_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), self.state[0].data_ptr(),
                                           self.state[1].data_ptr(), fp.total, self.hyper.data_ptr(), o["betas"][0],
                                           o["betas"][1], o["eps"], o["wd"], int(o["kind"] == "adamw"), scale, zero, n_extra,
-                                          self._loss_extra_idx, keep_dst, s))
+                                          self._loss_extra_idx, keep_dst, inv_s, s))
 
     # ---- segments: [fwd + loss + head/backward slice 0], [slice 1], ..., [finish + optimizer] ------------
     def _segment_fns(self):
@@ -457,6 +472,8 @@ class TrainEngine:
 
     def _allreduce(self, lo, hi):
         if self.world > 1:
+            if self.loss_scaled:                # every rank scaled by its own S: reduce unscaled gradients
+                self.fp.grad[lo:hi].mul_(self.gscale[1])
             self._pending.append(torch.distributed.all_reduce(self.fp.grad[lo:hi], group=self.pg, async_op=True))
 
     def _run(self, fn, idx):
@@ -540,6 +557,8 @@ class TrainEngine:
                 for fn in segs:
                     fn()
                 self._finish_backward()
+                if self.loss_scaled and self.keep_grads:
+                    self.fp.grad.mul_(self.gscale[1])          # .grad is read by the caller: unscaled
                 self._optimizer()
             self._run(whole, "step")
             self.nsteps += 1

@@ -1,6 +1,8 @@
 """torch.autograd bridges over the C ABI: each Function is one fused stage of the hot path
 (embedding, encoder, head, generic Linear), so `loss.backward()` of tools/train.py:290 /
 tools/pretrain.py:318 runs the HIP backward kernels.  No Function has a CPU branch."""
+import math
+
 import torch
 
 from . import ops
@@ -9,6 +11,20 @@ from . import runtime as rt
 
 def _zeros_like_all(ts):
     return [torch.zeros_like(t) for t in ts]
+
+
+def _f16_scale(dy, dtype):
+    """Loss scaling of the f16 compute mode on the autograd (drop-in module) path: the incoming gradient is multiplied by
+    S = 2^k, k such that max |dy| * S lies in [64, 128), before it becomes a 16-bit MFMA operand, and every result is
+    divided by S again (exact: powers of two).  Costs one host read of max |dy| per backward stage -- the drop-in path
+    follows the reference's own loop, which synchronises every step anyway (tools/train.py:293); the fused engine scales
+    on the device.  Returns None for bf16 / f32 (wide exponent: no scaling)."""
+    if rt.dtype_code(dtype) != rt.F16:
+        return None
+    amax = float(dy.detach().abs().max())
+    if not (amax > 0.0) or not math.isfinite(amax):
+        return None
+    return 2.0 ** (7 - math.frexp(amax)[1])
 
 
 class EmbedFn(torch.autograd.Function):
@@ -36,7 +52,12 @@ class EmbedFn(torch.autograd.Function):
         dx = dx.contiguous()
         dW_pad = torch.zeros((D, ld), dtype=torch.float32, device=dx.device)
         db = torch.zeros((D,), dtype=torch.float32, device=dx.device)
-        ops.gemm_wgrad(dx.view(B * (P + 1), D), tokens, dW_pad, dtype, db=db, M=B * P, N=D, K=ld, dymap=(P, P + 1, 1))
+        S = _f16_scale(dx, dtype)
+        ops.gemm_wgrad((dx if S is None else dx * S).view(B * (P + 1), D), tokens, dW_pad, dtype, db=db, M=B * P, N=D, K=ld,
+                       dymap=(P, P + 1, 1))
+        if S is not None:
+            dW_pad.mul_(1.0 / S)
+            db.mul_(1.0 / S)
         dpos_used = torch.zeros(((P + 1) * D,), dtype=torch.float32, device=dx.device)
         ops.colsum_f32(dx.view(B, (P + 1) * D), dpos_used)
         dpos = torch.zeros(pos_shape, dtype=torch.float32, device=dx.device)
@@ -71,6 +92,9 @@ class LinearFn(torch.autograd.Function):
         xc, wt = ctx.saved_tensors
         N, K, ld, dtype, lead, has_bias = ctx.meta
         dy2 = dy.reshape(-1, N).contiguous()
+        S = _f16_scale(dy2, dtype)
+        if S is not None:
+            dy2 = dy2 * S
         dW_pad = torch.zeros((N, ld), dtype=torch.float32, device=dy.device)
         db = torch.zeros((N,), dtype=torch.float32, device=dy.device) if has_bias else None
         ops.gemm_wgrad(dy2, xc, dW_pad, dtype, db=db, N=N, K=ld)
@@ -79,6 +103,12 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty((dy2.shape[0], K), dtype=torch.float32, device=dy.device)
             ops.gemm_nt(dy2, wt, dx, dtype, N=K, K=N)        # wt = W^T (K, pad8(N)); contraction over N
             dx = dx.view(*lead, K)
+        if S is not None:
+            dW_pad.mul_(1.0 / S)
+            if db is not None:
+                db.mul_(1.0 / S)
+            if dx is not None:
+                dx = dx * (1.0 / S)
         return dx, dW_pad[:, :K].contiguous(), db, None
 
 
@@ -114,8 +144,13 @@ class EncoderFn(torch.autograd.Function):
         P = ops.layer_param_array([ps[11 * i:11 * (i + 1)] for i in range(depth)])
         G = ops.layer_param_array([grads[11 * i:11 * (i + 1)] for i in range(depth)])
         _, scratch = None, torch.empty(rt.lib.sitk_encoder_scratch_bytes(cfg), dtype=torch.uint8, device=dy.device)
-        dx = dy.contiguous().clone()
+        S = _f16_scale(dy, dtype)
+        dx = dy.contiguous().clone() if S is None else dy.contiguous() * S
         ops.encoder_bwd(cfg, P, G, xin.view(B * N, D), dx.view(B * N, D), acts, scratch)
+        if S is not None:
+            dx.mul_(1.0 / S)
+            for g in grads:
+                g.mul_(1.0 / S)
         return (dx, None, *grads)
 
 

@@ -57,7 +57,10 @@ class _MppEmbedFn(torch.autograd.Function):
         ops.masked_colsum(dx2, replaced_full, None, r, "f32")
         _, wt = ops.stage_weight(weight.contiguous(), dtype, want_c=False)      # (K, pad8(D)) = W^T
         dmt = torch.empty((1, K), dtype=torch.float32, device=dx.device)
-        ops.gemm_nt(r, wt, dmt, dtype, M=1, N=K, K=D)
+        S = Fn._f16_scale(r, dtype)                                             # f16 mode: scaled operand, see functional.py
+        ops.gemm_nt(r if S is None else r * S, wt, dmt, dtype, M=1, N=K, K=D)
+        if S is not None:
+            dmt.mul_(1.0 / S)
         return g[0], g[1], g[2], g[3], g[4], dmt.view(mt_shape), None, None, None, None
 
 

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import runtime as rt
-from .runtime import BF16, F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_STORE  # noqa: F401
+from .runtime import BF16, F16, F32, EPI_BIAS_GELU, EPI_BIAS_RES, EPI_DGELU, EPI_STORE  # noqa: F401
 
 
 def pad8(n):
@@ -427,16 +427,18 @@ def head_bwd(x, ln_w, ln_b, w, dlogits, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, p
 
 
 def head_loss_fwd_bwd(x, ln_w, ln_b, w, b, target, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, pool_mean, l1=False,
-                      ordered=True):
+                      ordered=True, grad_scale=None):
     """pool + head + loss and their backward in one launch; returns logits (B, n_classes).  ordered: per-sample terms of
-    the parameter gradients / loss go through a workspace and are added in sample order (bitwise reproducible)."""
+    the parameter gradients / loss go through a workspace and are added in sample order (bitwise reproducible).
+    grad_scale: (2,) fp32 device tensor -> every gradient comes out multiplied by the power of two S the call picks from
+    the batch and leaves there as {S, 1 / S} (loss scaling of the f16 compute mode)."""
     ncls = w.shape[0]
     logits = torch.empty((B, ncls), dtype=torch.float32, device=x.device)
     ws = torch.empty(rt.lib.sitk_head_ws_floats(B, D, ncls), dtype=torch.float32, device=x.device) if ordered else None
     rt.check(rt.lib.sitk_head_loss_fwd_bwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w.data_ptr(), b.data_ptr(),
                                            target.data_ptr(), logits.data_ptr(), loss.data_ptr(), dx.data_ptr(),
                                            d_ln_w.data_ptr(), d_ln_b.data_ptr(), d_w.data_ptr(), d_b.data_ptr(), B, N, D, ncls,
-                                           int(pool_mean), int(l1), rt.ptr(ws), rt.stream_ptr()))
+                                           int(pool_mean), int(l1), rt.ptr(ws), rt.ptr(grad_scale), rt.stream_ptr()))
     return logits
 
 

@@ -74,7 +74,7 @@ def layer_kernels(eng, nset):
     H, M = tr.heads, tr.mlp_dim
     I, R = H * 64, B * N
     dev, td = eng.device, eng.tdt
-    es = 2 if td == torch.bfloat16 else 4
+    es = 4 if td == torch.float32 else 2
     L = eng.depth
     f32 = torch.float32
     S = [_Set(eng, 7 + i) for i in range(nset)]

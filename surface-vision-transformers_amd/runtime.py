@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SITK_LIB: A/B timing of two builds of the same ABI (tools/kbench.py); the default is the in-tree build
 LIB_PATH = os.environ.get("SITK_LIB") or os.path.join(_HERE, "libsitk.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
 ABI_VERSION = 8
 
@@ -108,7 +108,7 @@ _SIGS = {
     "sitk_head_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sitk_head_ws_floats": (_Z, [_I, _I, _I]),
     "sitk_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
-    "sitk_head_loss_fwd_bwd": (C.c_int, [_P] * 13 + [_I] * 6 + [_P, _P]),
+    "sitk_head_loss_fwd_bwd": (C.c_int, [_P] * 13 + [_I] * 6 + [_P, _P, _P]),
     "sitk_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "sitk_colsum_f32": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "sitk_colsum_f32_dup": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P]),
@@ -116,12 +116,12 @@ _SIGS = {
     "sitk_mpp_draw": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _P]),
     "sitk_mpp_gather_corrupt": (C.c_int, [_P] * 13 + [_I, _I, _I, _I, _I, _I, _I, _P]),
     "sitk_mpp_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _P]),
-    "sitk_mpp_loss_fwd_bwd_ld": (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _L, _I, _L, _P]),
+    "sitk_mpp_loss_fwd_bwd_ld": (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _L, _I, _L, _F, _P]),
     "sitk_masked_colsum": (C.c_int, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P]),
     "sitk_sgd_step": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _I, _F, _P]),
     "sitk_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _F, _P]),
-    "sitk_sgd_step_dev": (C.c_int, [_P, _P, _P, _L, _P, _F, _F, _I, _F, _I, _L, _L, _P, _P]),
-    "sitk_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _I, _L, _L, _P, _P]),
+    "sitk_sgd_step_dev": (C.c_int, [_P, _P, _P, _L, _P, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P]),
+    "sitk_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
@@ -153,15 +153,19 @@ def stream_ptr():
 
 
 def dtype_code(dtype):
-    if dtype in (BF16, "bf16", torch.bfloat16):
+    if isinstance(dtype, int) and not isinstance(dtype, bool) and dtype in (F32, BF16, F16):
+        return dtype
+    if dtype in ("bf16", torch.bfloat16):
         return BF16
-    if dtype in (F32, "f32", "fp32", torch.float32):
+    if dtype in ("f16", "fp16", "half", torch.float16):
+        return F16
+    if dtype in ("f32", "fp32", torch.float32):
         return F32
-    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'bf16' or 'f32')")
+    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'bf16', 'f16' or 'f32')")
 
 
 def torch_dtype(code):
-    return torch.bfloat16 if code == BF16 else torch.float32
+    return {BF16: torch.bfloat16, F16: torch.float16, F32: torch.float32}[code]
 
 
 def ptr(t):

@@ -34,7 +34,8 @@ def pk():
     return sit, mpp, engine
 
 
-@pytest.mark.parametrize("dtype,layout,pool", [("f32", "surface", "cls"), ("bf16", "patched", "mean"), ("bf16", "surface", "cls")])
+@pytest.mark.parametrize("dtype,layout,pool", [("f32", "surface", "cls"), ("bf16", "patched", "mean"), ("bf16", "surface", "cls"),
+                                               ("f16", "patched", "mean"), ("f16", "surface", "cls")])
 def test_engine_step_equals_autograd_plus_sgd(pk, dtype, layout, pool):
     sit, _, engine = pk
     B = 4
@@ -88,7 +89,7 @@ def test_engine_backward_slices_match_single_slice(pk):
     assert rel(flats[1], flats[0]) < 1e-6
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_mpp_engine_gradients_match_autograd_path(pk, dtype):
     sit, mpp, engine = pk
     B, P, V = 3, 320, 153
@@ -121,14 +122,15 @@ def test_mpp_engine_gradients_match_autograd_path(pk, dtype):
     assert all(np.isfinite(ls)) and np.mean(ls[-3:]) < np.mean(ls[:3]), ls
 
 
-def test_engine_bench_config_matches_autograd_path(pk):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_engine_bench_config_matches_autograd_path(pk, dtype):
     """BASELINE config 2 end to end, exactly as bench.py runs it: SiT-tiny, depth 12, B = 64, bf16, raw surfaces,
     one hipGraph per segment -- two steps against the autograd module path + torch.optim.SGD on the same batch
     (tools/train.py:280-291).  Compared: both losses and the parameter UPDATE (after - before) of every tensor."""
     sit, _, engine = pk
     B, lr = 64, 0.01
     kw = dict(sit_oracle.MODEL_SIZES["tiny"], num_patches=320, num_vertices=153, num_channels=4)
-    m1 = sit.SiT(**kw, compute_dtype="bf16")
+    m1 = sit.SiT(**kw, compute_dtype=dtype)
     _load(m1, 21)
     m2 = copy.deepcopy(m1)
     before = {k: p.detach().clone() for k, p in m1.named_parameters()}
@@ -147,17 +149,18 @@ def test_engine_bench_config_matches_autograd_path(pk):
     eng = engine.TrainEngine(m2, B, input_layout="surface", lr=lr, momentum=0.9, use_graph=True)
     got = [float(eng.step(x, y)) for _ in range(2)]
     assert eng._graphs, "the step must have been captured"
-    check("engine/bench_tiny_b64", "loss", "bf16", max(abs(a - b) / abs(b) for a, b in zip(got, losses)), "out")
+    check("engine/bench_tiny_b64", "loss", dtype, max(abs(a - b) / abs(b) for a, b in zip(got, losses)), "out")
     worst = (0.0, "")
     for (k, p), (_, q) in zip(m2.named_parameters(), m1.named_parameters()):
         d_eng, d_ref = p.detach().cpu() - before[k], q.detach().cpu() - before[k]
         worst = max(worst, (rel(d_eng, d_ref), k))
     print("worst parameter update:", worst)
-    check("engine/bench_tiny_b64", "update_rel", "bf16", worst[0], "grad")
+    check("engine/bench_tiny_b64", "update_rel", dtype, worst[0], "grad")
     assert eng.fp.still_flat()
 
 
-def test_engine_bench_config_is_bitwise_reproducible(pk):
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_engine_bench_config_is_bitwise_reproducible(pk, dtype):
     """no float atomics on the bench path any more (the head's parameter gradients and the loss go
     through per-sample partial rows, d pos_embedding / d cls_token and the LayerNorm gradients through ordered sums, the
     weight gradients of the one-launch 12-layer slice write each tile once).  Two engines from the same weights, the
@@ -166,7 +169,7 @@ def test_engine_bench_config_is_bitwise_reproducible(pk):
     sit, _, engine = pk
     B = 64
     kw = dict(sit_oracle.MODEL_SIZES["tiny"], num_patches=320, num_vertices=153, num_channels=4)
-    base = sit.SiT(**kw, compute_dtype="bf16")
+    base = sit.SiT(**kw, compute_dtype=dtype)
     _load(base, 21)
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.randn((B, 40962, 4), device=DEV, generator=g)
@@ -342,7 +345,7 @@ def test_graph_follows_lr_schedule_and_step_count(pk, optimizer):
         flats[use_graph] = eng.fp.flat.clone()
         worst = max((rel(p.data, q.data), k) for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()))
         assert worst[0] < 2e-5, worst
-    assert torch.equal(flats[True], flats[False])     # ordered reductions everywhere on this path: replay == eager, bit for bit
+    assert rel(flats[True], flats[False]) < 1e-6      # (f32 verification mode: its generic 64 x 64 weight-gradient tiles add with float atomics)
 
 
 def test_resident_dataset_pipeline(pk):

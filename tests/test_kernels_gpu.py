@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 from oracle import detgen, sit_oracle  # noqa: E402
 
 DEV = "cuda:0"
-TOL = {"f32": 2e-5, "bf16": 1e-2}
-DTYPES = ["f32", "bf16"]
+TOL = {"f32": 2e-5, "bf16": 1e-2, "f16": 2e-3}
+DTYPES = ["f32", "bf16", "f16"]
+H16S = ["bf16", "f16"]
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +31,7 @@ def ops():
 
 
 def tdt(dtype):
-    return torch.bfloat16 if dtype == "bf16" else torch.float32
+    return {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype]
 
 
 def rel(a, b):
@@ -106,8 +107,8 @@ def test_gemm_nt_integer_exact(ops, dtype, M, N, K):
     out = torch.empty((M, N), dtype=tdt(dtype), device=DEV)
     ops.gemm_nt(A.to(tdt(dtype)), W.to(tdt(dtype)), out, dtype)
     ref = A @ W.t()
-    if dtype == "bf16":
-        ref = ref.to(torch.bfloat16)                         # |sums| can exceed 256: compare after the same rounding
+    if dtype != "f32":
+        ref = ref.to(tdt(dtype))                             # |sums| can exceed 256 (2048 in f16): compare after the same rounding
     assert torch.equal(out, ref.to(out.dtype))
 
 
@@ -243,41 +244,43 @@ def test_layernorm_fwd_bwd(ops, dtype, D):
     assert rel(dgam2, gr.grad) < 2e-5 and rel(dbet2, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("h16", H16S)
 @pytest.mark.parametrize("D,M,H", [(192, 768, 3), (384, 1536, 6)])
-def test_wgrad_large_tile_slab_path_integer_exact(ops, D, M, H):
+def test_wgrad_large_tile_slab_path_integer_exact(ops, D, M, H, h16):
     """bf16 128x192-tile kernel + slab reduction (sitk_gemm_wgrad_group_ws): both orientations, partial
     tiles (192 = 128 + 64), bias on either side, accumulate semantics, token tail (R % 64 != 0)."""
     R, I = 321 * 8 + 5, H * 64
     probs, refs = [], []
     for i, (n, k, bias) in enumerate([(D, M, True), (M, D, True), (D, I, True), (3 * I, D, False)]):
-        dY, X = ints(f"wgb/dY{i}", (R, n), -2, 3).to(torch.bfloat16), ints(f"wgb/X{i}", (R, k), -2, 3).to(torch.bfloat16)
+        dY, X = ints(f"wgb/dY{i}", (R, n), -2, 3).to(tdt(h16)), ints(f"wgb/X{i}", (R, k), -2, 3).to(tdt(h16))
         X[:, 0] += 1.0
         dW = torch.ones((n, k), device=DEV)                  # pre-existing gradient: must be accumulated into
         db = torch.zeros((n,), device=DEV) if bias else None
         probs.append(dict(dY=dY, X=X, dW=dW, db=db))
         refs.append((dY.float().t() @ X.float() + 1.0, dY.float().sum(0)))
     from sitk import runtime as rt
-    ops.gemm_wgrad_group(probs, "bf16", workspace="auto")
+    ops.gemm_wgrad_group(probs, h16, workspace="auto")
     for p, (rw, rb) in zip(probs, refs):
         assert torch.equal(p["dW"], rw)
         if p["db"] is not None:
             assert torch.equal(p["db"], rb)
 
 
-def test_wgrad_large_tile_row_mapped_dy_integer_exact(ops):
+@pytest.mark.parametrize("h16", H16S)
+def test_wgrad_large_tile_row_mapped_dy_integer_exact(ops, h16):
     """The patch-embedding weight gradient in the large-tile path: dY = rows 1..P of every sample of a (B, P + 1, D)
     gradient (row map group P, stride P + 1, offset 1), X = (B P, ld) tokens with K = 612 of ld = 616 columns used,
     next to a plain problem; token splits that start inside a group."""
     B, P, D, K, ld = 8, 320, 192, 612, 616
-    dx = ints("wgm/dx", (B * (P + 1), D), -2, 3).to(torch.bfloat16)
-    tok = ints("wgm/tok", (B * P, ld), -2, 3).to(torch.bfloat16)
+    dx = ints("wgm/dx", (B * (P + 1), D), -2, 3).to(tdt(h16))
+    tok = ints("wgm/tok", (B * P, ld), -2, 3).to(tdt(h16))
     tok[:, K:] = 0
     dW = torch.zeros((D, ld), device=DEV)
     db = torch.zeros((D,), device=DEV)
-    dY2, X2 = ints("wgm/dY2", (B * P, 768), -2, 3).to(torch.bfloat16), ints("wgm/X2", (B * P, D), -2, 3).to(torch.bfloat16)
+    dY2, X2 = ints("wgm/dY2", (B * P, 768), -2, 3).to(tdt(h16)), ints("wgm/X2", (B * P, D), -2, 3).to(tdt(h16))
     dW2 = torch.zeros((768, D), device=DEV)
     ops.gemm_wgrad_group([dict(dY=dx, X=tok, dW=dW, db=db, dymap=(P, P + 1, 1), M=B * P),
-                          dict(dY=dY2, X=X2, dW=dW2)], "bf16", workspace="auto")
+                          dict(dY=dY2, X=X2, dW=dW2)], h16, workspace="auto")
     dxp = dx.float().view(B, P + 1, D)[:, 1:].reshape(B * P, D)
     assert torch.equal(dW, dxp.t() @ tok.float()) and torch.equal(db, dxp.sum(0))
     assert torch.equal(dW2, dY2.float().t() @ X2.float())
@@ -336,10 +339,11 @@ def test_attention_fwd_bwd(ops, dtype, B, N, H):
         assert e < (5e-5 if dtype == "f32" else 2e-2), (name, e)
 
 
+@pytest.mark.parametrize("h16", H16S)
 @pytest.mark.parametrize("B,N,H", [(2, 321, 3), (1, 81, 3), (3, 64, 2), (1, 100, 1)])
-def test_attention_bwd_with_to_out_backward_folded(ops, B, N, H):
+def test_attention_bwd_with_to_out_backward_folded(ops, B, N, H, h16):
     """sitk_attention_bwd_proj == sitk_gemm_nt (d_o = dx_mid Wo) + sitk_attention_bwd, and writes that d_o."""
-    dtype, td, D, I = "bf16", torch.bfloat16, 192, H * 64
+    dtype, td, D, I = h16, tdt(h16), 192, H * 64
     assert ops.attention_bwd_proj_supported(N, D, dtype) and not ops.attention_bwd_proj_supported(N, 384, dtype)
     qkv = rnd("atp/qkv", (B * N, 3 * I), 1.0).to(td)
     dxmid = rnd("atp/dx", (B * N, D), 1.0).to(td)
@@ -366,7 +370,8 @@ def test_attention_large_scores_online_softmax(ops):
     assert rel(o, oref) < 2e-5 and rel(lse, lref) < 1e-5
 
 
-def test_attention_ring_large_scores_rescale_branch(ops):
+@pytest.mark.parametrize("h16", H16S)
+def test_attention_ring_large_scores_rescale_branch(ops, h16):
     """bf16 LDS-ring forward (N = 700): the deferred rescale (taken only when a row maximum grows) is forced late -- key 650
     dominates query 10, key 400 dominates query 333 -- and must agree with the softmax reference; lse too."""
     B, N, H = 1, 700, 2
@@ -374,8 +379,8 @@ def test_attention_ring_large_scores_rescale_branch(ops):
     qkv[:, 0:128] *= 4.0
     qkv[650, 128:192] = 6.0 * qkv[10, 0:64]                  # head 0
     qkv[400, 192:256] = 5.0 * qkv[333, 64:128]               # head 1
-    qb = qkv.to(torch.bfloat16)
-    o, lse = ops.attention_fwd(qb, B, N, H, 0.125, "bf16")
+    qb = qkv.to(tdt(h16))
+    o, lse = ops.attention_fwd(qb, B, N, H, 0.125, h16)
     oref, lref = _attn_ref(qb, B, N, H, 0.125)
     assert rel(o, oref) < 1e-2 and rel(lse, lref) < 2e-3
     assert rel(o.float().view(N, H, 64)[10, 0], oref.view(N, H, 64)[10, 0]) < 1e-2
@@ -505,10 +510,27 @@ def test_colsum_and_masked_colsum(ops):
     out2 = torch.zeros(192, device=DEV)
     ops.masked_colsum(x, fa, fb, out2, "f32")
     assert rel(out2, (x * (fa & fb).float()[:, None]).sum(0)) < 1e-5
-    xb = x.to(torch.bfloat16)
-    out3 = torch.zeros(192, device=DEV)
-    ops.masked_colsum(xb, fa, None, out3, "bf16")
-    assert rel(out3, (xb.float() * fa.float()[:, None]).sum(0)) < 1e-5
+    for h16 in H16S:
+        xb = x.to(tdt(h16))
+        out3 = torch.zeros(192, device=DEV)
+        ops.masked_colsum(xb, fa, None, out3, h16)
+        assert rel(out3, (xb.float() * fa.float()[:, None]).sum(0)) < 1e-5
+
+
+def test_colsum_short_inputs_are_summed_in_a_fixed_order(ops):
+    """d pos_embedding / d cls_token shape (rows = batch, wide): one workgroup per column group over all rows, no float
+    atomics -- two calls give the same bits, the duplicated first columns (d cls_token) too, and accumulate semantics hold."""
+    B, cols, D = 64, 321 * 192, 192
+    x = rnd("csd/x", (B, cols))
+    outs = []
+    for _ in range(2):
+        out, out2 = torch.ones(cols, device=DEV), torch.zeros(D, device=DEV)
+        import sitk  # noqa: F401
+        from sitk import runtime as rt
+        rt.check(rt.lib.sitk_colsum_f32_dup(x.data_ptr(), B, cols, cols, out.data_ptr(), out2.data_ptr(), D, rt.stream_ptr()))
+        outs.append((out, out2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel(outs[0][0] - 1.0, x.double().sum(0).float()) < 1e-6 and rel(outs[0][1], x[:, :D].double().sum(0).float()) < 1e-6
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -15,6 +15,20 @@ pytestmark = pytest.mark.gpu
 from oracle import detgen  # noqa: E402
 
 DEV = "cuda:0"
+
+
+class _H:
+    """The 16-bit compute type under test: every test of this module runs once per type (bf16, f16)."""
+    name, td = "bf16", torch.bfloat16
+
+
+@pytest.fixture(autouse=True, params=["bf16", "f16"])
+def _h16(request):
+    _H.name = request.param
+    _H.td = torch.bfloat16 if request.param == "bf16" else torch.float16
+    yield
+    _H.name, _H.td = "bf16", torch.bfloat16
+
 D = 192
 
 
@@ -40,7 +54,7 @@ def ints(name, shape, lo=-3, hi=4):
 
 
 def r16(t):
-    return t.to(torch.bfloat16).double()
+    return t.to(_H.td).double()
 
 
 def params(tag, M):
@@ -54,15 +68,15 @@ SHAPES = [(128, 64), (321 * 3, 768), (1000, 256), (20544, 768), (25000, 128)]   
 
 
 def test_supported_shapes(ops):
-    assert ops.mlp_fused_supported(192, 768, "bf16")
-    assert not ops.mlp_fused_supported(384, 1536, "bf16")      # small / base use the unfused kernels
+    assert ops.mlp_fused_supported(192, 768, _H.name)
+    assert not ops.mlp_fused_supported(384, 1536, _H.name)      # small / base use the unfused kernels
     assert not ops.mlp_fused_supported(192, 768, "f32")        # the exact-f32 verification mode too
-    assert not ops.mlp_fused_supported(192, 2048, "bf16")
+    assert not ops.mlp_fused_supported(192, 2048, _H.name)
     from sitk import runtime as rt
     x = torch.zeros((8, 384), device=DEV)
     with pytest.raises(rt.SitkError):
-        ops.mlp_fwd(x, x[0], x[0], torch.zeros((64, 384), device=DEV).bfloat16(), x[0, :64],
-                    torch.zeros((384, 64), device=DEV).bfloat16(), x[0], "bf16")
+        ops.mlp_fwd(x, x[0], x[0], torch.zeros((64, 384), device=DEV).to(_H.td), x[0, :64],
+                    torch.zeros((384, 64), device=DEV).to(_H.td), x[0], _H.name)
 
 
 @pytest.mark.parametrize("rows,M", SHAPES)
@@ -71,7 +85,7 @@ def test_mlp_fused_fwd(ops, rows, M):
     config-2 shape (20544 x 768)."""
     x = rnd("mlpf/x", (rows, D), 1.5)
     ln_w, ln_b, w1, b1, w2, b2 = params("mlpf", M)
-    out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16", want_g=True)
+    out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name, want_g=True)
     torch.cuda.synchronize()
     xd = x.double()
     h_r = torch.nn.functional.layer_norm(xd, (D,), ln_w.double(), ln_b.double(), 1e-5)
@@ -86,7 +100,7 @@ def test_mlp_fused_fwd(ops, rows, M):
     assert rel(out - x, br_r) < 6e-3                           # the branch alone (the residual would mask errors)
     assert rel(out, xd + br_r) < 2e-3
     # inference form (nothing saved) gives the same output bits
-    out2 = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16", save=False)[0]
+    out2 = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name, save=False)[0]
     assert torch.equal(out, out2)
 
 
@@ -98,7 +112,7 @@ def test_mlp_fused_fwd_integer_exact(ops):
     ln_w, ln_b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
     w1, w2 = ints("mlpi/w1", (M, D), -2, 3), ints("mlpi/w2", (D, M), -2, 3)
     b1, b2 = ints("mlpi/b1", (M,)), ints("mlpi/b2", (D,))
-    out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16", want_g=True)
+    out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name, want_g=True)
     torch.cuda.synchronize()
     u_r = h.double() @ w1.double().T + b1.double()
     assert rel(u, u_r) < 3e-3                                  # one bf16 rounding of the stored u
@@ -111,10 +125,10 @@ def test_mlp_fused_bwd(ops, rows, M):
     x = rnd("mlpb/x", (rows, D), 1.5)
     ln_w, ln_b, w1, b1, w2, b2 = params("mlpb", M)
     dy = rnd("mlpb/dy", (rows, D), 1.0)
-    out, h, mean, rstd, u, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16")
-    w2t = w2.bfloat16().T.contiguous()                         # (M, D)
-    w1t = w1.bfloat16().T.contiguous()                         # (D, M)
-    dx, dx_c, du, g, partials = ops.mlp_bwd(dy, dy.bfloat16(), x, mean, rstd, ln_w, w2t, w1t, u, "bf16")
+    out, h, mean, rstd, u, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name)
+    w2t = w2.to(_H.td).T.contiguous()                         # (M, D)
+    w1t = w1.to(_H.td).T.contiguous()                         # (D, M)
+    dx, dx_c, du, g, partials = ops.mlp_bwd(dy, dy.to(_H.td), x, mean, rstd, ln_w, w2t, w1t, u, _H.name)
     torch.cuda.synchronize()
     ud = u.double()                                            # the saved (bf16) pre-activation is what backward sees
     cdf = 0.5 * (1 + torch.erf(ud / math.sqrt(2)))
@@ -146,9 +160,9 @@ def test_mlp_fused_bwd_zero_gradient_rows(ops):
     ln_w, ln_b, w1, b1, w2, b2 = params("mlpz", M)
     dy = rnd("mlpz/dy", (rows, D), 1.0)
     dy[::3] = 0
-    out, h, mean, rstd, u, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16")
-    dx, dx_c, du, g, partials = ops.mlp_bwd(dy, dy.bfloat16(), x, mean, rstd, ln_w, w2.bfloat16().T.contiguous(),
-                                            w1.bfloat16().T.contiguous(), u, "bf16")
+    out, h, mean, rstd, u, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name)
+    dx, dx_c, du, g, partials = ops.mlp_bwd(dy, dy.to(_H.td), x, mean, rstd, ln_w, w2.to(_H.td).T.contiguous(),
+                                            w1.to(_H.td).T.contiguous(), u, _H.name)
     assert float(dx[::3].abs().max()) == 0.0 and float(du[::3].float().abs().max()) == 0.0
     assert bool(torch.isfinite(dx).all()) and bool(torch.isfinite(partials).all())
 
@@ -162,12 +176,12 @@ def test_mlp_fused_repeatable_and_in_bounds(ops):
     x = rnd("mlpr/x", (rows, D), 1.5)
     ln_w, ln_b, w1, b1, w2, b2 = params("mlpr", M)
     dy = rnd("mlpr/dy", (rows, D), 1.0)
-    w1c, w2c = w1.bfloat16(), w2.bfloat16()
+    w1c, w2c = w1.to(_H.td), w2.to(_H.td)
     w1t, w2t = w1c.T.contiguous(), w2c.T.contiguous()
     ref = None
     for _ in range(4):
-        out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1c, b1, w2c, b2, "bf16", want_g=True)
-        got = (out, h, u, g) + ops.mlp_bwd(dy, dy.bfloat16(), x, mean, rstd, ln_w, w2t, w1t, u, "bf16")
+        out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1c, b1, w2c, b2, _H.name, want_g=True)
+        got = (out, h, u, g) + ops.mlp_bwd(dy, dy.to(_H.td), x, mean, rstd, ln_w, w2t, w1t, u, _H.name)
         torch.cuda.synchronize()
         if ref is None:
             ref = [t.clone() for t in got]
@@ -176,11 +190,11 @@ def test_mlp_fused_repeatable_and_in_bounds(ops):
                 assert torch.equal(a, b)
     # sentinel rows behind every row-indexed output of the forward kernel
     big = lambda cols, dt: torch.full((rows + pad, cols), 7.0, dtype=dt, device=DEV)  # noqa: E731
-    out_b, h_b, u_b, g_b = big(D, torch.float32), big(D, torch.bfloat16), big(M, torch.bfloat16), big(M, torch.bfloat16)
+    out_b, h_b, u_b, g_b = big(D, torch.float32), big(D, _H.td), big(M, _H.td), big(M, _H.td)
     mean, rstd = torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
     rt.check(rt.lib.sitk_mlp_fwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w1c.data_ptr(), b1.data_ptr(), w2c.data_ptr(),
                                  b2.data_ptr(), h_b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), u_b.data_ptr(), g_b.data_ptr(),
-                                 out_b.data_ptr(), rows, D, M, rt.BF16, rt.stream_ptr()))
+                                 out_b.data_ptr(), rows, D, M, rt.dtype_code(_H.name), rt.stream_ptr()))
     torch.cuda.synchronize()
     for t, r in ((out_b, ref[0]), (h_b, ref[1]), (u_b, ref[2]), (g_b, ref[3])):
         assert torch.equal(t[:rows], r)
@@ -193,20 +207,20 @@ def test_attn_out_mlp_fwd(ops, rows):
     Checked against float64 torch math on bf16-rounded operands, and the MLP part against the stand-alone fused
     kernel run on the kernel's own x_mid (identical bits: same code path after the prologue)."""
     M = 768
-    assert ops.attn_out_mlp_fused_supported(rows, D, 192, M, "bf16")
-    assert not ops.attn_out_mlp_fused_supported(30000, D, 192, M, "bf16")      # 128-row workgroups: separate kernels
-    assert not ops.attn_out_mlp_fused_supported(rows, D, 384, M, "bf16")
+    assert ops.attn_out_mlp_fused_supported(rows, D, 192, M, _H.name)
+    assert not ops.attn_out_mlp_fused_supported(30000, D, 192, M, _H.name)      # 128-row workgroups: separate kernels
+    assert not ops.attn_out_mlp_fused_supported(rows, D, 384, M, _H.name)
     x = rnd("aom/x", (rows, D), 1.5)
-    o = rnd("aom/o", (rows, D), 1.0).bfloat16()
+    o = rnd("aom/o", (rows, D), 1.0).to(_H.td)
     wo, bo = rnd("aom/wo", (D, D), D ** -0.5), rnd("aom/bo", (D,), 0.1)
     ln_w, ln_b, w1, b1, w2, b2 = params("aom", M)
-    out, xmid, h, mean, rstd, u, g = ops.attn_out_mlp_fwd(o, wo.bfloat16(), bo, x, ln_w, ln_b, w1.bfloat16(), b1,
-                                                          w2.bfloat16(), b2, "bf16", want_g=True)
+    out, xmid, h, mean, rstd, u, g = ops.attn_out_mlp_fwd(o, wo.to(_H.td), bo, x, ln_w, ln_b, w1.to(_H.td), b1,
+                                                          w2.to(_H.td), b2, _H.name, want_g=True)
     torch.cuda.synchronize()
     xm_r = x.double() + o.double() @ r16(wo).T + bo.double()
     assert rel(xmid, xm_r) < 2e-6                              # fp32 accumulation of bf16 x bf16 products
     assert rel(xmid - x, xm_r - x.double()) < 2e-5
-    ref = ops.mlp_fwd(xmid, ln_w, ln_b, w1.bfloat16(), b1, w2.bfloat16(), b2, "bf16", want_g=True)
+    ref = ops.mlp_fwd(xmid, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name, want_g=True)
     for a, b in zip((out, h, mean, rstd, u, g), ref):
         assert torch.equal(a, b)
     # sentinel rows behind x_mid
@@ -214,11 +228,11 @@ def test_attn_out_mlp_fwd(ops, rows):
     pad = 128
     xm_b = torch.full((rows + pad, D), 7.0, device=DEV)
     out_b = torch.empty((rows, D), device=DEV)
-    woc, w1c, w2c = wo.bfloat16(), w1.bfloat16(), w2.bfloat16()          # keep the operands alive across the raw call
+    woc, w1c, w2c = wo.to(_H.td), w1.to(_H.td), w2.to(_H.td)          # keep the operands alive across the raw call
     rt.check(rt.lib.sitk_attn_out_mlp_fwd(o.data_ptr(), woc.data_ptr(), bo.data_ptr(), x.data_ptr(), xm_b.data_ptr(),
                                           ln_w.data_ptr(), ln_b.data_ptr(), w1c.data_ptr(), b1.data_ptr(),
                                           w2c.data_ptr(), b2.data_ptr(), 0, 0, 0, 0, 0, out_b.data_ptr(), rows, D, 192,
-                                          M, rt.BF16, rt.stream_ptr()))
+                                          M, rt.dtype_code(_H.name), rt.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(xm_b[:rows], xmid) and bool((xm_b[rows:] == 7.0).all()) and torch.equal(out_b, out)
 
@@ -229,21 +243,21 @@ def test_attn_out_mlp_next_fwd(ops, rows):
     launches (attn_out_mlp_fwd, then ln_gemm_fwd on its `out`)."""
     M, N3 = 768, 576
     x = rnd("aon/x", (rows, D), 1.5)
-    o = rnd("aon/o", (rows, D), 1.0).bfloat16()
-    woc, bo = rnd("aon/wo", (D, D), D ** -0.5).bfloat16(), rnd("aon/bo", (D,), 0.1)
+    o = rnd("aon/o", (rows, D), 1.0).to(_H.td)
+    woc, bo = rnd("aon/wo", (D, D), D ** -0.5).to(_H.td), rnd("aon/bo", (D,), 0.1)
     ln_w, ln_b, w1, b1, w2, b2 = params("aon", M)
-    w1c, w2c = w1.bfloat16(), w2.bfloat16()
+    w1c, w2c = w1.to(_H.td), w2.to(_H.td)
     n_lw, n_lb = rnd("aon/nlw", (D,), 0.3) + 1.0, rnd("aon/nlb", (D,), 0.2)
-    wq = rnd("aon/wq", (N3, D), D ** -0.5).bfloat16()
-    got = ops.attn_out_mlp_next_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, n_lw, n_lb, wq, "bf16", want_g=True)
-    ref = ops.attn_out_mlp_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, "bf16", want_g=True)
-    qkv, nh, nmean, nrstd = ops.ln_gemm_fwd(ref[0], n_lw, n_lb, wq, "bf16")
+    wq = rnd("aon/wq", (N3, D), D ** -0.5).to(_H.td)
+    got = ops.attn_out_mlp_next_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, n_lw, n_lb, wq, _H.name, want_g=True)
+    ref = ops.attn_out_mlp_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, _H.name, want_g=True)
+    qkv, nh, nmean, nrstd = ops.ln_gemm_fwd(ref[0], n_lw, n_lb, wq, _H.name)
     torch.cuda.synchronize()
     for a, b in zip(got[:7], ref):
         assert torch.equal(a, b)
     assert torch.equal(got[7], nh) and torch.equal(got[10], qkv)
     assert rel(got[8], nmean) < 1e-6 and rel(got[9], nrstd) < 1e-6
     # repeatable
-    again = ops.attn_out_mlp_next_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, n_lw, n_lb, wq, "bf16", want_g=True)
+    again = ops.attn_out_mlp_next_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, n_lw, n_lb, wq, _H.name, want_g=True)
     for a, b in zip(got, again):
         assert torch.equal(a, b)

@@ -40,7 +40,7 @@ def sitk_models():
     return sit, mpp
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name", list(SIT_CASES))
 def test_sit_matches_reference_golden(sitk_models, golden_dir, name, dtype):
     sit, _ = sitk_models
@@ -69,13 +69,13 @@ def test_sit_matches_reference_golden(sitk_models, golden_dir, name, dtype):
             worst_head, worst_hk = he, k
     print(f"{name} {dtype}: worst gradient norm {worst_k}, worst gradient head {worst_hk}")
     check(f"sit/{name}", "gnorm", dtype, worst, "grad")
-    if dtype == "f32":
+    if dtype in ("f32", "f16"):
         assert worst_head < 0.05, (worst_hk, worst_head)
     else:
         check(f"sit/{name}", "ghead", dtype, worst_head, "grad")
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 def test_sit_full_gradient_vs_oracle(sitk_models, dtype):
     """Element-wise gradient parity (not only norms) on BASELINE config 1's model, depth 3."""
     sit, _ = sitk_models
@@ -112,7 +112,7 @@ def test_raw_surface_entry_equals_patched_entry(sitk_models):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("name", list(MPP_CASES))
 def test_mpp_matches_reference_golden(sitk_models, golden_dir, name, dtype):
     sit, mpp = sitk_models
