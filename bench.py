@@ -104,6 +104,15 @@ def cpu_baseline(seconds=15.0):
                       f"({med * 1e3:.1f} ms/step), torch {torch.__version__} CPU"}
 
 
+def rt_overlap_layers(eng):
+    """layers whose weight gradients the engine runs on its side stream (0: none)"""
+    if not getattr(eng, "_overlap", None):
+        return 0
+    from sitk import runtime as rt
+    rt.lib.sitk_overlap_layers_.restype = int
+    return rt.lib.sitk_overlap_layers_(eng._overlap)
+
+
 def self_launch_command(n, argv):
     """`python bench.py --gpus N` typed bare: the one-rank-per-GPU launcher to start as a child process."""
     import socket
@@ -124,9 +133,12 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--task", default="regression", choices=["regression", "mpp"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches")
+    ap.add_argument("--graph", action="store_true", help="force hipGraph replay (no side stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--wgrad-overlap", type=int, default=None,
+                    help="layers whose weight gradients run on a side stream beside the backward chain (default: engine's choice)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (gloo: rehearsal of the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
@@ -173,7 +185,8 @@ def main():
         model = masked_patch_pretraining(model, mk["dim"], K, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
                                          channels=4, num_vertices=V)
     eng = engine.TrainEngine(model, B, task=args.task, input_layout="surface", lr=1e-5, momentum=0.9,
-                             process_group=pg, use_graph=not args.no_graph, device=dev)
+                             process_group=pg, use_graph=(True if args.graph else (False if args.no_graph else None)), device=dev,
+                             wgrad_overlap=args.wgrad_overlap)
     g = torch.Generator(device=dev).manual_seed(100 + rank)   # every rank its own synthetic shard
     x = torch.randn((B, 40962, 4), device=dev, generator=g)
     y = torch.randn((B,), device=dev, generator=g) * 2 + 40 if args.task == "regression" else None
@@ -210,7 +223,8 @@ def main():
                                f"gather(B,40962,4) + fwd + {'masked MSE' if args.task == 'mpp' else 'MSE'} + bwd + "
                                f"SGD(m=0.9), " + {"bf16": "bf16 MFMA / fp32 accumulate", "f16": "f16 MFMA / fp32 accumulate, loss-scaled backward",
                                                   "f32": "f32 MFMA (verification mode)"}[args.dtype],
-                   "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                   "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph),
+                   "wgrad_overlap_layers": int(rt_overlap_layers(eng)),
                    "loss_after": round(loss, 6)},
         "step_gflop_per_sample": round(gf, 3),
         "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),

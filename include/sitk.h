@@ -160,6 +160,11 @@ int sitk_gemm_wgrad_group(const sitk_wgrad_desc* d, int count, int dtype, sitk_s
 size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int count, int dtype);
 int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int dtype, void* ws, size_t ws_bytes,
                              sitk_stream_t stream);
+/* The same sized for `cus` compute units instead of the chip (1..256): the token splits are chosen so that the launch
+ * has at most ~cus workgroups (one per CU: a workgroup owns its CU's LDS) -- for launches that run on a side stream
+ * BESIDE another kernel chain, on the CUs that chain leaves idle.  The workspace of the 256-CU form is large enough.  */
+int sitk_gemm_wgrad_group_ws_cus(const sitk_wgrad_desc* d, int count, int dtype, void* ws, size_t ws_bytes, int cus,
+                                 sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps 1e-5, biased variance, affine): the PreNorm norms of the
@@ -343,6 +348,23 @@ int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_layer_params*
                            size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,
                            const sitk_wgrad_desc* embed, void* dx_c, int* embed_done, const sitk_wgrad_desc* extra,
                            int n_extra, int* extra_done, sitk_stream_t stream);
+
+/* The weight gradients of FINISHED layers beside the rest of backward.  Every kernel of the backward chain is one wave of
+ * 192 - 214 workgroups that each own a CU's LDS: 42 - 64 of the 256 CUs idle through the whole chain, while the weight
+ * gradients -- which nothing downstream reads before the optimizer -- wait for its end.  With an overlap object the call
+ * hands the weight-gradient launch of each of the first `layers` layers it finishes to a SIDE stream (forked and joined
+ * through events, so it can be captured into the caller's graph), sized for `cus` CUs (42: measured on MI355X, the chain
+ * beside it runs ~4 % longer and hides ~75 % of the side work); the remaining layers' gradients run in one launch behind
+ * the chain as before.  The object owns one non-blocking HIP stream and layers + 1 events; one object per engine (not
+ * re-entrant: two concurrent calls must not share it).  overlap == NULL: sitk_encoder_bwd_extra.                     */
+typedef struct sitk_overlap sitk_overlap;
+sitk_overlap* sitk_overlap_create(int max_layers, int cus);
+void sitk_overlap_destroy(sitk_overlap* o);
+int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* params,
+                             const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
+                             size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,
+                             const sitk_wgrad_desc* embed, void* dx_c, int* embed_done, const sitk_wgrad_desc* extra,
+                             int n_extra, int* extra_done, sitk_overlap* overlap, sitk_stream_t stream);
 
 /* Row 0 of every sample of the residual stream: x[b, 0, :] = cls_token + pos_embedding[0, :]
  * (models/sit.py:70-73; rows 1..P come from the patch-embedding GEMM's BIAS_RES epilogue).      */

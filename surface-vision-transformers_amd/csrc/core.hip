@@ -74,6 +74,39 @@ extern "C" int sitk_timeline_read(sitk_timeline* t, float* us, const char** labe
   return k;
 }
 
+// ---- overlap: a side stream and the events that tie it to the caller's stream (sitk.h) ----
+struct sitk_overlap {
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev;
+  int layers = 0, cus = 0;
+};
+extern "C" sitk_overlap* sitk_overlap_create(int max_layers, int cus) {
+  if (max_layers < 1 || max_layers > 64 || cus < 1 || cus > 128) { sitk_rt::set_error("overlap: bad arguments"); return nullptr; }
+  sitk_overlap* o = new sitk_overlap;
+  o->layers = max_layers; o->cus = cus;
+  if (hipStreamCreateWithFlags(&o->side, hipStreamNonBlocking) != hipSuccess) { sitk_rt::set_error("overlap: hipStreamCreate failed"); delete o; return nullptr; }
+  o->ev.resize(max_layers + 1);
+  for (size_t i = 0; i < o->ev.size(); ++i)
+    if (hipEventCreateWithFlags(&o->ev[i], hipEventDisableTiming) != hipSuccess) {
+      sitk_rt::set_error("overlap: hipEventCreate failed");
+      o->ev.resize(i);
+      sitk_overlap_destroy(o);
+      return nullptr;
+    }
+  return o;
+}
+extern "C" void sitk_overlap_destroy(sitk_overlap* o) {
+  if (!o) return;
+  for (hipEvent_t e : o->ev) (void)hipEventDestroy(e);
+  if (o->side) (void)hipStreamDestroy(o->side);
+  delete o;
+}
+// internal accessors for encoder.hip (both sets of objects)
+extern "C" void* sitk_overlap_stream_(sitk_overlap* o) { return o ? (void*)o->side : nullptr; }
+extern "C" void* sitk_overlap_event_(sitk_overlap* o, int i) { return (o && i >= 0 && i < (int)o->ev.size()) ? (void*)o->ev[i] : nullptr; }
+extern "C" int sitk_overlap_layers_(const sitk_overlap* o) { return o ? o->layers : 0; }
+extern "C" int sitk_overlap_cus_(const sitk_overlap* o) { return o ? o->cus : 0; }
+
 extern "C" int sitk_abi_version(void) { return SITK_ABI_VERSION; }
 extern "C" const char* sitk_last_error(void) { return sitk_rt::g_err; }
 extern "C" int sitk_dtype_size(int dtype) { return (dtype == SITK_BF16 || dtype == SITK_F16) ? 2 : (dtype == SITK_F32 ? 4 : 0); }

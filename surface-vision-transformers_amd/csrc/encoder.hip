@@ -128,6 +128,8 @@ struct Scratch {
   size_t ln_partial_floats;
   char* wgrad_ws;
   size_t wgrad_ws_bytes;
+  char* wgrad_ws_side;          // slab of the side-stream weight-gradient launches (sitk_encoder_bwd_overlap)
+  size_t wgrad_ws_side_bytes;
 };
 
 struct Layout {
@@ -204,6 +206,12 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
       L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype);
     if (L.scratch.wgrad_ws_bytes) L.scratch.wgrad_ws_bytes += (size_t)128 * 128 * 192 * 4;   // + the patch embedding's and the caller's extra tiles (sitk_encoder_bwd_extra)
     L.scratch.wgrad_ws = stake(L.scratch.wgrad_ws_bytes);
+    {
+      sitk_wgrad_desc wg8[8];
+      for (int i = 0; i < 8; ++i) wg8[i] = wg4[i % 4];
+      L.scratch.wgrad_ws_side_bytes = std::max(sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype), sitk_gemm_wgrad_group_ws_bytes(wg8, 8, c.dtype));
+    }
+    L.scratch.wgrad_ws_side = stake(L.scratch.wgrad_ws_side_bytes);
   }
   L.scratch.ln_partial_floats = sitk_layernorm_bwd_partial_floats((int64_t)R, (int)D);
   L.scratch.ln_partials = (float*)stake(L.scratch.ln_partial_floats * 4 * 2 * c.depth);   // one region per LayerNorm
@@ -407,6 +415,23 @@ extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_la
                                       void* dx_c, int* embed_done, const sitk_wgrad_desc* extra, int n_extra, int* extra_done,
                                       sitk_stream_t stream) {
   SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_bwd_extra, cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, embed, dx_c, embed_done, extra, n_extra, extra_done, stream);
+  return sitk_encoder_bwd_overlap(cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, embed, dx_c,
+                                  embed_done, extra, n_extra, extra_done, nullptr, stream);
+}
+
+// accessors of the overlap object (core.hip, compiled once)
+extern "C" void* sitk_overlap_stream_(sitk_overlap* o);
+extern "C" void* sitk_overlap_event_(sitk_overlap* o, int i);
+extern "C" int sitk_overlap_layers_(const sitk_overlap* o);
+extern "C" int sitk_overlap_cus_(const sitk_overlap* o);
+
+SITK_F16_TWIN(sitk_encoder_bwd_overlap)
+extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
+                                        const float* x_in, float* dx, void* acts, size_t acts_bytes, void* scratch,
+                                        size_t scratch_bytes, int layer_begin, int layer_end, const sitk_wgrad_desc* embed,
+                                        void* dx_c, int* embed_done, const sitk_wgrad_desc* extra, int n_extra, int* extra_done,
+                                        sitk_overlap* overlap, sitk_stream_t stream) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_bwd_overlap, cfg, P, G, x_in, dx, acts, acts_bytes, scratch, scratch_bytes, layer_begin, layer_end, embed, dx_c, embed_done, extra, n_extra, extra_done, overlap, stream);
   if (embed_done) *embed_done = 0;
   if (extra_done) *extra_done = 0;
   SITK_TRY(check_cfg(cfg));
@@ -425,6 +450,12 @@ extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_la
   // B, LN1' reads B and writes A, so d(x_out) [A] and d(x_mid) [B] both survive until the layer's
   // four weight gradients run as ONE grouped launch.
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+  hipStream_t side = reinterpret_cast<hipStream_t>(sitk_overlap_stream_(overlap));
+  const int side_max = (overlap && S.wg_batch && S.wgrad_ws_side_bytes && !c.timeline)        // (a timeline times ONE stream)
+                           ? std::min(sitk_overlap_layers_(overlap), layer_end - layer_begin) : 0;
+  const int side_cus = sitk_overlap_cus_(overlap);
+  int n_side = 0;
+  std::vector<sitk_wgrad_desc> wg_side;
   std::vector<LnFinalizeEntry> ln_entries;
   ln_entries.reserve(2 * (layer_end - layer_begin));
   // slot of a layer's weight-gradient operands: its own when the slice's weight gradients are batched, else shared
@@ -502,7 +533,24 @@ extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_la
         wgrad_desc(R, D, I, dxBc, 0, a.o, G[l].wo, G[l].bo),
         wgrad_desc(R, 3 * I, D, dqkv, 0, a.h1, G[l].wqkv, nullptr),
     };
-    if (S.wg_batch) wg_all.insert(wg_all.end(), wg, wg + 4);       // launched once, after the slice's last layer
+    if (S.wg_batch && n_side < side_max) {
+      // This layer's weight gradients run beside the rest of the chain, on the side stream.  Two layers per launch: their 42
+      // tiles, each over ALL tokens, are one workgroup per idle CU -- no token split, so no slab traffic and no reduction
+      // launch (one layer at a time would be 21 tiles split in two: measured 190 us per layer against ~150 this way).
+      wg_side.insert(wg_side.end(), wg, wg + 4);
+      ++n_side;
+      if ((int)wg_side.size() == 8 || n_side == side_max) {
+        hipEvent_t ev = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, n_side - 1));
+        if (hipEventRecord(ev, hs) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) {
+          set_error("encoder_bwd_overlap: fork of the side stream failed");
+          return SITK_ERR_LAUNCH;
+        }
+        SITK_TRY(sitk_gemm_wgrad_group_ws_cus(wg_side.data(), (int)wg_side.size(), dt, S.wgrad_ws_side, S.wgrad_ws_side_bytes,
+                                              side_cus, side));
+        wg_side.clear();
+      }
+    }
+    else if (S.wg_batch) wg_all.insert(wg_all.end(), wg, wg + 4);       // launched once, after the slice's last layer
     else { SITK_TRY(sitk_gemm_wgrad_group_ws(wg, 4, dt, S.wgrad_ws, S.wgrad_ws_bytes, stream)); SITK_MARK("wgrad"); }
     float* part1 = S.ln_partials + (size_t)(2 * l) * S.ln_partial_floats;
     if (qkv_fused(c)) {
@@ -547,5 +595,12 @@ extern "C" int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_la
   // every LayerNorm parameter gradient of the slice in one reduction launch
   SITK_TRY(layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs));
   SITK_MARK("ln_finalize");
+  if (n_side > 0) {        // join: whatever follows on the caller's stream (the optimizer) sees the side stream's gradients
+    hipEvent_t ev = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, sitk_overlap_layers_(overlap)));
+    if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent(hs, ev, 0) != hipSuccess) {
+      set_error("encoder_bwd_overlap: join of the side stream failed");
+      return SITK_ERR_LAUNCH;
+    }
+  }
   return SITK_OK;
 }

@@ -306,26 +306,34 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
       }
     }
   }
+  // Bias gradient.  Each of the two token halves of the workgroup (wt) holds its own partial column sums: a tile over all
+  // tokens adds them to db with float atomics (two addends on a zeroed or already final value: the order cannot change
+  // the result bits ... of a two-term sum, fp addition being commutative); token-split tiles store them behind the tile
+  // slabs -- [block][wt][192] -- and the reduce kernel adds them in a fixed order.
+  float* bslab = slab + (size_t)gridDim.x * WB_TILE_ELEMS + ((size_t)bid * 2 + wt) * 192;
   if (biasP && fr == 0) {   // column sums of dY blocks on the P side: accb[i][jj] <-> n = p0 + wh*64 + 16i + 4fq + jj
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int n = p0 + wh * 64 + 16 * i + 4 * fq + jj;
-        if (n < P.cp) unsafeAtomicAdd(P.db + n, accb[i][jj]);
+        if (P.splits > 1) bslab[wh * 64 + 16 * i + 4 * fq + jj] = accb[i][jj];
+        else if (n < P.cp) unsafeAtomicAdd(P.db + n, accb[i][jj]);
       }
   }
   if (biasQ && fq == 0) {   // dY on the Q side: every row of the ones product holds the sums; row 0 = (fq 0, jj 0)
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
       const int n = q0 + 16 * j + fr;
-      if (n < P.cq) unsafeAtomicAdd(P.db + n, accb[j][0]);
+      if (P.splits > 1) bslab[16 * j + fr] = accb[j][0];
+      else if (n < P.cq) unsafeAtomicAdd(P.db + n, accb[j][0]);
     }
   }
 }
 
 // dW (+)= sum over the splits of a tile's slabs, honouring the orientation; one thread per 4 Q columns
-__global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, const float* __restrict__ slab, int total_tiles) {
+__global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, const float* __restrict__ slab, int total_tiles,
+                                                                 int total_blocks) {
   const int gt = blockIdx.y;  // global tile index over all problems
   int pi = 0, tbase = 0;
   for (int i = 0; i < grp.count; ++i) {
@@ -339,6 +347,23 @@ __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, cons
   const int t = blockIdx.x * 256 + threadIdx.x;          // 6144 threads per 128 x 192 tile, 4 elements each
   if (t * 4 >= WB_TILE_ELEMS) return;
   const size_t sbase = (size_t)(P.block_begin + tile) * WB_TILE_ELEMS, sstep = (size_t)P.tiles * WB_TILE_ELEMS;
+  // bias partials of the tile's splits ([block][token half][192], behind the tile slabs), summed in split order by the first
+  // 192 threads of the tiles that carry the bias (the same predicates as in the tile kernel)
+  if (P.db && t < 192 && ((!P.swapped && q0 == 0) || (P.swapped && p0 == 0))) {
+    const float* bs = slab + (size_t)total_blocks * WB_TILE_ELEMS;
+    const bool pside = !P.swapped;
+    const int n = (pside ? p0 : q0) + t;
+    if (t < (pside ? 128 : 192) && n < (pside ? P.cp : P.cq)) {
+      float b = 0.f;
+      // P side: both token halves of all four waves hold sums; Q side: only the waves with wh == 0 (token halves wt = 0, 1)
+      for (int sp = 0; sp < P.splits; ++sp) {
+        const size_t blk = (size_t)(P.block_begin + tile) + (size_t)sp * P.tiles;
+        b += bs[(blk * 2 + 0) * 192 + t];
+        b += bs[(blk * 2 + 1) * 192 + t];
+      }
+      P.db[n] += b;
+    }
+  }
   if (!P.swapped) {                                       // dW rows = P columns: 4 consecutive Q columns per thread
     const int e4 = t * 4, r = e4 / 192, c = e4 % 192;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -377,7 +402,7 @@ static bool wb_eligible(const sitk_wgrad_desc& d) {
   return align && plain && d.M >= 2048 && (d.K % 192 == 0 || d.N % 192 == 0);
 }
 
-static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks, int& tiles_total) {
+static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks, int& tiles_total, int cus = 256) {
   tiles_total = 0;
   for (int i = 0; i < count; ++i) {
     WbProblem& p = g.p[i];
@@ -411,18 +436,20 @@ static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks,
   // round: every tile is the same amount of work, so the launch takes ceil(blocks / 256) rounds; 2 - 4 token splits
   // shorten the rounds and fill the last one (config 3: 864 tiles = 3.4 rounds run as 4; split in two, 6.75 as 7:
   // -12 %), at the price of one slab write + read per block (~1.5 % of a block's operand bytes per split).
+  // cus < 256: the launch is meant to run BESIDE another kernel chain on the CUs that chain leaves idle (encoder.hip's side
+  // streams): it may occupy `cus` CUs, not the chip
   int many = 1;
-  if (tiles_total > 256) {
+  if (tiles_total > cus) {
     double best = 1e30;
     for (int sp = 1; sp <= 4; ++sp) {
-      const double rounds = (double)cdiv(tiles_total * sp, 256);
+      const double rounds = (double)cdiv(tiles_total * sp, cus);
       const double cost = rounds / sp * (1.0 + (sp > 1 ? 0.015 * sp : 0.0));
       if (cost < best - 1e-9) { best = cost; many = sp; }
     }
   }
   for (int i = 0; i < count; ++i) {
     WbProblem& p = g.p[i];
-    int splits = tiles_total > 256 ? many : std::max(1, 256 / tiles_total);
+    int splits = tiles_total > cus ? many : std::max(1, cus / tiles_total);
     splits = std::min(splits, std::max(1, p.M / 256));
     p.chunk = cdiv(cdiv(p.M, splits), 64) * 64;
     p.splits = cdiv(p.M, p.chunk);
@@ -445,14 +472,22 @@ extern "C" size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int c
   WbGroup g;
   int blocks, tiles;
   wb_plan(d, count, g, blocks, tiles);
-  return (size_t)blocks * WB_TILE_ELEMS * sizeof(float);
+  return (size_t)blocks * (WB_TILE_ELEMS + 2 * 192) * sizeof(float);      // tile slabs + bias partials of split tiles
 }
 
 SITK_F16_TWIN(sitk_gemm_wgrad_group_ws)
 extern "C" int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int dtype, void* ws, size_t ws_bytes,
                                         sitk_stream_t stream) {
   SITK_FORWARD_F16(dtype, sitk_gemm_wgrad_group_ws, d, count, dtype, ws, ws_bytes, stream);
+  return sitk_gemm_wgrad_group_ws_cus(d, count, dtype, ws, ws_bytes, 256, stream);
+}
+
+SITK_F16_TWIN(sitk_gemm_wgrad_group_ws_cus)
+extern "C" int sitk_gemm_wgrad_group_ws_cus(const sitk_wgrad_desc* d, int count, int dtype, void* ws, size_t ws_bytes, int cus,
+                                            sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_gemm_wgrad_group_ws_cus, d, count, dtype, ws, ws_bytes, cus, stream);
   SITK_REQUIRE(d != nullptr && count >= 1 && count <= WB_MAX_PROBLEMS, "gemm_wgrad_group_ws: 1..%d problems", WB_MAX_PROBLEMS);
+  SITK_REQUIRE(cus >= 1 && cus <= 256, "gemm_wgrad_group_ws: cus = %d (1..256)", cus);
   const size_t need = sitk_gemm_wgrad_group_ws_bytes(d, count, dtype);
   if (need == 0 || ws == nullptr || ws_bytes < need) {       // generic tiles, 4 problems per launch
     for (int i0 = 0; i0 < count; i0 += 4) SITK_TRY(sitk_gemm_wgrad_group(d + i0, std::min(4, count - i0), dtype, stream));
@@ -462,7 +497,7 @@ extern "C" int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int
     SITK_REQUIRE(d[i].dY && d[i].X && d[i].dW, "gemm_wgrad_group_ws: null operand in problem %d", i);
   WbGroup g;
   int blocks, tiles;
-  wb_plan(d, count, g, blocks, tiles);
+  wb_plan(d, count, g, blocks, tiles, cus);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(wgrad_big_kernel, dim3(blocks), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
   SITK_LAUNCH_CHECK("wgrad_big");
@@ -470,6 +505,6 @@ extern "C" int sitk_gemm_wgrad_group_ws(const sitk_wgrad_desc* d, int count, int
   for (int i = 0; i < count; ++i) any_split |= g.p[i].splits > 1;
   if (!any_split) return SITK_OK;                          // every tile covered all its tokens and went straight to dW
   hipLaunchKernelGGL(wgrad_big_reduce_kernel, dim3(WB_TILE_ELEMS / 4 / 256, tiles), dim3(256), 0, s, g,
-                     reinterpret_cast<const float*>(ws), tiles);
+                     reinterpret_cast<const float*>(ws), tiles, blocks);
   return check_launch("wgrad_big_reduce");
 }

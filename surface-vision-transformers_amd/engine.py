@@ -131,6 +131,14 @@ class TrainEngine:
                   zeroed by a fill at the start of the next step); False (default) -> the optimizer pass zeroes every
                   gradient it consumes (optimizer.zero_grad() of tools/train.py:288 folded into optimizer.step()).
 
+    wgrad_overlap: number of layers whose weight gradients run on a side stream BESIDE the rest of the backward chain, on
+                  the CUs its one-wave kernels leave idle (sitk_encoder_bwd_overlap); 0 = off.  Needs eager launches.
+    use_graph:    True = the step is replayed from hipGraph(s) (one per segment); False = eager launches.
+                  None (default) with wgrad_overlap None: the faster of the two forms measured for the configuration --
+                  eager + 7 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192), hipGraph
+                  replay without a side stream everywhere else (other widths, data parallelism: there the idle CUs belong
+                  to the gradient all-reduce).
+
     The learning rate (and Adam's step count) live in device memory: `set_lr()` takes effect in captured graphs too,
     so the schedulers of tools/pretrain.py:42-50 can drive the engine.  `load_dataset()` keeps a whole data set
     resident in HBM; `step(indices=...)` then assembles the batch on the GPU (tools/train.py:97-113,282).
@@ -138,7 +146,8 @@ class TrainEngine:
 
     def __init__(self, model, batch_size, *, task="regression", input_layout="surface", loss="mse", optimizer="sgd",
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
-                 process_group=None, bwd_slices=None, use_graph=True, device=None, normalise=None, keep_grads=False):
+                 process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
+                 wgrad_overlap=None):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -251,10 +260,28 @@ class TrainEngine:
             bwd_slices = 1 if self.world == 1 else min(3, tr.depth)
         bounds = [round(i * tr.depth / bwd_slices) for i in range(bwd_slices + 1)]
         self.slices = [(bounds[i], bounds[i + 1]) for i in range(bwd_slices)][::-1]
+        fused = self.dtype != rt.F32 and bool(rt.lib.sitk_mlp_fused_supported(self.D, tr.mlp_dim, self.dtype))
+        if wgrad_overlap is None:
+            # measured on MI355X (tiny, B = 64, eager launches): 2.56 ms without, 2.49 with 6 - 7 of 12 layers on the side
+            # stream, 2.55 with 8, 2.66 with 9 (the side stream then finishes after the chain's own tail launch)
+            wgrad_overlap = round(7 / 12 * tr.depth) if (use_graph is not True and fused and self.world == 1 and bwd_slices == 1) else 0
+        if wgrad_overlap > 0 and (self.world > 1 or bwd_slices != 1 or use_graph):
+            # A step with a forked side stream is enqueued eagerly: replayed from a hipGraph, ROCm 7.2 runs the two branches on
+            # two queues but the chain's own kernels then start late (2.82 ms per step against 2.49 eager; the host needs ~0.4
+            # ms to enqueue a step of 2.5 ms, so eager launches cost nothing: 2.54 against 2.55 ms without the side stream)
+            raise rt.SitkError("wgrad_overlap needs one GPU, one backward slice and eager launches (use_graph=False)")
+        self._overlap = rt.lib.sitk_overlap_create(int(wgrad_overlap), 42) if wgrad_overlap > 0 else None
+        if use_graph is None:
+            use_graph = not self._overlap
         self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices), len(self.slices))
         self.use_graph = use_graph
         self._graphs = None
         self._pending = []
+
+    def __del__(self):
+        ov, self._overlap = getattr(self, "_overlap", None), None
+        if ov:
+            rt.lib.sitk_overlap_destroy(ov)
 
     # ---------------------------------------------------------------------------------------------
     def _s(self):
@@ -380,7 +407,8 @@ class TrainEngine:
                                         N=self.K, K=self.D)]
             self._embed_wgrad_done, self._extra_wgrad_done = ops.encoder_bwd_embed(
                 self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, lb, le, self.tokens, self.fp.g(lin.weight),
-                self.fp.g(lin.bias), self.dx_c, self.P, extra=extra)   # written straight into the (D, K) gradient (tokens: zero pad to ld)
+                self.fp.g(lin.bias), self.dx_c, self.P, extra=extra,   # written straight into the (D, K) gradient (tokens: zero pad to ld)
+                overlap=self._overlap)
             return
         ops.encoder_bwd(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, layer_begin=lb, layer_end=le)
 

@@ -384,10 +384,12 @@ def wgrad_desc(dY, X, dW, db=None, M=None, N=None, K=None, dymap=None):
     return d
 
 
-def encoder_bwd_embed(cfg, params, grads, x_in, dx, acts, scratch, layer_begin, layer_end, tokens, dW, db, dx_c, P, extra=None):
+def encoder_bwd_embed(cfg, params, grads, x_in, dx, acts, scratch, layer_begin, layer_end, tokens, dW, db, dx_c, P, extra=None,
+                      overlap=None):
     """encoder_bwd with the patch embedding's weight gradient (dW (D, ld) fp32 += d(x_in)[rows 1..P]^T tokens, db) taken
     into the slice's one weight-gradient launch; `extra`: more WgradDesc problems for the same launch.  Returns
-    (embed taken, extra taken): what was not taken the caller runs itself (gemm_wgrad)."""
+    (embed taken, extra taken): what was not taken the caller runs itself (gemm_wgrad).  overlap: handle of
+    sitk_overlap_create -> the first finished layers' weight gradients run on its side stream beside the chain."""
     d = rt.WgradDesc()
     d.M, d.N, d.K = tokens.shape[0], dW.shape[0], dW.shape[1]
     d.dY, d.lddy, d.dy_is_f32, d.dymap = 0, dW.shape[0], 0, _rowmap((P, P + 1, 1))
@@ -396,10 +398,10 @@ def encoder_bwd_embed(cfg, params, grads, x_in, dx, acts, scratch, layer_begin, 
     done, xdone = C.c_int(0), C.c_int(0)
     extra = extra or []
     xarr = (rt.WgradDesc * max(1, len(extra)))(*extra)
-    rt.check(rt.lib.sitk_encoder_bwd_extra(C.byref(cfg), params, grads, x_in.data_ptr(), dx.data_ptr(), acts.data_ptr(),
-                                           acts.numel(), scratch.data_ptr(), scratch.numel(), layer_begin, layer_end,
-                                           C.byref(d), dx_c.data_ptr(), C.byref(done), xarr, len(extra), C.byref(xdone),
-                                           rt.stream_ptr()))
+    rt.check(rt.lib.sitk_encoder_bwd_overlap(C.byref(cfg), params, grads, x_in.data_ptr(), dx.data_ptr(), acts.data_ptr(),
+                                             acts.numel(), scratch.data_ptr(), scratch.numel(), layer_begin, layer_end,
+                                             C.byref(d), dx_c.data_ptr(), C.byref(done), xarr, len(extra), C.byref(xdone),
+                                             overlap, rt.stream_ptr()))
     return bool(done.value), bool(xdone.value)
 
 

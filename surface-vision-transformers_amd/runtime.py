@@ -75,6 +75,7 @@ _SIGS = {
     "sitk_gemm_wgrad_group": (C.c_int, [C.POINTER(WgradDesc), _I, _I, _P]),
     "sitk_gemm_wgrad_group_ws_bytes": (_Z, [C.POINTER(WgradDesc), _I, _I]),
     "sitk_gemm_wgrad_group_ws": (C.c_int, [C.POINTER(WgradDesc), _I, _I, _P, _Z, _P]),
+    "sitk_gemm_wgrad_group_ws_cus": (C.c_int, [C.POINTER(WgradDesc), _I, _I, _P, _Z, _I, _P]),
     "sitk_layernorm_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     "sitk_layernorm_bwd_partial_floats": (_Z, [_L, _I]),
     "sitk_layernorm_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
@@ -104,6 +105,11 @@ _SIGS = {
     "sitk_encoder_bwd_extra": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,
                                          _P, _Z, _P, _Z, _I, _I, C.POINTER(WgradDesc), _P, C.POINTER(C.c_int),
                                          C.POINTER(WgradDesc), _I, C.POINTER(C.c_int), _P]),
+    "sitk_overlap_create": (C.c_void_p, [_I, _I]),
+    "sitk_overlap_destroy": (None, [_P]),
+    "sitk_encoder_bwd_overlap": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,
+                                           _P, _Z, _P, _Z, _I, _I, C.POINTER(WgradDesc), _P, C.POINTER(C.c_int),
+                                           C.POINTER(WgradDesc), _I, C.POINTER(C.c_int), _P, _P]),
     "sitk_embed_cls_rows": (C.c_int, [_P, _P, _P, _I, _I, _I, _P]),
     "sitk_head_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sitk_head_ws_floats": (_Z, [_I, _I, _I]),

@@ -122,8 +122,9 @@ def test_mpp_engine_gradients_match_autograd_path(pk, dtype):
     assert all(np.isfinite(ls)) and np.mean(ls[-3:]) < np.mean(ls[:3]), ls
 
 
+@pytest.mark.parametrize("mode", ["graph", "side_stream"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_engine_bench_config_matches_autograd_path(pk, dtype):
+def test_engine_bench_config_matches_autograd_path(pk, dtype, mode):
     """BASELINE config 2 end to end, exactly as bench.py runs it: SiT-tiny, depth 12, B = 64, bf16, raw surfaces,
     one hipGraph per segment -- two steps against the autograd module path + torch.optim.SGD on the same batch
     (tools/train.py:280-291).  Compared: both losses and the parameter UPDATE (after - before) of every tensor."""
@@ -146,9 +147,14 @@ def test_engine_bench_config_matches_autograd_path(pk, dtype):
         loss.backward()
         opt.step()
         losses.append(float(loss))
-    eng = engine.TrainEngine(m2, B, input_layout="surface", lr=lr, momentum=0.9, use_graph=True)
+    # "graph": one hipGraph per step; "side_stream": bench.py's default form -- eager launches, the weight gradients of the
+    # first 7 finished layers on the engine's side stream beside the rest of backward (sitk_encoder_bwd_overlap)
+    eng = engine.TrainEngine(m2, B, input_layout="surface", lr=lr, momentum=0.9, use_graph=True if mode == "graph" else None)
     got = [float(eng.step(x, y)) for _ in range(2)]
-    assert eng._graphs, "the step must have been captured"
+    if mode == "graph":
+        assert eng._graphs and not eng._overlap, "the step must have been captured"
+    else:
+        assert eng._overlap and not eng.use_graph, "the default form of this configuration forks the side stream"
     check("engine/bench_tiny_b64", "loss", dtype, max(abs(a - b) / abs(b) for a, b in zip(got, losses)), "out")
     worst = (0.0, "")
     for (k, p), (_, q) in zip(m2.named_parameters(), m1.named_parameters()):
@@ -159,8 +165,9 @@ def test_engine_bench_config_matches_autograd_path(pk, dtype):
     assert eng.fp.still_flat()
 
 
+@pytest.mark.parametrize("mode", ["graph", "side_stream"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_engine_bench_config_is_bitwise_reproducible(pk, dtype):
+def test_engine_bench_config_is_bitwise_reproducible(pk, dtype, mode):
     """no float atomics on the bench path any more (the head's parameter gradients and the loss go
     through per-sample partial rows, d pos_embedding / d cls_token and the LayerNorm gradients through ordered sums, the
     weight gradients of the one-launch 12-layer slice write each tile once).  Two engines from the same weights, the
@@ -176,7 +183,9 @@ def test_engine_bench_config_is_bitwise_reproducible(pk, dtype):
     y = torch.randn((B,), device=DEV, generator=g) * 2 + 40
     runs = []
     for _ in range(2):
-        eng = engine.TrainEngine(copy.deepcopy(base), B, input_layout="surface", lr=0.01, momentum=0.9, use_graph=True)
+        eng = engine.TrainEngine(copy.deepcopy(base), B, input_layout="surface", lr=0.01, momentum=0.9,
+                                 use_graph=True if mode == "graph" else None)
+        assert bool(eng._overlap) == (mode == "side_stream")
         losses = [eng.step(x, y).clone() for _ in range(3)]
         torch.cuda.synchronize()
         runs.append((eng.fp.flat.clone(), torch.cat(losses)))
