@@ -104,15 +104,6 @@ def cpu_baseline(seconds=15.0):
                       f"({med * 1e3:.1f} ms/step), torch {torch.__version__} CPU"}
 
 
-def rt_overlap_layers(eng):
-    """layers whose weight gradients the engine runs on its side stream (0: none)"""
-    if not getattr(eng, "_overlap", None):
-        return 0
-    from sitk import runtime as rt
-    rt.lib.sitk_overlap_layers_.restype = int
-    return rt.lib.sitk_overlap_layers_(eng._overlap)
-
-
 def self_launch_command(n, argv):
     """`python bench.py --gpus N` typed bare: the one-rank-per-GPU launcher to start as a child process."""
     import socket
@@ -224,7 +215,7 @@ def main():
                                f"SGD(m=0.9), " + {"bf16": "bf16 MFMA / fp32 accumulate", "f16": "f16 MFMA / fp32 accumulate, loss-scaled backward",
                                                   "f32": "f32 MFMA (verification mode)"}[args.dtype],
                    "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph),
-                   "wgrad_overlap_layers": int(rt_overlap_layers(eng)),
+                   "wgrad_overlap_layers": int(eng.wgrad_overlap),
                    "loss_after": round(loss, 6)},
         "step_gflop_per_sample": round(gf, 3),
         "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),

@@ -317,7 +317,11 @@ size_t sitk_encoder_acts_bytes(const sitk_encoder_cfg* cfg);
 size_t sitk_encoder_scratch_bytes(const sitk_encoder_cfg* cfg);
 
 /* x_in (B*N, dim) fp32 -> x_out (B*N, dim) fp32.  save_for_backward = 0 runs the forward-only
- * (inference) schedule that keeps no activations (acts then only needs the staged weights).   */
+ * (inference) schedule that keeps no activations (acts then only needs the staged weights).
+ * save_for_backward bit 1 (value 2 or 3): the compute-dtype weight copies in `acts` are already current -- the caller ran
+ * sitk_encoder_stage_weights (e.g. on a side stream, beside the gather and the patch embedding) since the last update. */
+int sitk_encoder_stage_weights(const sitk_encoder_cfg* cfg, const sitk_layer_params* params, void* acts, size_t acts_bytes,
+                               sitk_stream_t stream);
 int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* params, const float* x_in,
                      float* x_out, void* acts, size_t acts_bytes, void* scratch, size_t scratch_bytes,
                      int save_for_backward, sitk_stream_t stream);
@@ -358,8 +362,18 @@ int sitk_encoder_bwd_extra(const sitk_encoder_cfg* cfg, const sitk_layer_params*
  * the chain as before.  The object owns one non-blocking HIP stream and layers + 1 events; one object per engine (not
  * re-entrant: two concurrent calls must not share it).  overlap == NULL: sitk_encoder_bwd_extra.                     */
 typedef struct sitk_overlap sitk_overlap;
-sitk_overlap* sitk_overlap_create(int max_layers, int cus);
+sitk_overlap* sitk_overlap_create(int max_layers, int cus, int caller_joins);
 void sitk_overlap_destroy(sitk_overlap* o);
+/* The side stream for the caller's own use: sitk_overlap_fork makes it wait for everything enqueued on `stream` so far,
+ * sitk_overlap_join makes `stream` wait for everything enqueued on the side stream so far; between the two the caller
+ * passes sitk_overlap_stream(o) as the stream argument of any entry point whose work may run beside `stream`'s (the
+ * engine: weight staging beside the gather + patch embedding; d pos_embedding / d cls_token beside the last
+ * weight-gradient launch).  caller_joins != 0 at creation: sitk_encoder_bwd_overlap does NOT join at its end -- it
+ * leaves the side stream behind the chain's last kernel and its own side launches (the LayerNorm parameter-gradient
+ * reduction runs there), and the caller joins (sitk_overlap_join) before anything reads a gradient.                 */
+sitk_stream_t sitk_overlap_stream(sitk_overlap* o);
+int sitk_overlap_fork(sitk_overlap* o, sitk_stream_t stream);
+int sitk_overlap_join(sitk_overlap* o, sitk_stream_t stream);
 int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* params,
                              const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
                              size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,

@@ -300,6 +300,17 @@ extern "C" size_t sitk_encoder_scratch_bytes(const sitk_encoder_cfg* cfg) {
   return make_layout(*cfg, nullptr, nullptr).scratch_bytes;
 }
 
+SITK_F16_TWIN(sitk_encoder_stage_weights)
+extern "C" int sitk_encoder_stage_weights(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, void* acts, size_t acts_bytes,
+                                          sitk_stream_t stream) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_stage_weights, cfg, P, acts, acts_bytes, stream);
+  SITK_TRY(check_cfg(cfg));
+  SITK_REQUIRE(P && acts, "encoder_stage_weights: null pointer");
+  Layout L = make_layout(*cfg, (char*)acts, nullptr);
+  SITK_REQUIRE(acts_bytes >= L.acts_bytes, "encoder_stage_weights: acts workspace %zu < %zu", acts_bytes, L.acts_bytes);
+  return stage_all(*cfg, P, L, reinterpret_cast<hipStream_t>(stream));
+}
+
 SITK_F16_TWIN(sitk_encoder_fwd)
 extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const float* x_in, float* x_out,
                                 void* acts, size_t acts_bytes, void* scratch, size_t scratch_bytes, int save, sitk_stream_t stream) {
@@ -316,8 +327,9 @@ extern "C" int sitk_encoder_fwd(const sitk_encoder_cfg* cfg, const sitk_layer_pa
   const float scale = 0.125f;  // dim_head ** -0.5, dim_head = 64
 
   SITK_MARK("begin");
-  SITK_TRY(stage_all(c, P, L, s));
+  if (!(save & 2)) SITK_TRY(stage_all(c, P, L, s));
   SITK_MARK("stage_weights");
+  save &= 1;
 
   const float* x = x_in;
   bool have_qkv = false;   // the previous block's fused kernel already produced this block's h1 / statistics / qkv
@@ -424,6 +436,7 @@ extern "C" void* sitk_overlap_stream_(sitk_overlap* o);
 extern "C" void* sitk_overlap_event_(sitk_overlap* o, int i);
 extern "C" int sitk_overlap_layers_(const sitk_overlap* o);
 extern "C" int sitk_overlap_cus_(const sitk_overlap* o);
+extern "C" int sitk_overlap_caller_joins_(const sitk_overlap* o);
 
 SITK_F16_TWIN(sitk_encoder_bwd_overlap)
 extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
@@ -567,6 +580,12 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
       ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, 0});
     }
   }
+  hipEvent_t ev_chain = nullptr;
+  const bool use_side = overlap != nullptr;     // (the caller of a caller_joins object relies on the fork below, side launches or not)
+  if (use_side) {            // the chain is complete here: everything behind this point may run beside the tail launch
+    ev_chain = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, sitk_overlap_layers_(overlap)));
+    if (hipEventRecord(ev_chain, hs) != hipSuccess) { set_error("encoder_bwd_overlap: event record failed"); return SITK_ERR_LAUNCH; }
+  }
   // The weight (+ bias) gradients of every layer of the slice in ONE launch: nothing downstream of a layer reads
   // its parameter gradients, and with 21 tiles per layer a whole slice brings enough tiles to give each workgroup
   // a long token run (12 layers: 252 tiles = one tile over ALL tokens per workgroup -- no token split, one slab
@@ -592,15 +611,21 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
     SITK_TRY(sitk_gemm_wgrad_group_ws(wg_all.data(), (int)wg_all.size(), dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
     SITK_MARK("wgrad");
   }
-  // every LayerNorm parameter gradient of the slice in one reduction launch
-  SITK_TRY(layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs));
-  SITK_MARK("ln_finalize");
-  if (n_side > 0) {        // join: whatever follows on the caller's stream (the optimizer) sees the side stream's gradients
-    hipEvent_t ev = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, sitk_overlap_layers_(overlap)));
-    if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent(hs, ev, 0) != hipSuccess) {
-      set_error("encoder_bwd_overlap: join of the side stream failed");
-      return SITK_ERR_LAUNCH;
+  // every LayerNorm parameter gradient of the slice in one reduction launch; with a side stream it runs there, behind the
+  // chain's last kernel (event ev_chain, recorded in front of the tail weight-gradient launch) and beside that launch
+  if (use_side) {
+    if (hipStreamWaitEvent(side, ev_chain, 0) != hipSuccess) { set_error("encoder_bwd_overlap: fork of the side stream failed"); return SITK_ERR_LAUNCH; }
+    SITK_TRY(layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, side));
+    if (!sitk_overlap_caller_joins_(overlap)) {   // join: whatever follows on the caller's stream sees the side stream's gradients
+      hipEvent_t ev = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, sitk_overlap_layers_(overlap)));
+      if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent(hs, ev, 0) != hipSuccess) {
+        set_error("encoder_bwd_overlap: join of the side stream failed");
+        return SITK_ERR_LAUNCH;
+      }
     }
+  } else {
+    SITK_TRY(layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, hs));
+    SITK_MARK("ln_finalize");
   }
   return SITK_OK;
 }

@@ -93,14 +93,20 @@ struct HeadWs {
   }
 };
 
-__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ ws, int B, int D, int C,
+__global__ __launch_bounds__(64) void head_finalize_kernel(const float* __restrict__ ws, int B, int D, int C,
                                                             float* __restrict__ d_b, float* __restrict__ d_w,
                                                             float* __restrict__ d_ln_w, float* __restrict__ d_ln_b,
                                                             float* __restrict__ loss) {
-  const int W = head_ws_width(D, C), WS = head_ws_sums(D, C), c = blockIdx.x * 256 + threadIdx.x;
+  const int W = head_ws_width(D, C), WS = head_ws_sums(D, C), c = blockIdx.x * 64 + threadIdx.x;
   if (c >= WS) return;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += ws[(size_t)b * W + c];          // fixed order
+  for (int b0 = 0; b0 < B; b0 += 16) {                             // 16 independent loads in flight, added in sample order
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = b0 + i < B ? ws[(size_t)(b0 + i) * W + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+  }
   if (c < C) d_b[c] += s;
   else if (c < C + C * D) d_w[c - C] += s;
   else if (c < C + C * D + D) d_ln_w[c - C - C * D] += s;
@@ -672,7 +678,7 @@ extern "C" int sitk_head_bwd(const float* x, const float* ln_w, const float* ln_
                      D, n_classes, pool_mean, ws);
   SITK_LAUNCH_CHECK("head_bwd");
   if (ws) {
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 256)), dim3(256), 0, s, ws, B, D,
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 64)), dim3(64), 0, s, ws, B, D,
                        n_classes, d_b, d_w, d_ln_w, d_ln_b, (float*)nullptr);
     SITK_LAUNCH_CHECK("head_finalize");
   }
@@ -716,7 +722,7 @@ extern "C" int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const f
   }
   SITK_LAUNCH_CHECK("head_loss_fwd_bwd");
   if (ws) {
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 256)), dim3(256), 0, s, ws, B, D,
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 64)), dim3(64), 0, s, ws, B, D,
                        n_classes, d_b, d_w, d_ln_w, d_ln_b, loss);
     SITK_LAUNCH_CHECK("head_finalize");
   }

@@ -357,7 +357,7 @@ static int dispatch_ln_bwd(const void* dy, const float* x, const float* mean, co
 #undef SITK_LN_BWD
   SITK_LAUNCH_CHECK("layernorm_bwd");
   if (partials && finalize) {
-    if (grid > 512) hipLaunchKernelGGL(ln_finalize_kernel<16>, dim3(cdiv(2 * D, 16)), dim3(256), 0, s, partials, grid, D, dg, db);
+    if (grid > 64) hipLaunchKernelGGL(ln_finalize_kernel<16>, dim3(cdiv(2 * D, 16)), dim3(256), 0, s, partials, grid, D, dg, db);
     else hipLaunchKernelGGL(ln_finalize_kernel<64>, dim3(cdiv(2 * D, 64)), dim3(256), 0, s, partials, grid, D, dg, db);
     SITK_LAUNCH_CHECK("layernorm_bwd_finalize");
   }
@@ -381,7 +381,7 @@ int layernorm_finalize_multi(const LnFinalizeEntry* entries, int count, int64_t 
     for (int i = 0; i < n; ++i) b.e[i] = entries[i0 + i];
     int most = 0;
     for (int i = 0; i < n; ++i) most = std::max(most, b.e[i].nblocks > 0 ? b.e[i].nblocks : grid);
-    if (most > 512) hipLaunchKernelGGL(ln_finalize_multi_kernel<16>, dim3(cdiv(2 * D, 16), 1, n), dim3(256), 0, s, b, grid, D);
+    if (most > 64) hipLaunchKernelGGL(ln_finalize_multi_kernel<16>, dim3(cdiv(2 * D, 16), 1, n), dim3(256), 0, s, b, grid, D);
     else hipLaunchKernelGGL(ln_finalize_multi_kernel<64>, dim3(cdiv(2 * D, 64), 1, n), dim3(256), 0, s, b, grid, D);
     SITK_LAUNCH_CHECK("layernorm_finalize_multi");
   }

@@ -270,7 +270,9 @@ class TrainEngine:
             # two queues but the chain's own kernels then start late (2.82 ms per step against 2.49 eager; the host needs ~0.4
             # ms to enqueue a step of 2.5 ms, so eager launches cost nothing: 2.54 against 2.55 ms without the side stream)
             raise rt.SitkError("wgrad_overlap needs one GPU, one backward slice and eager launches (use_graph=False)")
-        self._overlap = rt.lib.sitk_overlap_create(int(wgrad_overlap), 42) if wgrad_overlap > 0 else None
+        self.wgrad_overlap = int(wgrad_overlap)
+        self._overlap = rt.lib.sitk_overlap_create(int(wgrad_overlap), 42, 1) if wgrad_overlap > 0 else None
+        self._side = rt.lib.sitk_overlap_stream(self._overlap) if self._overlap else None
         if use_graph is None:
             use_graph = not self._overlap
         self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices), len(self.slices))
@@ -287,18 +289,34 @@ class TrainEngine:
     def _s(self):
         return rt.stream_ptr()
 
+    def _stage_beside(self):
+        """With a side stream: the compute-dtype weight copies of all layers (one launch, ~16 us) are staged THERE, beside the
+        gather and the patch embedding on the main stream; _encoder_forward joins.  Returns the `save` flags of the forward."""
+        if not self._overlap:
+            return 1
+        rt.check(rt.lib.sitk_overlap_fork(self._overlap, self._s()))     # behind the previous step's optimizer pass
+        rt.check(rt.lib.sitk_encoder_stage_weights(C.byref(self.cfg), self.Pa, self.acts.data_ptr(), self.acts.numel(), self._side))
+        return 3
+
+    def _encoder_forward(self, save):
+        if self._overlap:
+            rt.check(rt.lib.sitk_overlap_join(self._overlap, self._s()))
+        rt.check(rt.lib.sitk_encoder_fwd(C.byref(self.cfg), self.Pa, self.x0.data_ptr(), self.xL.data_ptr(), self.acts.data_ptr(),
+                                         self.acts.numel(), self.scratch.data_ptr(), self.scratch.numel(), save, self._s()))
+
     def _forward_regression(self):
         sit, L, s = self.sit, rt.lib, self._s()
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
         lin = sit.to_patch_embedding[1]
         if self.keep_grads:
             self.fp.grad_all.zero_()                    # gradients + loss + padded embedding gradient
+        save = self._stage_beside()
         if self.layout == "surface":
             self._gather(self.tokens, ld, dt)
         else:
             rt.check(L.sitk_patchify(self.inp.data_ptr(), self.tokens.data_ptr(), B, self.Cc, P, self.V, ld, dt, s))
         self._embed_forward(self.tokens)
-        ops.encoder_fwd(self.cfg, self.Pa, self.x0, self.xL, self.acts, self.scratch, save=True)
+        self._encoder_forward(save)
         ln, fc = sit.mlp_head[0], sit.mlp_head[1]
         g = self.fp.g
         # pool + head + loss + their backward: one launch (dx = d(loss)/d(x_L) for every row comes out of it)
@@ -347,14 +365,19 @@ class TrainEngine:
             ops.gemm_wgrad(self.dx, tokens, self.dW_embed, dt, db=g(lin.bias), M=B * P, N=D, K=ld, dymap=(P, N, 1))
             g(lin.weight).copy_(self.dW_embed[:, :K])
         gpos = g(sit.pos_embedding).view(-1)[:N * D]
+        # d pos_embedding / d cls_token: column sums of the chain's final dx.  With a side stream (which
+        # sitk_encoder_bwd_overlap left behind the chain's last kernel) they run beside the tail weight-gradient launch.
         rt.check(rt.lib.sitk_colsum_f32_dup(self.dx.data_ptr(), B, N * D, N * D, gpos.data_ptr(),
-                                            g(sit.cls_token).data_ptr(), D, self._s()))
+                                            g(sit.cls_token).data_ptr(), D, self._side if self._overlap else self._s()))
+        if self._overlap:
+            rt.check(rt.lib.sitk_overlap_join(self._overlap, self._s()))      # every gradient of the step is behind this point
 
     def _forward_mpp(self):
         ssl, sit, L, s = self.ssl, self.sit, rt.lib, self._s()
         B, P, N, D, K, ld, dt = self.B, self.P, self.N, self.D, self.K, self.ld, self.dtype
         if self.keep_grads:
             self.fp.grad_all.zero_()                    # gradients + loss + padded embedding gradient + rsum
+        save = self._stage_beside()
         # the four random tensors of models/mpp.py:25-43,95-110 are drawn on the device (Philox; same distribution, not the
         # reference's stream: the parity path replays the reference's generator order through sitk.models.mpp instead)
         p_swap = ssl.swap_prob / (1 - ssl.replace_prob) if ssl.swap_prob > 0 else 0.0
@@ -378,7 +401,7 @@ class TrainEngine:
                                         self.repl.data_ptr(), mt, self.tokens.data_ptr(), B, P, K, ld, dt, s))
             self.rng_state[1:2] += 1
         self._embed_forward(self.tokens)
-        ops.encoder_fwd(self.cfg, self.Pa, self.x0, self.xL, self.acts, self.scratch, save=True)
+        self._encoder_forward(save)
         # to_original on tokens 1..P (models/mpp.py:129) and masked MSE (models/mpp.py:132)
         lo = ssl.to_original
         rt.check(L.sitk_stage_weight(lo.weight.data_ptr(), K, D, self.wo_c.data_ptr(), D, self.wo_t.data_ptr(),

@@ -105,7 +105,11 @@ _SIGS = {
     "sitk_encoder_bwd_extra": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,
                                          _P, _Z, _P, _Z, _I, _I, C.POINTER(WgradDesc), _P, C.POINTER(C.c_int),
                                          C.POINTER(WgradDesc), _I, C.POINTER(C.c_int), _P]),
-    "sitk_overlap_create": (C.c_void_p, [_I, _I]),
+    "sitk_overlap_create": (C.c_void_p, [_I, _I, _I]),
+    "sitk_overlap_stream": (C.c_void_p, [_P]),
+    "sitk_overlap_fork": (C.c_int, [_P, _P]),
+    "sitk_overlap_join": (C.c_int, [_P, _P]),
+    "sitk_encoder_stage_weights": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), _P, _Z, _P]),
     "sitk_overlap_destroy": (None, [_P]),
     "sitk_encoder_bwd_overlap": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,
                                            _P, _Z, _P, _Z, _I, _I, C.POINTER(WgradDesc), _P, C.POINTER(C.c_int),
