@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--wgrad-overlap", type=int, default=None,
                     help="layers whose weight gradients run on a side stream beside the backward chain (default: engine's choice)")
+    ap.add_argument("--dp-form", action="store_true",
+                    help="N = 1 only: run the DATA-PARALLEL form of the step (3 backward slices, one hipGraph per segment, every bucket "
+                         "all-reduced over a ONE-rank RCCL group) -- what each rank of an N > 1 run executes, minus the wire time")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (gloo: rehearsal of the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
@@ -148,8 +151,12 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device(f"cuda:{local_dev}")
     pg = None
-    if world > 1:
+    if world > 1 or args.dp_form:
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # Every kernel of the main chain is ONE wave of workgroups that each own a CU's LDS (214 of the 256 CUs, 192 in
         # attention): the all-reduce that overlaps backward has to fit in the CUs they leave idle, or each overlapped
@@ -214,7 +221,8 @@ def main():
                                f"gather(B,40962,4) + fwd + {'masked MSE' if args.task == 'mpp' else 'MSE'} + bwd + "
                                f"SGD(m=0.9), " + {"bf16": "bf16 MFMA / fp32 accumulate", "f16": "f16 MFMA / fp32 accumulate, loss-scaled backward",
                                                   "f32": "f32 MFMA (verification mode)"}[args.dtype],
-                   "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": bool(eng.use_graph),
+                   "global_batch": B * world, "parallelism": f"dp{world}" + (" (data-parallel form on a one-rank RCCL group)" if args.dp_form and world == 1 else ""),
+                   "hip_graph": bool(eng.use_graph),
                    "wgrad_overlap_layers": int(eng.wgrad_overlap),
                    "loss_after": round(loss, 6)},
         "step_gflop_per_sample": round(gf, 3),
@@ -236,7 +244,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -190,7 +190,11 @@ class TrainEngine:
         self._replay_randoms = False
         self.pg = process_group
         self.world = 1 if process_group is None else torch.distributed.get_world_size(process_group)
-        self._unscale_in_place = keep_grads or self.world > 1
+        # the data-parallel form of the step (backward slices, bucketed all-reduce between captured segments): whenever a
+        # process group is given -- also a ONE-rank group, which runs every collective of that form on the real backend
+        # (the only way to put RCCL under the engine on a one-GPU box: tests/test_dp_gpu.py)
+        self.dp = process_group is not None
+        self._unscale_in_place = keep_grads or self.dp
         self.nsteps = 0
 
         self.fp = FlatParams(self.module, self.device, grad_extra=self.D * self.ld + 4 * _ALIGN + self.D)
@@ -257,15 +261,15 @@ class TrainEngine:
         if bwd_slices is None:
             # every extra slice costs ~35 us (its own weight-gradient launch and reduction: 2.77 / 2.82 / 2.86 / 2.89 ms per
             # step for 1 / 2 / 3 / 4 slices, SiT-tiny B = 64) and hides that fraction of the gradient all-reduce less
-            bwd_slices = 1 if self.world == 1 else min(3, tr.depth)
+            bwd_slices = 1 if not self.dp else min(3, tr.depth)
         bounds = [round(i * tr.depth / bwd_slices) for i in range(bwd_slices + 1)]
         self.slices = [(bounds[i], bounds[i + 1]) for i in range(bwd_slices)][::-1]
         fused = self.dtype != rt.F32 and bool(rt.lib.sitk_mlp_fused_supported(self.D, tr.mlp_dim, self.dtype))
         if wgrad_overlap is None:
             # measured on MI355X (tiny, B = 64, eager launches): 2.56 ms without, 2.49 with 6 - 7 of 12 layers on the side
             # stream, 2.55 with 8, 2.66 with 9 (the side stream then finishes after the chain's own tail launch)
-            wgrad_overlap = round(7 / 12 * tr.depth) if (use_graph is not True and fused and self.world == 1 and bwd_slices == 1) else 0
-        if wgrad_overlap > 0 and (self.world > 1 or bwd_slices != 1 or use_graph):
+            wgrad_overlap = round(7 / 12 * tr.depth) if (use_graph is not True and fused and not self.dp and bwd_slices == 1) else 0
+        if wgrad_overlap > 0 and (self.dp or bwd_slices != 1 or use_graph):
             # A step with a forked side stream is enqueued eagerly: replayed from a hipGraph, ROCm 7.2 runs the two branches on
             # two queues but the chain's own kernels then start late (2.82 ms per step against 2.49 eager; the host needs ~0.4
             # ms to enqueue a step of 2.5 ms, so eager launches cost nothing: 2.54 against 2.55 ms without the side stream)
@@ -522,7 +526,7 @@ class TrainEngine:
         return segs
 
     def _allreduce(self, lo, hi):
-        if self.world > 1:
+        if self.dp:
             if self.loss_scaled:                # every rank scaled by its own S: reduce unscaled gradients
                 self.fp.grad[lo:hi].mul_(self.gscale[1])
             self._pending.append(torch.distributed.all_reduce(self.fp.grad[lo:hi], group=self.pg, async_op=True))
@@ -602,7 +606,7 @@ class TrainEngine:
                                    "indices=, or call unload_dataset() first")
             self.load_batch(x, target)
         segs = self._segment_fns()
-        if self.world == 1:
+        if not self.dp:
             # one GPU: nothing happens between the segments -- the whole step is ONE graph (one replay per step)
             def whole():
                 for fn in segs:

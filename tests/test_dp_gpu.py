@@ -230,3 +230,57 @@ def test_bench_gpus_2_as_typed_prints_one_json_line():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+
+
+# ---- RCCL under the engine: a ONE-rank NCCL (= RCCL) group runs the data-parallel form of the step -- backward slices, one
+# hipGraph per segment, every bucket's all-reduce on the backend's own stream between the replays -- on the real backend
+def _rccl_worker(port, task, use_graph, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    from sitk import engine
+    x, y = _data()
+    if task == "mpp":
+        eng = engine.TrainEngine(_make_mpp("f32"), B, task="mpp", input_layout="patched", lr=LR, momentum=0.9,
+                                 process_group=dist.group.WORLD, bwd_slices=3, use_graph=use_graph, device="cuda:0")
+    else:
+        eng = engine.TrainEngine(_make_model("f32"), B, input_layout="patched", lr=LR, momentum=0.9,
+                                 process_group=dist.group.WORLD, bwd_slices=3, use_graph=use_graph, device="cuda:0")
+    assert eng.dp and len(eng.slices) == 3
+    draws = []
+    for _ in range(STEPS):
+        eng.step(x.cuda(), y.cuda() if task != "mpp" else None)
+        torch.cuda.synchronize()
+        if task == "mpp":
+            draws.append({k: v.cpu().numpy() for k, v in eng.last_randoms.items()})
+    q.put((eng.fp.flat.cpu().numpy(), draws))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("task,use_graph", [("regression", True), ("regression", False), ("mpp", True)])
+def test_one_rank_rccl_group_runs_the_data_parallel_step(task, use_graph):
+    import sitk  # noqa: F401
+    from sitk import engine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), task, use_graph, q))
+    p.start()
+    got, draws = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    x, y = _data()
+    if task == "mpp":
+        ref = engine.TrainEngine(_make_mpp("f32"), B, task="mpp", input_layout="patched", lr=LR, momentum=0.9, use_graph=False,
+                                 device="cuda:0")
+    else:
+        ref = engine.TrainEngine(_make_model("f32"), B, input_layout="patched", lr=LR, momentum=0.9, use_graph=False,
+                                 device="cuda:0")
+    for st in range(STEPS):
+        if task == "mpp":
+            ref.set_randoms(draws[st])
+        ref.step(x.cuda(), y.cuda() if task != "mpp" else None)
+    want = ref.fp.flat.cpu()
+    err = float((torch.from_numpy(got).double() - want.double()).norm() / want.double().norm())
+    assert err < 1e-6, err
