@@ -121,11 +121,11 @@ extern "C" int sitk_overlap_join(sitk_overlap* o, sitk_stream_t stream) {
   return SITK_OK;
 }
 // internal accessors for encoder.hip (both sets of objects)
-extern "C" int sitk_overlap_caller_joins_(const sitk_overlap* o) { return o ? o->caller_joins : 0; }
-extern "C" void* sitk_overlap_stream_(sitk_overlap* o) { return o ? (void*)o->side : nullptr; }
-extern "C" void* sitk_overlap_event_(sitk_overlap* o, int i) { return (o && i >= 0 && i < (int)o->ev.size()) ? (void*)o->ev[i] : nullptr; }
-extern "C" int sitk_overlap_layers_(const sitk_overlap* o) { return o ? o->layers : 0; }
-extern "C" int sitk_overlap_cus_(const sitk_overlap* o) { return o ? o->cus : 0; }
+extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_caller_joins_(const sitk_overlap* o) { return o ? o->caller_joins : 0; }
+extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_stream_(sitk_overlap* o) { return o ? (void*)o->side : nullptr; }
+extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_event_(sitk_overlap* o, int i) { return (o && i >= 0 && i < (int)o->ev.size()) ? (void*)o->ev[i] : nullptr; }
+extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_layers_(const sitk_overlap* o) { return o ? o->layers : 0; }
+extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_cus_(const sitk_overlap* o) { return o ? o->cus : 0; }
 
 extern "C" int sitk_abi_version(void) { return SITK_ABI_VERSION; }
 extern "C" const char* sitk_last_error(void) { return sitk_rt::g_err; }

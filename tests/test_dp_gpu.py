@@ -164,7 +164,9 @@ def test_two_rank_mpp_engine_matches_single_process_full_batch(use_graph, slices
         assert upd > 0, n
         if err / upd > worst[1]:
             worst = (n, err / upd)
-        assert err / upd < 2e-4, (n, err / upd)
+        # relative to the UPDATE, plus two units in the last place of the parameter itself (a LayerNorm weight of ~1 that moved by
+        # 4e-4 cannot agree better than its own fp32 spacing, 1.2e-7)
+        assert err < 2e-4 * upd + 2.4e-7 * float(want.norm()), (n, err / upd)
     print("worst update-relative error:", worst)
 
 

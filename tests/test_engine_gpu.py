@@ -382,3 +382,37 @@ def test_resident_dataset_pipeline(pk):
             assert abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l1)), (float(l1), float(l2))
         assert rel(e2.fp.flat, e1.fp.flat) < 1e-6        # same tokens bit for bit; float atomics in the loss / column sums
         assert torch.equal(e2.target.cpu(), torch.from_numpy(labels[picks[-1]]))
+
+
+@pytest.mark.parametrize("tscale", [1e-4, 1.0, 1e4])
+def test_f16_loss_scale_follows_the_batch(pk, tscale):
+    """f16 compute mode: the gradient stream is scaled by a power of two the fused head + loss call picks from THIS batch's
+    largest |d loss / d logits| (tests of the mode at ordinary magnitudes are above).  Targets 1e-4 .. 1e4 of the ordinary
+    size move that gradient over eight decades -- far outside what a fixed scale and IEEE half's 5 exponent bits could
+    carry -- and the gradients must still match the f32-mode engine; the published scale puts the batch maximum in [64, 128)."""
+    sit, _, engine = pk
+    B = 4
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=2, num_patches=320, num_vertices=153, num_channels=4)
+    base = sit.SiT(**kw, compute_dtype="f32")
+    _load(base, 11)
+    x = torch.from_numpy(detgen.normal("ls/x", (B, 4, 320, 153), seed=1)).to(DEV)
+    # (targets of ONE sign: with mixed signs the samples' loss gradients cancel in the batch sum -- y = -2, -5, -10, +15 leaves a
+    # twentieth of the terms -- and every mode's relative gradient error grows by that factor, bf16's and f16's alike)
+    y = -(1.0 + torch.from_numpy(detgen.normal("ls/y", (B,), seed=1)).to(DEV).abs()) * tscale
+    grads = {}
+    for dtype in ("f32", "f16"):
+        m = sit.SiT(**kw, compute_dtype=dtype)
+        m.load_state_dict(base.state_dict())
+        eng = engine.TrainEngine(m, B, input_layout="patched", lr=0.0, momentum=0.0, use_graph=False, keep_grads=True)
+        loss = float(eng.step(x, y))
+        assert np.isfinite(loss)
+        grads[dtype] = (loss, {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        if dtype == "f16":
+            S = float(eng.gscale[0])
+            dl_max = float((2.0 * (eng.logits.view(-1) - y) / B).abs().max())
+            assert S == 2.0 ** round(np.log2(S)) and 64.0 <= dl_max * S < 128.0, (S, dl_max)
+    assert abs(grads["f16"][0] - grads["f32"][0]) <= 1e-3 * abs(grads["f32"][0])
+    worst = max((rel(grads["f16"][1][k], g), k) for k, g in grads["f32"][1].items())
+    print("worst gradient:", worst)
+    assert all(bool(torch.isfinite(g).all()) for g in grads["f16"][1].values())
+    assert worst[0] < 2e-3, worst
