@@ -163,7 +163,11 @@ def main():
         # kernel needs a second wave.  One RCCL channel = one workgroup; the 22 MB of gradients do not need more.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL's stream at HIGH priority: the runtime keeps streams of different priorities on different hardware queues, and
+            # the engine's data-parallel form makes this stream wait for its side stream -- on the main stream's queue that wait
+            # would stall the backward chain (measured with a one-rank group: 3.14 ms per step against 2.65)
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", device_id=dev, pg_options=opts)
         else:
             dist.init_process_group("gloo")
         pg = dist.group.WORLD

@@ -372,6 +372,9 @@ void sitk_overlap_destroy(sitk_overlap* o);
  * leaves the side stream behind the chain's last kernel and its own side launches (the LayerNorm parameter-gradient
  * reduction runs there), and the caller joins (sitk_overlap_join) before anything reads a gradient.                 */
 sitk_stream_t sitk_overlap_stream(sitk_overlap* o);
+/* how many layers the NEXT sitk_encoder_bwd_overlap call hands to the side stream (0 .. max_layers of the creation; a
+ * data-parallel caller sets the whole slice for every slice but the last) */
+int sitk_overlap_set_layers(sitk_overlap* o, int layers);
 int sitk_overlap_fork(sitk_overlap* o, sitk_stream_t stream);
 int sitk_overlap_join(sitk_overlap* o, sitk_stream_t stream);
 int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* params,

@@ -77,14 +77,25 @@ extern "C" int sitk_timeline_read(sitk_timeline* t, float* us, const char** labe
 // ---- overlap: a side stream and the events that tie it to the caller's stream (sitk.h) ----
 struct sitk_overlap {
   hipStream_t side = nullptr;
-  std::vector<hipEvent_t> ev;     // [0, layers): forks of sitk_encoder_bwd_overlap; layers: its join; layers + 1: sitk_overlap_fork / _join
-  int layers = 0, cus = 0, caller_joins = 0;
+  std::vector<hipEvent_t> ev;     // [0, max_layers): forks of sitk_encoder_bwd_overlap; max_layers: its chain / join event;
+                                  // max_layers + 1: sitk_overlap_fork / _join
+  int max_layers = 0, layers = 0, cus = 0, caller_joins = 0;
 };
 extern "C" sitk_overlap* sitk_overlap_create(int max_layers, int cus, int caller_joins) {
   if (max_layers < 1 || max_layers > 64 || cus < 1 || cus > 128) { sitk_rt::set_error("overlap: bad arguments"); return nullptr; }
   sitk_overlap* o = new sitk_overlap;
-  o->layers = max_layers; o->cus = cus; o->caller_joins = caller_joins != 0;
-  if (hipStreamCreateWithFlags(&o->side, hipStreamNonBlocking) != hipSuccess) { sitk_rt::set_error("overlap: hipStreamCreate failed"); delete o; return nullptr; }
+  o->max_layers = o->layers = max_layers; o->cus = cus; o->caller_joins = caller_joins != 0;
+  // LOWEST stream priority: (a) the runtime keeps streams of different priorities on different hardware queues -- a side stream of
+  // the default priority can land on the queue of the caller's stream (seen with RCCL's streams in the process: every kernel of
+  // the step on one queue, the "side" launches in line with the chain) --, (b) work beside the chain should never win a CU from it
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (hipStreamCreateWithPriority(&o->side, hipStreamNonBlocking, prio_least) != hipSuccess &&
+      hipStreamCreateWithFlags(&o->side, hipStreamNonBlocking) != hipSuccess) {
+    sitk_rt::set_error("overlap: hipStreamCreate failed");
+    delete o;
+    return nullptr;
+  }
   o->ev.resize(max_layers + 2);
   for (size_t i = 0; i < o->ev.size(); ++i)
     if (hipEventCreateWithFlags(&o->ev[i], hipEventDisableTiming) != hipSuccess) {
@@ -102,9 +113,14 @@ extern "C" void sitk_overlap_destroy(sitk_overlap* o) {
   delete o;
 }
 extern "C" sitk_stream_t sitk_overlap_stream(sitk_overlap* o) { return o ? (sitk_stream_t)o->side : nullptr; }
+extern "C" int sitk_overlap_set_layers(sitk_overlap* o, int layers) {
+  if (!o || layers < 0 || layers > o->max_layers) { sitk_rt::set_error("overlap_set_layers: 0..max_layers"); return SITK_ERR_INVALID; }
+  o->layers = layers;
+  return SITK_OK;
+}
 extern "C" int sitk_overlap_fork(sitk_overlap* o, sitk_stream_t stream) {
   if (!o) return SITK_ERR_INVALID;
-  hipEvent_t e = o->ev[o->layers + 1];
+  hipEvent_t e = o->ev[o->max_layers + 1];
   if (hipEventRecord(e, reinterpret_cast<hipStream_t>(stream)) != hipSuccess || hipStreamWaitEvent(o->side, e, 0) != hipSuccess) {
     sitk_rt::set_error("overlap: fork failed");
     return SITK_ERR_LAUNCH;
@@ -113,7 +129,7 @@ extern "C" int sitk_overlap_fork(sitk_overlap* o, sitk_stream_t stream) {
 }
 extern "C" int sitk_overlap_join(sitk_overlap* o, sitk_stream_t stream) {
   if (!o) return SITK_ERR_INVALID;
-  hipEvent_t e = o->ev[o->layers + 1];
+  hipEvent_t e = o->ev[o->max_layers + 1];
   if (hipEventRecord(e, o->side) != hipSuccess || hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), e, 0) != hipSuccess) {
     sitk_rt::set_error("overlap: join failed");
     return SITK_ERR_LAUNCH;
@@ -122,6 +138,7 @@ extern "C" int sitk_overlap_join(sitk_overlap* o, sitk_stream_t stream) {
 }
 // internal accessors for encoder.hip (both sets of objects)
 extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_caller_joins_(const sitk_overlap* o) { return o ? o->caller_joins : 0; }
+extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_max_layers_(const sitk_overlap* o) { return o ? o->max_layers : 0; }
 extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_stream_(sitk_overlap* o) { return o ? (void*)o->side : nullptr; }
 extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_event_(sitk_overlap* o, int i) { return (o && i >= 0 && i < (int)o->ev.size()) ? (void*)o->ev[i] : nullptr; }
 extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_layers_(const sitk_overlap* o) { return o ? o->layers : 0; }

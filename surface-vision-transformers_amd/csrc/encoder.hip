@@ -437,6 +437,7 @@ extern "C" void* sitk_overlap_event_(sitk_overlap* o, int i);
 extern "C" int sitk_overlap_layers_(const sitk_overlap* o);
 extern "C" int sitk_overlap_cus_(const sitk_overlap* o);
 extern "C" int sitk_overlap_caller_joins_(const sitk_overlap* o);
+extern "C" int sitk_overlap_max_layers_(const sitk_overlap* o);
 
 SITK_F16_TWIN(sitk_encoder_bwd_overlap)
 extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
@@ -583,7 +584,7 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
   hipEvent_t ev_chain = nullptr;
   const bool use_side = overlap != nullptr;     // (the caller of a caller_joins object relies on the fork below, side launches or not)
   if (use_side) {            // the chain is complete here: everything behind this point may run beside the tail launch
-    ev_chain = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, sitk_overlap_layers_(overlap)));
+    ev_chain = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, sitk_overlap_max_layers_(overlap)));
     if (hipEventRecord(ev_chain, hs) != hipSuccess) { set_error("encoder_bwd_overlap: event record failed"); return SITK_ERR_LAUNCH; }
   }
   // The weight (+ bias) gradients of every layer of the slice in ONE launch: nothing downstream of a layer reads
@@ -617,7 +618,7 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
     if (hipStreamWaitEvent(side, ev_chain, 0) != hipSuccess) { set_error("encoder_bwd_overlap: fork of the side stream failed"); return SITK_ERR_LAUNCH; }
     SITK_TRY(layernorm_finalize_multi(ln_entries.data(), (int)ln_entries.size(), R, D, side));
     if (!sitk_overlap_caller_joins_(overlap)) {   // join: whatever follows on the caller's stream sees the side stream's gradients
-      hipEvent_t ev = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, sitk_overlap_layers_(overlap)));
+      hipEvent_t ev = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, sitk_overlap_max_layers_(overlap)));
       if (hipEventRecord(ev, side) != hipSuccess || hipStreamWaitEvent(hs, ev, 0) != hipSuccess) {
         set_error("encoder_bwd_overlap: join of the side stream failed");
         return SITK_ERR_LAUNCH;

@@ -258,14 +258,27 @@ class TrainEngine:
             raise ValueError(optimizer)
 
         # backward slices (last layer first) and the gradient ranges that become final after each
+        fused = self.dtype != rt.F32 and bool(rt.lib.sitk_mlp_fused_supported(self.D, tr.mlp_dim, self.dtype))
+        # Data parallelism on the 16-bit fused path, eager launches (the default there): TWO slices -- the first 7 / 12 of the
+        # layers, whose weight gradients all go to the side stream beside the rest of the chain exactly as on one GPU, and the
+        # rest, whose weight gradients run on the main stream behind the chain.  The first slice's bucket is all-reduced from the
+        # side stream's context (the process group's stream then waits for the side stream, the main chain for nothing), the
+        # second behind the finish stage.
+        self.dp_side = bool(self.dp and fused and wgrad_overlap is None and use_graph is not True and bwd_slices is None
+                            and tr.depth >= 2)
+        if self.dp_side:
+            k = min(tr.depth - 1, max(1, round(7 / 12 * tr.depth)))
+            self.slices = [(tr.depth - k, tr.depth), (0, tr.depth - k)]
+            bwd_slices = 2
         if bwd_slices is None:
             # every extra slice costs ~35 us (its own weight-gradient launch and reduction: 2.77 / 2.82 / 2.86 / 2.89 ms per
             # step for 1 / 2 / 3 / 4 slices, SiT-tiny B = 64) and hides that fraction of the gradient all-reduce less
             bwd_slices = 1 if not self.dp else min(3, tr.depth)
-        bounds = [round(i * tr.depth / bwd_slices) for i in range(bwd_slices + 1)]
-        self.slices = [(bounds[i], bounds[i + 1]) for i in range(bwd_slices)][::-1]
-        fused = self.dtype != rt.F32 and bool(rt.lib.sitk_mlp_fused_supported(self.D, tr.mlp_dim, self.dtype))
-        if wgrad_overlap is None:
+        if not self.dp_side:
+            bounds = [round(i * tr.depth / bwd_slices) for i in range(bwd_slices + 1)]
+            self.slices = [(bounds[i], bounds[i + 1]) for i in range(bwd_slices)][::-1]
+        auto = wgrad_overlap is None
+        if auto:
             # measured on MI355X (tiny, B = 64, eager launches): 2.56 ms without, 2.49 with 6 - 7 of 12 layers on the side
             # stream, 2.55 with 8, 2.66 with 9 (the side stream then finishes after the chain's own tail launch)
             wgrad_overlap = round(7 / 12 * tr.depth) if (use_graph is not True and fused and not self.dp and bwd_slices == 1) else 0
@@ -274,9 +287,15 @@ class TrainEngine:
             # two queues but the chain's own kernels then start late (2.82 ms per step against 2.49 eager; the host needs ~0.4
             # ms to enqueue a step of 2.5 ms, so eager launches cost nothing: 2.54 against 2.55 ms without the side stream)
             raise rt.SitkError("wgrad_overlap needs one GPU, one backward slice and eager launches (use_graph=False)")
+        if self.dp_side:
+            wgrad_overlap = sum(le - lb for lb, le in self.slices[:-1])
+            max_side = max(le - lb for lb, le in self.slices)
+        else:
+            max_side = int(wgrad_overlap)
         self.wgrad_overlap = int(wgrad_overlap)
-        self._overlap = rt.lib.sitk_overlap_create(int(wgrad_overlap), 42, 1) if wgrad_overlap > 0 else None
+        self._overlap = rt.lib.sitk_overlap_create(max_side, 42, 1) if wgrad_overlap > 0 else None
         self._side = rt.lib.sitk_overlap_stream(self._overlap) if self._overlap else None
+        self._side_torch = torch.cuda.ExternalStream(self._side, device=self.device) if self.dp_side else None
         if use_graph is None:
             use_graph = not self._overlap
         self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices), len(self.slices))
@@ -426,6 +445,8 @@ class TrainEngine:
     def _backward_slice(self, lb, le):
         if lb == 0 and self.dx_c is not None:
             # the slice that ends at layer 0 also carries the patch embedding's weight gradient (one launch for all)
+            if self.dp_side:
+                rt.check(rt.lib.sitk_overlap_set_layers(self._overlap, 0))           # last slice: its weight gradients on the main stream
             lin = self.sit.to_patch_embedding[1]
             extra = None
             if self.task == "mpp":
@@ -436,6 +457,13 @@ class TrainEngine:
                 self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, lb, le, self.tokens, self.fp.g(lin.weight),
                 self.fp.g(lin.bias), self.dx_c, self.P, extra=extra,   # written straight into the (D, K) gradient (tokens: zero pad to ld)
                 overlap=self._overlap)
+            return
+        if self.dp_side:
+            rt.check(rt.lib.sitk_overlap_set_layers(self._overlap, le - lb))          # the whole slice beside the next slice's chain
+            rt.check(rt.lib.sitk_encoder_bwd_overlap(C.byref(self.cfg), self.Pa, self.Ga, self.x0.data_ptr(), self.dx.data_ptr(),
+                                                     self.acts.data_ptr(), self.acts.numel(), self.scratch.data_ptr(),
+                                                     self.scratch.numel(), lb, le, None, None, None, None, 0, None, self._overlap,
+                                                     self._s()))
             return
         ops.encoder_bwd(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, layer_begin=lb, layer_end=le)
 
@@ -620,9 +648,19 @@ class TrainEngine:
             return self.loss
         for i, fn in enumerate(segs):
             self._run(fn, i)
-            if i < len(segs) - 1:
+            if i < len(segs) - 1 and not self.dp_side:
                 for lo, hi in self.bucket_plan[i]:      # final now: reduce while the remaining slices run
                     self._allreduce(lo, hi)
+        if self.dp_side:
+            # The first slice's weight gradients and LayerNorm reduction are on the SIDE stream: its bucket is reduced from that
+            # stream's context (the process group's stream waits for the side stream).  Issued only now, behind the host's
+            # enqueue of the whole chain: should the process group's stream share a hardware queue with the main stream (ROCm
+            # maps streams of one priority onto few queues), its wait sits BEHIND the chain's launches in that queue instead of
+            # in front of them (issued right after the first slice it stalled the chain for 350 us: 3.14 ms per step).
+            with torch.cuda.stream(self._side_torch):
+                for i in range(len(segs) - 1):
+                    for lo, hi in self.bucket_plan[i]:
+                        self._allreduce(lo, hi)
         self._run(self._finish_backward, "finish")
         for lo, hi in self.bucket_plan[len(segs) - 1]:  # the last slice's gradients + everything `finish` wrote
             self._allreduce(lo, hi)

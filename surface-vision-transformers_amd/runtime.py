@@ -107,6 +107,7 @@ _SIGS = {
                                          C.POINTER(WgradDesc), _I, C.POINTER(C.c_int), _P]),
     "sitk_overlap_create": (C.c_void_p, [_I, _I, _I]),
     "sitk_overlap_stream": (C.c_void_p, [_P]),
+    "sitk_overlap_set_layers": (C.c_int, [_P, _I]),
     "sitk_overlap_fork": (C.c_int, [_P, _P]),
     "sitk_overlap_join": (C.c_int, [_P, _P]),
     "sitk_encoder_stage_weights": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), _P, _Z, _P]),

@@ -286,3 +286,72 @@ def test_one_rank_rccl_group_runs_the_data_parallel_step(task, use_graph):
     want = ref.fp.flat.cpu()
     err = float((torch.from_numpy(got).double() - want.double()).norm() / want.double().norm())
     assert err < 1e-6, err
+
+
+# ---- the data-parallel form WITH the side stream (16-bit fused path, the default there): two slices; the first one's weight
+# gradients run on the side stream and its bucket is all-reduced from that stream's context
+KW320 = dict(sit_oracle.MODEL_SIZES["tiny"], depth=4, num_patches=320, num_vertices=153, num_channels=4)
+B320 = 8          # 8 x 321 = 2 568 tokens: enough for the large-tile weight-gradient path the side stream uses
+LR320 = 0.002     # (a step size at which three steps of this model descend: at 0.05 the loss explodes and amplifies every rounding)
+
+
+def _make_model320(dtype):
+    import sitk  # noqa: F401
+    from sitk.models.sit import SiT
+    m = SiT(**KW320, compute_dtype=dtype)
+    vals = detgen.fill_state_dict(m.state_dict(), seed=19)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+    return m
+
+
+def _data320():
+    x = torch.from_numpy(detgen.normal("dps/x", (B320, 4, 320, 153), seed=1))
+    y = -(1.0 + torch.from_numpy(detgen.normal("dps/y", (B320,), seed=1)).abs())
+    return x, y
+
+
+def _rccl_side_worker(port, dtype, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    from sitk import engine
+    x, y = _data320()
+    eng = engine.TrainEngine(_make_model320(dtype), B320, input_layout="patched", lr=LR320, momentum=0.9,
+                             process_group=dist.group.WORLD, device="cuda:0")
+    assert eng.dp and eng.dp_side and not eng.use_graph and eng.slices == [(2, 4), (0, 2)] and eng.wgrad_overlap == 2
+    losses = []
+    for _ in range(3):
+        losses.append(float(eng.step(x.cuda(), y.cuda())))
+    torch.cuda.synchronize()
+    q.put((eng.fp.flat.cpu().numpy(), losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_one_rank_rccl_group_with_side_stream_matches_plain_engine(dtype):
+    import sitk  # noqa: F401
+    from sitk import engine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_side_worker, args=(_free_port(), dtype, q))
+    p.start()
+    got, losses = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    x, y = _data320()
+    model = _make_model320(dtype)
+    init = {n: t.detach().clone() for n, t in model.named_parameters()}
+    ref = engine.TrainEngine(model, B320, input_layout="patched", lr=LR320, momentum=0.9, use_graph=True, device="cuda:0")
+    want_losses = [float(ref.step(x.cuda(), y.cuda())) for _ in range(3)]
+    assert max(abs(a - b) / abs(b) for a, b in zip(losses, want_losses)) < 1e-4, (losses, want_losses)
+    got = torch.from_numpy(got)
+    for n, t in ref.module.named_parameters():
+        o, k = ref.fp.offsets[id(t)]
+        want = t.detach().cpu().double().reshape(-1)
+        upd = float((want - init[n].double().reshape(-1)).norm())
+        err = float((got[o:o + k].double() - want).norm())
+        # same operands, same kernels; the weight-gradient tiles sum their tokens in another order (whole-token tiles on the side
+        # stream against token-split tiles + slab) and three steps feed the differences back through 16-bit roundings
+        assert err < 2e-2 * upd + 2.4e-7 * float(want.norm()), (n, err / max(upd, 1e-30))

@@ -1,12 +1,13 @@
 #!/bin/bash
-# end-of-round collection on the GPU box: full check + kernel tables + PMC of the dominant kernels
-cd "$GRAFT_REPO_ROOT"
-tag=${1:-final}
-bash tools/gpu_run_all.sh $tag || exit 1
-bash tools/gpu_profile.sh r2_tiny_$tag > /dev/null || exit 1
-bash tools/gpu_profile.sh r2_mpp_tiny_$tag --task mpp > /dev/null || exit 1
-bash tools/gpu_profile.sh r2_cfg3_$tag --model small --patches 1280 --batch 32 > /dev/null || exit 1
-bash tools/gpu_pmc2.sh block_tail_12w "mlp_kernel<false" tools/kbench.py proj_mlp_next_fwd --reps 5 > /dev/null 2>&1
-bash tools/gpu_pmc2.sh mlp_bwd_12w "mlp_kernel<true" tools/kbench.py mlp_bwd --reps 5 > /dev/null 2>&1
-bash tools/gpu_pmc2.sh attn_fwd_res "attn_fwd_res" tools/kbench.py attn_fwd --reps 5 > /dev/null 2>&1
-echo DONE
+# end-of-round check: full GPU test suite, smoke, the bench lines, one kernel-trace timeline of the default step
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/r3_tests_final.log 2>&1; rc=$?
+tail -3 gpurun_out/r3_tests_final.log
+[ $rc -eq 124 ] && exit 124
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r3_smoke.log 2>&1; tail -3 gpurun_out/r3_smoke.log
+bash tools/gpu_bench4.sh final
+rm -rf gpurun_out/prof_ovf
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_ovf -- python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-probe > gpurun_out/prof_ovf.log 2>&1 || { tail -5 gpurun_out/prof_ovf.log; exit 1; }
+f=$(ls gpurun_out/prof_ovf/*/*_kernel_trace.csv | head -1)
+python tools/trace_step_timeline.py "$f" "wgrad|ln_finalize|mlp_kernel<true|stage_weights|gather_tokens|colsum|sgd_dev|head_" > gpurun_out/r03_overlap_timeline.txt
+rm -rf gpurun_out/prof_ovf
