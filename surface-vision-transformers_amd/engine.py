@@ -305,7 +305,7 @@ class TrainEngine:
 
     def __del__(self):
         ov, self._overlap = getattr(self, "_overlap", None), None
-        if ov:
+        if ov and rt is not None and getattr(rt, "lib", None) is not None:      # (module globals may be gone at interpreter exit)
             rt.lib.sitk_overlap_destroy(ov)
 
     # ---------------------------------------------------------------------------------------------
