@@ -466,6 +466,19 @@ int sitk_masked_colsum(const void* in, int ld, int in_is_f32, int dtype, const u
                        const uint8_t* flag_b, int64_t rows, int cols, float* out, sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Dropout and GELU as stand-alone fp32 elementwise kernels: the UNFUSED encoder path the Python mirror takes when the
+ * reference's `dropout` constructor argument (models/sit.py:36,57 -> vit_pytorch Attention.to_out.1, FeedForward.net.2 /
+ * net.4) is > 0 in training mode.  Every reference configuration uses 0.0 (config/SiT/training/hparams.yml:46).
+ *   dropout_fwd: y = res + x * keep / (1 - p) (res may be NULL), keep ~ Bernoulli(1 - p) from a Philox4x32-10 stream
+ *                (state = {seed, draws so far} in device memory, advanced by the call); mask (n) uint8 kept for backward.
+ *   dropout_bwd: dx = dy * mask / (1 - p).       gelu: exact erf (nn.GELU()).                               */
+int sitk_dropout_fwd(const float* x, const float* res, float* y, uint8_t* mask, int64_t n, float p, uint64_t* state,
+                     sitk_stream_t stream);
+int sitk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, sitk_stream_t stream);
+int sitk_gelu_fwd(const float* u, float* g, int64_t n, sitk_stream_t stream);
+int sitk_gelu_bwd(const float* dg, const float* u, float* du, int64_t n, sitk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Optimizer of tools/train.py:228-243,291: SGD(momentum, weight_decay, nesterov) / Adam / AdamW
  * over one flat fp32 parameter buffer.  grad_scale multiplies the gradient first (1/world).    */
 int sitk_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,

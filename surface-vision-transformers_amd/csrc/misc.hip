@@ -530,6 +530,46 @@ __global__ __launch_bounds__(256) void mpp_loss_ld_kernel(const float* __restric
   if (threadIdx.x == 0) unsafeAtomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_count);
 }
 
+// ---- dropout / GELU as stand-alone elementwise kernels: the UNFUSED encoder path taken when the reference's `dropout` ctor
+// argument (models/sit.py:36,57: Attention.to_out.1, FeedForward.net.2 / net.4 of vit_pytorch) is > 0 in training.  Every
+// reference configuration sets 0.0 (config/SiT/*/hparams.yml:46), so this path is for API completeness, not speed.
+// y = res + x * keep / (1 - p), keep ~ Bernoulli(1 - p) from Philox4x32-10 keyed by the seed; counter = (draw index, vector
+// index): 4 elements per Philox call.  The mask is stored (1 byte per element) for the backward pass.
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                          float* __restrict__ y, uint8_t* __restrict__ mask, int64_t n, float p,
+                                                          const uint64_t* __restrict__ state) {
+  const uint64_t seed = state[0], draw = state[1];
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const float scale = 1.0f / (1.0f - p);
+  const int64_t nvec = (n + 3) >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    uint32_t c[4] = {(uint32_t)draw, (uint32_t)i, (uint32_t)(draw >> 32) ^ 0x5bd1e995u, (uint32_t)(i >> 32)};
+    philox4x32(c, k0, k1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t j = 4 * i + e;
+      if (j < n) {
+        const bool keep = u01(c[e]) >= p;
+        mask[j] = keep;
+        y[j] = (res ? res[j] : 0.f) + (keep ? x[j] * scale : 0.f);
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                          float* __restrict__ dx, int64_t n, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dx[i] = mask[i] ? dy[i] * scale : 0.f;
+}
+__global__ __launch_bounds__(256) void advance_draw_kernel(uint64_t* state) { state[1] += 1; }
+// exact-erf GELU (nn.GELU(), utils/utils.py:30's net.1) and its derivative, fp32
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ g, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) g[i] = gelu_erf(u[i]);
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ u,
+                                                       float* __restrict__ du, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) du[i] = dg[i] * gelu_erf_grad(u[i]);
+}
+
 // ---- optimizers ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                   int64_t n, float lr, float momentum, float wd, int nesterov, float gscale) {
@@ -883,4 +923,37 @@ extern "C" int sitk_mpp_loss_fwd_bwd_ld(const float* out, int ldo, const float* 
                        reinterpret_cast<float*>(dout), lddo, rows, K, inv, grad_scale);
   else { set_error("mpp_loss_ld: bad dtype %d", dout_dtype); return SITK_ERR_INVALID; }
   return check_launch("mpp_loss_ld");
+}
+
+extern "C" int sitk_dropout_fwd(const float* x, const float* res, float* y, uint8_t* mask, int64_t n, float p, uint64_t* state,
+                                sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(x && y && mask && state && n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad arguments (0 <= p < 1)");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for((n + 3) / 4, 256, 2048)), dim3(256), 0, s, x, res, y, mask, n, p, state);
+  SITK_LAUNCH_CHECK("dropout_fwd");
+  hipLaunchKernelGGL(advance_draw_kernel, dim3(1), dim3(1), 0, s, state);      // the next call draws a fresh mask
+  return check_launch("dropout_advance");
+}
+
+extern "C" int sitk_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(dy && mask && dx && n > 0 && p >= 0.f && p < 1.f, "dropout_bwd: bad arguments");
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, mask,
+                     dx, n, 1.0f / (1.0f - p));
+  return check_launch("dropout_bwd");
+}
+
+extern "C" int sitk_gelu_fwd(const float* u, float* g, int64_t n, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(u && g && n > 0, "gelu_fwd: bad arguments");
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), u, g, n);
+  return check_launch("gelu_fwd");
+}
+
+extern "C" int sitk_gelu_bwd(const float* dg, const float* u, float* du, int64_t n, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(dg && u && du && n > 0, "gelu_bwd: bad arguments");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dg, u, du, n);
+  return check_launch("gelu_bwd");
 }

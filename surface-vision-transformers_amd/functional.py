@@ -176,3 +176,101 @@ class HeadFn(torch.autograd.Function):
         ops.head_bwd(xin.view(B * N, D), ln_w, ln_b, w, dlogits.contiguous().float(), dx.view(B * N, D), *g, B, N, D,
                      ctx.pool_mean)
         return (dx, *g, None)
+
+
+# ---- unfused stages: the encoder path with dropout > 0 (models/sit.py:36,57; every reference config uses 0.0) ------------------
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm(D) (eps 1e-5, affine) over the last dim of an fp32 (..., D) tensor; fp32 out (the 16-bit rounding of the
+    normalised rows happens where the fused path rounds them: at the next Linear's operand load)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        D = x.shape[-1]
+        x2 = x.detach().reshape(-1, D).contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, weight.detach().contiguous(), bias.detach().contiguous(), "f32")
+        ctx.save_for_backward(x2, mean, rstd, weight.detach())
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd, w = ctx.saved_tensors
+        D = x2.shape[1]
+        dg, db = torch.zeros(D, device=dy.device), torch.zeros(D, device=dy.device)
+        dx = ops.layernorm_bwd(dy.reshape(-1, D).contiguous().float(), x2, mean, rstd, w.contiguous(), None, dg, db, "f32")
+        return dx.view(ctx.shape), dg, db
+
+
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T dim_head^-0.5) v for qkv (B, N, 3 H 64) fp32 laid out [q | k | v], each (h d) h-major -> (B, N, H 64) fp32."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, dtype):
+        B, N, _ = qkv.shape
+        code = rt.dtype_code(dtype)
+        qc = qkv.detach().reshape(B * N, -1).to(rt.torch_dtype(code)).contiguous()
+        o, lse = ops.attention_fwd(qc, B, N, heads, 0.125, dtype)
+        ctx.save_for_backward(qc, o, lse)
+        ctx.meta = (B, N, heads, dtype)
+        return o.float().view(B, N, heads * 64)
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qc, o, lse = ctx.saved_tensors
+        B, N, heads, dtype = ctx.meta
+        S = _f16_scale(d_o, dtype)
+        dob = (d_o if S is None else d_o * S).reshape(B * N, -1).to(qc.dtype).contiguous()
+        dqkv = ops.attention_bwd(qc, o, dob, lse, B, N, heads, 0.125, dtype).float()
+        if S is not None:
+            dqkv = dqkv * (1.0 / S)
+        return dqkv.view(B, N, -1), None, None
+
+
+class GeluFn(torch.autograd.Function):
+    """exact-erf GELU (nn.GELU()), fp32, libsitk's elementwise kernel."""
+
+    @staticmethod
+    def forward(ctx, u):
+        u = u.detach().contiguous()
+        g = torch.empty_like(u)
+        rt.check(rt.lib.sitk_gelu_fwd(u.data_ptr(), g.data_ptr(), u.numel(), rt.stream_ptr()))
+        ctx.save_for_backward(u)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        (u,) = ctx.saved_tensors
+        dg = dg.contiguous().float()
+        du = torch.empty_like(u)
+        rt.check(rt.lib.sitk_gelu_bwd(dg.data_ptr(), u.data_ptr(), du.data_ptr(), u.numel(), rt.stream_ptr()))
+        return du
+
+
+class DropoutResidualFn(torch.autograd.Function):
+    """res + Dropout_p(x) (res may be None): nn.Dropout of the reference block followed by its residual add.  The mask comes
+    from a device-side Philox stream (`state`: int64[2] = {seed, draws so far}), not from torch's generator: a seeded
+    reference run cannot be replayed bit for bit through it (same distribution, other stream)."""
+
+    recorder = None        # tests: a list that receives every mask drawn, in call order
+
+    @staticmethod
+    def forward(ctx, x, res, p, state):
+        x = x.detach().contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        r = None if res is None else res.detach().contiguous()
+        rt.check(rt.lib.sitk_dropout_fwd(x.data_ptr(), rt.ptr(r), y.data_ptr(), mask.data_ptr(), x.numel(), float(p),
+                                         state.data_ptr(), rt.stream_ptr()))
+        ctx.save_for_backward(mask)
+        ctx.p, ctx.has_res = float(p), res is not None
+        if DropoutResidualFn.recorder is not None:
+            DropoutResidualFn.recorder.append(mask.clone())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(dy)
+        rt.check(rt.lib.sitk_dropout_bwd(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p, rt.stream_ptr()))
+        return dx, (dy if ctx.has_res else None), None, None

@@ -59,6 +59,7 @@ class Transformer(nn.Module):
         super().__init__()
         self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, mlp_dim
         self.p_dropout = float(dropout)
+        self._drop_state = None
         self.compute_dtype = compute_dtype
         self.layers = nn.ModuleList([
             nn.ModuleList([PreNorm(dim, Attention(dim, heads, dim_head, dropout)),
@@ -74,15 +75,57 @@ class Transformer(nn.Module):
                         ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias])
         return out
 
+    def _forward_with_dropout(self, x):
+        """Training with dropout > 0 (the three nn.Dropout of a vit_pytorch block: behind to_out.0, behind GELU, behind net.3):
+        the block stage by stage -- LayerNorm, Linear, attention, GELU and dropout + residual each as its own libsitk launch --
+        instead of the fused per-block kernels, which have no mask plumbing.  Every reference configuration sets dropout 0.0
+        (config/SiT/training/hparams.yml:46): this path exists so that the constructor argument is honoured, not for speed.
+        The masks come from a device-side Philox stream seeded from torch's seed at first use."""
+        dt, p = self.compute_dtype, self.p_dropout
+        if self._drop_state is None or self._drop_state.device != x.device:
+            self._drop_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=x.device)
+        st = self._drop_state
+        x = x.float()
+        for attn, ff in self.layers:
+            h = Fn.LayerNormFn.apply(x, attn.norm.weight, attn.norm.bias)
+            qkv = Fn.LinearFn.apply(h, attn.fn.to_qkv.weight, None, dt)
+            o = Fn.AttentionFn.apply(qkv, self.heads, dt)
+            y = Fn.LinearFn.apply(o, attn.fn.to_out[0].weight, attn.fn.to_out[0].bias, dt)
+            x = Fn.DropoutResidualFn.apply(y, x, p, st)
+            h = Fn.LayerNormFn.apply(x, ff.norm.weight, ff.norm.bias)
+            u = Fn.LinearFn.apply(h, ff.fn.net[0].weight, ff.fn.net[0].bias, dt)
+            g = Fn.DropoutResidualFn.apply(Fn.GeluFn.apply(u), None, p, st)
+            y = Fn.LinearFn.apply(g, ff.fn.net[3].weight, ff.fn.net[3].bias, dt)
+            x = Fn.DropoutResidualFn.apply(y, x, p, st)
+        return x
+
     def forward(self, x):
-        if self.training and self.p_dropout > 0:
-            raise SitkError("dropout > 0 inside the encoder is not implemented on the HIP path "
-                            "(every reference config uses dropout 0.0: config/SiT/*/hparams.yml)")
         if not x.is_cuda:
             raise SitkError("sitk Transformer: input must be on the GPU (no CPU path)")
+        if self.training and self.p_dropout > 0:
+            return self._forward_with_dropout(x)
         flat = [p for layer in self.layer_tensors() for p in layer]
         cfg = (self.dim, self.depth, self.heads, self.mlp_dim, self.compute_dtype)
         return Fn.EncoderFn.apply(x.float(), cfg, *flat)
+
+
+class Dropout(nn.Dropout):
+    """nn.Dropout(p) of models/sit.py:55 (emb_dropout) on libsitk's Philox stream (same `p` attribute, no parameters);
+    identity in eval mode and for p == 0."""
+
+    def __init__(self, p=0.0):
+        super().__init__(p)
+        self._state = None
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        if not x.is_cuda:
+            raise SitkError("sitk Dropout: input must be on the GPU (no CPU path)")
+        if self._state is None or self._state.device != x.device:
+            self._state = torch.tensor([(torch.initial_seed() + 0x9E3779B9) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64,
+                                       device=x.device)
+        return Fn.DropoutResidualFn.apply(x.float(), None, self.p, self._state)
 
 
 class ToTokens(nn.Module):
@@ -123,7 +166,7 @@ class SiT(nn.Module):
         self.to_patch_embedding[1].compute_dtype = compute_dtype
         self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
         self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
-        self.dropout = nn.Dropout(emb_dropout)
+        self.dropout = Dropout(emb_dropout)
         self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout, compute_dtype=compute_dtype)
         self.pool = pool
         self.to_latent = nn.Identity()

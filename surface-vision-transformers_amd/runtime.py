@@ -129,6 +129,10 @@ _SIGS = {
     "sitk_mpp_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _L, _P]),
     "sitk_mpp_loss_fwd_bwd_ld": (C.c_int, [_P, _I, _P, _I, _P, _P, _P, _I, _I, _L, _I, _L, _F, _P]),
     "sitk_masked_colsum": (C.c_int, [_P, _I, _I, _I, _P, _P, _L, _I, _P, _P]),
+    "sitk_dropout_fwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _P, _P]),
+    "sitk_dropout_bwd": (C.c_int, [_P, _P, _P, _L, _F, _P]),
+    "sitk_gelu_fwd": (C.c_int, [_P, _P, _L, _P]),
+    "sitk_gelu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "sitk_sgd_step": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _I, _F, _P]),
     "sitk_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _F, _P]),
     "sitk_sgd_step_dev": (C.c_int, [_P, _P, _P, _L, _P, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P]),

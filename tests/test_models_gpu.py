@@ -189,3 +189,103 @@ def test_eval_forward_and_cpu_input_is_refused(sitk_models):
     with torch.no_grad():
         out = model(torch.zeros(2, 4, 80, 561, device=DEV))
     assert out.shape == (2, 1) and torch.isfinite(out).all()
+
+
+# ---- dropout > 0: the stage-by-stage encoder path (models/sit.py:36,55,57; no reference config uses it) ----------------------
+class _ReplayDropout(torch.nn.Module):
+    """Stands in for the oracle's nn.Dropout modules: applies the masks the HIP path drew, in call order."""
+
+    def __init__(self, masks, p):
+        super().__init__()
+        self.masks, self.p = masks, p
+
+    def forward(self, x):
+        m = self.masks.pop(0)
+        assert m.shape == x.shape, (m.shape, x.shape)
+        return x * m.to(x.dtype) / (1.0 - self.p)
+
+
+def _replace_dropouts(module, masks, p):
+    for name, child in list(module.named_children()):
+        if isinstance(child, torch.nn.Dropout):
+            setattr(module, name, _ReplayDropout(masks, p))
+        else:
+            _replace_dropouts(child, masks, p)
+
+
+def _dropout_models(sit, dtype, p, depth=2):
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=depth, num_patches=320, num_vertices=153, num_channels=4)
+    ref = sit_oracle.SiT(**kw, dropout=p, emb_dropout=p)
+    _load(ref, 11)
+    model = sit.SiT(**kw, dropout=p, emb_dropout=p, compute_dtype=dtype)
+    model.load_state_dict(ref.state_dict())
+    return ref, model.to(DEV).train()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16"])
+def test_dropout_path_matches_oracle_with_the_same_masks(sitk_models, dtype):
+    sit, _ = sitk_models
+    from sitk.functional import DropoutResidualFn
+    p = 0.1
+    ref, model = _dropout_models(sit, dtype, p)
+    x = detgen.normal("do/x", (4, 4, 320, 153), seed=2)
+    y = detgen.normal("do/y", (4,), seed=2)
+    DropoutResidualFn.recorder = rec = []
+    try:
+        lo = torch.nn.functional.mse_loss(model(torch.from_numpy(x).to(DEV)).squeeze(), torch.from_numpy(y).to(DEV))
+        lo.backward()
+    finally:
+        DropoutResidualFn.recorder = None
+    assert len(rec) == 1 + 3 * 2                              # emb_dropout + three per block
+    masks = [m.cpu() for m in rec]
+    rates = [1.0 - float(m.float().mean()) for m in masks]
+    assert all(abs(r - p) < 0.01 for r in rates), rates       # >= 2.4e5 draws each: sigma < 7e-4
+    assert not torch.equal(masks[1], masks[4])                # the stream advances between calls
+    _replace_dropouts(ref, masks, p)
+    ref.train()
+    lr = torch.nn.functional.mse_loss(ref(torch.from_numpy(x)).squeeze(), torch.from_numpy(y))
+    lr.backward()
+    assert not masks                                          # every mask consumed, in the oracle's call order
+    check("dropout/tiny320_d2", "loss", dtype, abs(float(lo) - float(lr)) / float(lr), "loss")
+    worst = max((rel(q.grad, r.grad), k) for (k, q), (_, r) in zip(model.named_parameters(), ref.named_parameters()))
+    print("dropout path, worst element-wise gradient:", worst)
+    check("dropout/tiny320_d2", "grad_rel", dtype, worst[0], "grad")
+
+
+def test_dropout_path_with_p_zero_masks_equals_the_fused_path(sitk_models):
+    """The stage-by-stage path, forced at p = 0 (all-ones masks), against the fused EncoderFn path on the same weights."""
+    sit, _ = sitk_models
+    _, model = _dropout_models(sit, "f32", 0.0, depth=3)
+    x = torch.from_numpy(detgen.normal("do0/x", (2, 321, 192), seed=5)).to(DEV).requires_grad_()
+    tr = model.transformer
+    a = tr(x)
+    ga, = torch.autograd.grad(a.square().sum(), x)
+    b = tr._forward_with_dropout(x)
+    gb, = torch.autograd.grad(b.square().sum(), x)
+    assert rel(b, a) < 1e-5 and rel(gb, ga) < 1e-5, (rel(b, a), rel(gb, ga))
+
+
+def test_dropout_is_seeded_and_off_in_eval(sitk_models):
+    sit, _ = sitk_models
+    x = torch.from_numpy(detgen.normal("do/x", (2, 4, 320, 153), seed=4)).to(DEV)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(1234)
+        _, model = _dropout_models(sit, "bf16", 0.2, depth=1)
+        outs.append((model(x).detach().clone(), model(x).detach().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # same seed, same stream
+    assert not torch.equal(outs[0][0], outs[0][1])                                        # successive calls draw new masks
+    model.eval()
+    _, clean = _dropout_models(sit, "bf16", 0.0, depth=1)
+    clean.eval()
+    with torch.no_grad():
+        assert torch.equal(model(x), clean(x))
+
+
+def test_engine_refuses_dropout(sitk_models):
+    sit, _ = sitk_models
+    from sitk.engine import TrainEngine
+    from sitk.runtime import SitkError
+    _, model = _dropout_models(sit, "bf16", 0.1, depth=1)
+    with pytest.raises(SitkError, match="dropout"):
+        TrainEngine(model, batch_size=2, input_layout="patched")
