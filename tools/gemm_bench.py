@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=32 * 1281)
     ap.add_argument("--sets", type=int, default=4)
     ap.add_argument("--reps", type=int, default=8)
+    ap.add_argument("--only", type=int, default=-1, help="run only row i (0..7)")
     ap.add_argument("--lib", action="store_true", help="reference point: the same products (no epilogue) by torch.mm = the ROCm GEMM library")
     a = ap.parse_args()
     D, H = DIMS[a.model]
@@ -54,6 +55,8 @@ def main():
                    ("h", "wo", "oh"), ("qkv", "wqkv_t", "oh")]
         rows = [(name + " [torch.mm]", (lambda s, k=k: torch.mm(s[k[0]], s[k[1]].t(), out=s[k[2]])), fl, nb)
                 for (name, _, fl, nb), k in zip(rows, ops_lib)]
+    if a.only >= 0:
+        rows = rows[a.only:a.only + 1]
     tot = 0.0
     for name, fn, flops, nbytes in rows:
         for s in S:
