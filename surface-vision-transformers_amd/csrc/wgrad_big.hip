@@ -331,6 +331,259 @@ __global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The 128 x 384 form for dims 384 / 768 (every Linear of SiT-small / -base has one side that is a multiple of 384 and
+// the other a multiple of 128).  Counters of the 128 x 192 kernel at those sizes: 11.6 TB/s between L2 and the CUs
+// (640 B of operands per token and tile: 90 GB per step of config 5) with the matrix pipe a third busy -- the tile, not
+// the MFMA schedule, sets the time.  Twice the tile area on the Q side: 512 B of operands per token for twice the
+// products (0.8 x the bytes per flop).  Same wave tile (64 x 192 accumulator, 48 MFMAs per 32 tokens) and the same
+// hand-interleaved stage body; the four waves are 2 (P halves) x 2 (Q halves) and ALL of them take every token, so
+// a stage is 32 tokens (8 panels of 32 rows x 128 B = 32 KB), the ring is five stages deep (all 160 KB, four in flight)
+// and there is no token-half reduction.  The finished tile leaves through LDS in its two 128 x 192 halves, which are
+// exactly two adjacent tiles of the 128 x 192 numbering: WbProblem stays in those units (tiles, tiles_q, block_begin)
+// and the slab layout and the reduce kernel are shared.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __restrict__ slab) {
+  constexpr int PNL = 4096;       // one panel: 32 rows x 128 B
+  constexpr int STG = 8 * PNL;    // P0 P1 Q0 .. Q5
+  constexpr int NSTG = 5;
+  constexpr int PCS = 8;          // DMA pieces per wave and stage: 2 of the P side, 6 of the Q side
+  __shared__ __attribute__((aligned(256))) char smem[NSTG * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave & 1, wp = wave >> 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);            // in units of 128 x 384 tiles = two 128 x 192 blocks
+  int pi = 0;
+  for (int i = 1; i < grp.count; ++i)
+    if (2 * bid >= grp.p[i].block_begin) pi = i;
+  const WbProblem P = grp.p[pi];
+  const int tiles_r = P.tiles >> 1, tq_r = P.tiles_q >> 1;
+  const int local = bid - (P.block_begin >> 1);
+  const int split = local / tiles_r, tile = local % tiles_r;
+  const int p0 = (tile / tq_r) * 128, q0 = (tile % tq_r) * 384;
+  const int mbeg = split * P.chunk, mend = min(P.M, mbeg + P.chunk);
+  const char* zero = reinterpret_cast<const char*>(g_zero_page_wb);
+
+  const int r8 = lane >> 3;
+  const h16* zerop = reinterpret_cast<const h16*>(zero);
+  const h16* pbase[PCS];
+  int prow[PCS], pdst[PCS];
+#pragma unroll
+  for (int i = 0; i < PCS; ++i) {
+    const bool isP = i < 2;
+    const int q = isP ? wave * 2 + i : wave * 6 + (i - 2);
+    const int panel = q >> 2, row = (q & 3) * 8 + r8;
+    const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+    const int col = (isP ? p0 : q0) + panel * 64 + ((lane & 7) ^ (key << 1)) * 8;
+    const bool colok = col < (isP ? P.cp : P.cq);
+    const int ld = isP ? P.ldp : P.ldq;
+    const int grp_i = isP ? P.pgroup : P.qgroup, lrow = mbeg + row;
+    const int frow = grp_i ? (lrow / grp_i) * (isP ? P.pstride : P.qstride) + (isP ? P.poffset : P.qoffset) + lrow % grp_i : lrow;
+    pbase[i] = colok ? (isP ? P.P : P.Q) + (size_t)frow * ld + col : zerop;
+    prow[i] = colok ? row : (1 << 30);
+    pdst[i] = (isP ? 0 : 2 * PNL) + q * 1024;
+  }
+  const char* zp = zero;
+  asm volatile("" : "+v"(zp));
+  const char* pcur[PCS];
+#pragma unroll
+  for (int i = 0; i < PCS; ++i) pcur[i] = reinterpret_cast<const char*>(pbase[i]);
+  const int pincP = __builtin_amdgcn_readfirstlane(32 * P.ldp * (int)sizeof(h16));
+  const int pincQ = __builtin_amdgcn_readfirstlane(32 * P.ldq * (int)sizeof(h16));
+  int left = mend - mbeg;
+  int gposP = P.pgroup ? mbeg % P.pgroup : 0, gposQ = P.qgroup ? mbeg % P.qgroup : 0;
+  const int extraP = P.pgroup ? (P.pstride - P.pgroup) * P.ldp * (int)sizeof(h16) : 0;
+  const int extraQ = P.qgroup ? (P.qstride - P.qgroup) * P.ldq * (int)sizeof(h16) : 0;
+  int incP = pincP, incQ = pincQ;
+  auto next_stage_steps = [&]() __attribute__((always_inline)) {
+    gposP += 32;
+    gposQ += 32;
+    incP = pincP;
+    incQ = pincQ;
+    if (P.pgroup && gposP >= P.pgroup) { gposP = 0; incP += extraP; }
+    if (P.qgroup && gposQ >= P.qgroup) { gposQ = 0; incQ += extraQ; }
+  };
+  auto issue_piece = [&](int i, char* sb) __attribute__((always_inline)) {
+    const char* src = prow[i] < left ? pcur[i] : zp;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sb + pdst[i]), 16, 0, 0);
+    pcur[i] += i < 2 ? incP : incQ;
+    asm volatile("" : "+v"(pcur[i]));
+  };
+  auto issue = [&](int stage) __attribute__((always_inline)) {
+    char* sb = smem + stage * STG;
+    next_stage_steps();
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) issue_piece(i, sb);
+    left -= 32;
+  };
+
+  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int rowl = 8 * (lane >> 4) + ((lane >> 2) & 3);
+  const int keyl = ((rowl >> 1) & 1) | (((rowl >> 3) & 1) << 1);
+  uint32_t toffp[4], toffq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t t = lbase + rowl * 128 + 32 * (i ^ keyl) + 8 * (lane & 3);
+    toffp[i] = t + wp * PNL;
+    toffq[i] = t + (2 + 3 * wq) * PNL;
+  }
+
+  f32x4 acc[4][12], accb[12];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 12; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool biasP = P.db != nullptr && !P.swapped && q0 == 0 && wq == 0;   // dY on the P side: the 4 blocks of this P half
+  const bool biasQ = P.db != nullptr && P.swapped && p0 == 0 && wp == 0;    // dY on the Q side: the 12 blocks of this Q half
+  u32x4 ones;
+  {
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (h16)1.0f;
+    ones = __builtin_bit_cast(u32x4, o);
+  }
+
+  const int nstage = (mend - mbeg + 31) / 32;
+  struct Frags {
+    u32x2 pl[4], ph[4], ql[12], qh[12];
+  };
+  Frags fa, fb;
+  auto read_pair = [&](Frags& f, int r, uint32_t so) __attribute__((always_inline)) {
+    if (r < 4) {
+      const uint32_t a = toffp[r] + so;
+      asm volatile(SITK_WB_TR2("%0", "%1", "%2", 0, 512) : "=&v"(f.pl[r]), "=&v"(f.ph[r]) : "v"(a));
+    } else {
+      const int j = r - 4;
+      const uint32_t a = toffq[j & 3] + so;
+      if (j < 4) asm volatile(SITK_WB_TR2("%0", "%1", "%2", 0, 512) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
+      else if (j < 8) asm volatile(SITK_WB_TR2("%0", "%1", "%2", 4096, 4608) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
+      else asm volatile(SITK_WB_TR2("%0", "%1", "%2", 8192, 8704) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
+    }
+  };
+  for (int i = 0; i < NSTG - 1; ++i) issue(i);
+  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");            // stage 0 has landed (1..3 in flight)
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) read_pair(fa, r, 0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  auto stage_body = [&](Frags& cur, Frags& nxt, int s, auto bp, auto bq) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // stage s + 1 has landed (s + 2, s + 3 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    char* sb = smem + ((s + NSTG - 1) % NSTG) * STG;           // slot of stage s - 1: every wave has its fragments
+    const uint32_t so = ((s + 1) % NSTG) * STG;
+    next_stage_steps();
+    u32x4 fp[4], fqv[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fp[i] = u32x4{cur.pl[i][0], cur.pl[i][1], cur.ph[i][0], cur.ph[i][1]};
+#pragma unroll
+    for (int j = 0; j < 12; ++j) fqv[j] = u32x4{cur.ql[j][0], cur.ql[j][1], cur.qh[j][0], cur.qh[j][1]};
+#pragma unroll
+    for (int m = 0; m < 48; ++m) {
+      mma_acc_v(acc[m / 12][m % 12], fp[m / 12], fqv[m % 12]);
+      if (m % 3 == 0) read_pair(nxt, m / 3, so);
+      if (m % 6 == 5) issue_piece(m / 6, sb);
+    }
+    left -= 32;
+    if constexpr (decltype(bp)::value) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mma_acc_v(accb[i], fp[i], ones);
+    }
+    if constexpr (decltype(bq)::value) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) mma_acc_v(accb[j], ones, fqv[j]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto stages = [&](auto bp, auto bq) __attribute__((always_inline)) {
+    for (int s = 0; s < nstage; s += 2) {
+      stage_body(fa, fb, s, bp, bq);
+      stage_body(fb, fa, s + 1, bp, bq);
+    }
+  };
+  if (biasP) stages(std::true_type{}, std::false_type{});
+  else if (biasQ) stages(std::false_type{}, std::true_type{});
+  else stages(std::false_type{}, std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // acc[i][j][jj] <-> P column wp*64 + 16i + 4fq + jj, Q column wq*192 + 16j + fr.  Half h of the tile (the waves with
+  // wq == h) = block `blk0 + h` of the 128 x 192 numbering.
+  const int fr = lane & 15, fq = lane >> 4;
+  const size_t blk0 = (size_t)P.block_begin + (size_t)split * P.tiles + (size_t)tile * 2;
+  const size_t total_blocks = (size_t)gridDim.x * 2;
+  const bool vec_ok = (P.lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(P.dW) & 15) == 0;
+  float* til = reinterpret_cast<float*>(smem);
+  for (int h = 0; h < 2; ++h) {
+    if (wq == h) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) til[(wp * 64 + 16 * i + 4 * fq + jj) * 192 + 16 * j + fr] = acc[i][j][jj];
+    }
+    __syncthreads();
+    const int qh0 = q0 + 192 * h;
+    if (P.splits > 1) {
+      float* out = slab + (blk0 + h) * WB_TILE_ELEMS;
+      for (int e4 = tid * 4; e4 < WB_TILE_ELEMS; e4 += 1024) *reinterpret_cast<f32x4*>(out + e4) = *reinterpret_cast<const f32x4*>(til + e4);
+    } else if (!P.swapped) {
+      for (int e4 = tid * 4; e4 < WB_TILE_ELEMS; e4 += 1024) {
+        const int r = e4 / 192, c = e4 % 192, pc = p0 + r, qc = qh0 + c;
+        if (pc >= P.cp || qc >= P.cq) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(til + e4);
+        float* dst = P.dW + (size_t)pc * P.lddw + qc;
+        if (qc + 3 < P.cq && vec_ok) {
+          *reinterpret_cast<f32x4*>(dst) += v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (qc + e < P.cq) dst[e] += v[e];
+        }
+      }
+    } else {
+      for (int t = tid; t < WB_TILE_ELEMS / 4; t += 256) {
+        const int c = t % 192, r0 = (t / 192) * 4, qc = qh0 + c, pc = p0 + r0;
+        if (qc >= P.cq || pc >= P.cp) continue;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = til[(r0 + e) * 192 + c];
+        float* dst = P.dW + (size_t)qc * P.lddw + pc;
+        if (pc + 3 < P.cp && vec_ok) {
+          *reinterpret_cast<f32x4*>(dst) += v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (pc + e < P.cp) dst[e] += v[e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // Bias gradient: this kernel has no token halves -- the whole sum goes to slot 0 of the block's [2][192] pair, zeros to slot 1
+  float* bs = slab + total_blocks * WB_TILE_ELEMS;
+  if (biasP && fr == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int c = wp * 64 + 16 * i + 4 * fq + jj, n = p0 + c;
+        if (P.splits > 1) { bs[(blk0 * 2 + 0) * 192 + c] = accb[i][jj]; bs[(blk0 * 2 + 1) * 192 + c] = 0.f; }
+        else if (n < P.cp) unsafeAtomicAdd(P.db + n, accb[i][jj]);
+      }
+  }
+  if (biasQ && fq == 0) {
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const int c = 16 * j + fr, n = q0 + 192 * wq + c;
+      if (P.splits > 1) { bs[((blk0 + wq) * 2 + 0) * 192 + c] = accb[j][0]; bs[((blk0 + wq) * 2 + 1) * 192 + c] = 0.f; }
+      else if (n < P.cq) unsafeAtomicAdd(P.db + n, accb[j][0]);
+    }
+  }
+}
+
 // dW (+)= sum over the splits of a tile's slabs, honouring the orientation; one thread per 4 Q columns
 __global__ __launch_bounds__(256) void wgrad_big_reduce_kernel(WbGroup grp, const float* __restrict__ slab, int total_tiles,
                                                                  int total_blocks) {
@@ -402,15 +655,26 @@ static bool wb_eligible(const sitk_wgrad_desc& d) {
   return align && plain && d.M >= 2048 && (d.K % 192 == 0 || d.N % 192 == 0);
 }
 
-static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks, int& tiles_total, int cus = 256) {
+// the 128 x 384 kernel takes a launch whose every problem has a side that is a multiple of 384 (dims 384 / 768; not dim 192:
+// to_qkv and to_out of SiT-tiny have 192 / 576 on both sides, and a tiny launch is sized for the CUs beside the chain)
+static bool wb_wide(const sitk_wgrad_desc* d, int count) {
+  for (int i = 0; i < count; ++i)
+    if (d[i].K % 384 != 0 && d[i].N % 384 != 0) return false;
+  return true;
+}
+
+// Plans a launch in units of 128 x 192 blocks.  wide: every tile is a PAIR of such blocks side by side (128 x 384); the Q
+// side must then be a multiple of 384, and rounds are counted in pairs.
+static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks, int& tiles_total, int cus = 256, bool wide = false) {
   tiles_total = 0;
+  const int qm = wide ? 384 : 192;
   for (int i = 0; i < count; ++i) {
     WbProblem& p = g.p[i];
     // Q side (192-column tiles) = X columns (k) or dY columns (n): whichever orientation needs fewer 128 x 192 tiles
     // (net.3 of dim 192: dY 192 x X 768 is 2 x 4 tiles with dY on the 128 side, half of them half empty, but 6 x 1
     // the other way round)
-    const int tiles_normal = d[i].K % 192 == 0 ? cdiv(d[i].N, 128) * (d[i].K / 192) : (1 << 30);
-    const int tiles_swapped = d[i].N % 192 == 0 ? cdiv(d[i].K, 128) * (d[i].N / 192) : (1 << 30);
+    const int tiles_normal = d[i].K % qm == 0 ? cdiv(d[i].N, 128) * (d[i].K / 192) : (1 << 30);
+    const int tiles_swapped = d[i].N % qm == 0 ? cdiv(d[i].K, 128) * (d[i].N / 192) : (1 << 30);
     const bool normal = tiles_normal <= tiles_swapped;
     p.swapped = normal ? 0 : 1;
     p.P = reinterpret_cast<const h16*>(normal ? d[i].dY : d[i].X);
@@ -439,17 +703,18 @@ static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks,
   // cus < 256: the launch is meant to run BESIDE another kernel chain on the CUs that chain leaves idle (encoder.hip's side
   // streams): it may occupy `cus` CUs, not the chip
   int many = 1;
-  if (tiles_total > cus) {
+  const int units = wide ? tiles_total / 2 : tiles_total;      // workgroups per split
+  if (units > cus) {
     double best = 1e30;
     for (int sp = 1; sp <= 4; ++sp) {
-      const double rounds = (double)cdiv(tiles_total * sp, cus);
+      const double rounds = (double)cdiv(units * sp, cus);
       const double cost = rounds / sp * (1.0 + (sp > 1 ? 0.015 * sp : 0.0));
       if (cost < best - 1e-9) { best = cost; many = sp; }
     }
   }
   for (int i = 0; i < count; ++i) {
     WbProblem& p = g.p[i];
-    int splits = tiles_total > cus ? many : std::max(1, cus / tiles_total);
+    int splits = units > cus ? many : std::max(1, cus / units);
     splits = std::min(splits, std::max(1, p.M / 256));
     p.chunk = cdiv(cdiv(p.M, splits), 64) * 64;
     p.splits = cdiv(p.M, p.chunk);
@@ -471,7 +736,7 @@ extern "C" size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int c
     if (!wb_eligible(d[i])) return 0;
   WbGroup g;
   int blocks, tiles;
-  wb_plan(d, count, g, blocks, tiles);
+  wb_plan(d, count, g, blocks, tiles, 256, wb_wide(d, count));             // (a launch for fewer CUs checks its own plan against the size it is given)
   return (size_t)blocks * (WB_TILE_ELEMS + 2 * 192) * sizeof(float);      // tile slabs + bias partials of split tiles
 }
 
@@ -497,9 +762,13 @@ extern "C" int sitk_gemm_wgrad_group_ws_cus(const sitk_wgrad_desc* d, int count,
     SITK_REQUIRE(d[i].dY && d[i].X && d[i].dW, "gemm_wgrad_group_ws: null operand in problem %d", i);
   WbGroup g;
   int blocks, tiles;
-  wb_plan(d, count, g, blocks, tiles, cus);
+  const bool wide = wb_wide(d, count);
+  wb_plan(d, count, g, blocks, tiles, cus, wide);
+  SITK_REQUIRE((size_t)blocks * (WB_TILE_ELEMS + 2 * 192) * sizeof(float) <= ws_bytes, "gemm_wgrad_group_ws: workspace of %zu bytes, "
+               "%d blocks planned for %d CUs", ws_bytes, blocks, cus);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(wgrad_big_kernel, dim3(blocks), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
+  if (wide) hipLaunchKernelGGL(wgrad_wide_kernel, dim3(blocks / 2), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
+  else hipLaunchKernelGGL(wgrad_big_kernel, dim3(blocks), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
   SITK_LAUNCH_CHECK("wgrad_big");
   bool any_split = false;
   for (int i = 0; i < count; ++i) any_split |= g.p[i].splits > 1;

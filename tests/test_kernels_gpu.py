@@ -245,11 +245,13 @@ def test_layernorm_fwd_bwd(ops, dtype, D):
 
 
 @pytest.mark.parametrize("h16", H16S)
-@pytest.mark.parametrize("D,M,H", [(192, 768, 3), (384, 1536, 6)])
-def test_wgrad_large_tile_slab_path_integer_exact(ops, D, M, H, h16):
-    """bf16 128x192-tile kernel + slab reduction (sitk_gemm_wgrad_group_ws): both orientations, partial
-    tiles (192 = 128 + 64), bias on either side, accumulate semantics, token tail (R % 64 != 0)."""
-    R, I = 321 * 8 + 5, H * 64
+@pytest.mark.parametrize("D,M,H,R", [(192, 768, 3, 321 * 8 + 5), (384, 1536, 6, 321 * 8 + 5), (768, 3072, 12, 321 * 8 + 5),
+                                     (384, 1536, 6, 1281 * 4 + 37), (384, 768, 6, 321 * 20 + 1)])
+def test_wgrad_large_tile_slab_path_integer_exact(ops, D, M, H, R, h16):
+    """bf16 128x192-tile kernel (dim 192) / 128x384-tile kernel (dims 384, 768: every problem has a side that is a multiple
+    of 384) + slab reduction (sitk_gemm_wgrad_group_ws): both orientations, partial tiles (192 = 128 + 64), bias on either
+    side, accumulate semantics, token tail (R % 64 != 0, R % 32 != 0), token-split and whole-token tiles."""
+    I = H * 64
     probs, refs = [], []
     for i, (n, k, bias) in enumerate([(D, M, True), (M, D, True), (D, I, True), (3 * I, D, False)]):
         dY, X = ints(f"wgb/dY{i}", (R, n), -2, 3).to(tdt(h16)), ints(f"wgb/X{i}", (R, k), -2, 3).to(tdt(h16))
