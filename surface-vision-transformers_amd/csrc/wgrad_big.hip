@@ -1,21 +1,20 @@
-// sitk weight gradients, large-tile variant with a slab reduction (bf16, dims that are multiples of 192).
+// sitk weight gradients, large-tile kernel with a slab reduction (16-bit compute types, dims that are multiples of 192).
 //
 //   dW[n][k] += sum_m dY[m][n] X[m][k]        (and db[n] += sum_m dY[m][n])
 //
 // The 64x64-tile kernel of gemm.hip stages 32 flop per byte and is bound by L2 -> LDS traffic
-// (profiles/r01_pmc_wgrad_group.txt).  Here a workgroup owns a 128 x 192 output tile (77 flop/B):
-//   * the 128-column side ("P") and the 192-column side ("Q") are the two operands, whichever of
-//     dY / X has the dimension that is a multiple of 192 goes on the Q side (the tile is written
-//     back transposed when that is dY);
-//   * 4 waves = 2 token halves x 2 halves of the 128 side; a wave holds a 64 x 192 fp32 accumulator
-//     (48 MFMA tiles, 192 registers: one wave per SIMD owns the register file);
-//   * 64-token stages (2 + 3 panels of 64 rows x 128 B = 40 KB) move global -> LDS by LDS-DMA through
-//     a 4-deep ring (all 160 KB of the CU), three stages in flight, one raw barrier per stage;
-//     transposed fragments are read inside asm blocks (a compiler-visible LDS read would make hipcc
-//     drain the DMA ring with s_waitcnt vmcnt(0));
-//   * token-split partial tiles are written to a slab with plain stores and summed into dW by a
-//     second kernel: bitwise reproducible, and none of the 24 MB of partials goes through float
-//     atomics (1.3 TB/s chip-wide, MI355X_MICROARCH.md).
+// (profiles/r01_pmc_wgrad_group.txt).  Rounds 1 - 2 ran 128 x 192 output tiles (77 flop/B, 64-token stages, two token
+// halves per workgroup): still 9 - 12 TB/s between L2 and the CUs at every model size with the matrix pipe a quarter to a
+// third busy.  Now a workgroup owns TWO such blocks (wgrad_x2_kernel below: 128 x 384 or 256 x 192):
+//   * the two operands are the "P" and the "Q" side; whichever of dY / X has the dimension that is a multiple of 192
+//     (384) goes on the Q side (the tile is written back transposed when that is dY);
+//   * 4 waves, each with a 64 x 192 fp32 accumulator (48 MFMA tiles, 192 AGPRs: one wave per SIMD owns the register file);
+//   * 32-token stages (8 or 7 panels of 32 rows x 128 B) move global -> LDS by LDS-DMA through a 5-deep ring, four stages in
+//     flight, one raw barrier per stage; transposed fragments are read inside asm blocks (a compiler-visible LDS read would
+//     make hipcc drain the DMA ring with s_waitcnt vmcnt(0));
+//   * bookkeeping stays in units of 128 x 192 BLOCKS (WbProblem.tiles / tiles_q / block_begin, the slab, the reduce kernel);
+//   * token-split partial blocks are written to a slab with plain stores and summed into dW by a second kernel: bitwise
+//     reproducible, and none of the partials goes through float atomics (1.3 TB/s chip-wide, MI355X_MICROARCH.md).
 #include <algorithm>
 #include <type_traits>
 
@@ -24,21 +23,19 @@
 namespace sitk {
 
 // One launch takes up to 52 problems (the 4 Linears of up to 12 encoder layers + the patch embedding: 5.4 KB of
-// kernel arguments).  With
-// all 252 tiles of a 12-layer backward in one launch every workgroup owns a whole tile over ALL tokens: no token
-// split, so one slab write + one reduction launch per step instead of twelve of each (see sitk_encoder_bwd).
+// kernel arguments): a whole backward slice brings enough tiles to give each workgroup a long token run (see sitk_encoder_bwd).
 constexpr int WB_MAX_PROBLEMS = 52;   // 12 layers x 4 + the patch embedding (+ spare)
 constexpr int WB_TILE_ELEMS = 128 * 192;
 struct WbProblem {
-  const h16* P;   // 128-column side operand (M, ldp)
-  const h16* Q;   // 192-column side operand (M, ldq)
+  const h16* P;   // P side operand (M, ldp): 128-column block rows
+  const h16* Q;   // Q side operand (M, ldq): 192-column block columns
   int ldp, ldq, cp, cq;  // leading dims and total columns of each side
   float* dW;
   int lddw;
   int swapped;     // 0: P = dY (rows n), Q = X (cols k); 1: P = X (cols k), Q = dY (rows n)
   float* db;       // bias gradient of the dY side or null
   int M, tiles_q, tiles, block_begin, splits, chunk;
-  // row map of each side (sitk_rowmap; group 0 = identity).  group % 64 == 0, so a 64-row stage never straddles two
+  // row map of each side (sitk_rowmap; group 0 = identity).  group % 64 == 0, so a 32-row stage never straddles two
   // groups and the running DMA pointer only takes (stride - group) extra rows when a stage starts a new group.
   int pgroup, pstride, poffset, qgroup, qstride, qoffset;
 };
@@ -65,301 +62,44 @@ SITK_DEV void mma_acc_v(f32x4& acc, u32x4 a, u32x4 b) {
   asm volatile("v_mfma_f32_16x16x32_" SITK_H16_MNEMONIC " %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
-__global__ __launch_bounds__(256) void wgrad_big_kernel(WbGroup grp, float* __restrict__ slab) {
-  constexpr int STG = 5 * 8192;  // panels: P0 P1 Q0 Q1 Q2, each 64 rows x 128 B
-  constexpr int NSTG = 4;
-  __shared__ __attribute__((aligned(256))) char smem[NSTG * STG];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wt = wave & 1, wh = wave >> 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  int pi = 0;
-  for (int i = 1; i < grp.count; ++i)
-    if (bid >= grp.p[i].block_begin) pi = i;
-  const WbProblem P = grp.p[pi];
-  const int local = bid - P.block_begin;
-  const int split = local / P.tiles, tile = local % P.tiles;
-  const int p0 = (tile / P.tiles_q) * 128, q0 = (tile % P.tiles_q) * 192;
-  const int mbeg = split * P.chunk, mend = min(P.M, mbeg + P.chunk);
-  const char* zero = reinterpret_cast<const char*>(g_zero_page_wb);
-
-  // LDS-DMA: 40 pieces (8 rows x 128 B) per stage; wave w moves P pieces 4w..4w+3 and Q pieces 6w..6w+5.
-  // Per-lane source pointers of the first stage are set up once; a stage costs one compare, one select and
-  // one 64-bit add per piece (columns outside the matrix and rows past the split read the zero page).
-  const int r8 = lane >> 3;
-  const h16* zerop = reinterpret_cast<const h16*>(zero);
-  const h16* pbase[10];
-  int prow[10], pdst[10];
-  size_t pstep[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const bool isP = i < 4;
-    const int q = isP ? wave * 4 + i : wave * 6 + (i - 4);
-    const int panel = q >> 3, row = (q & 7) * 8 + r8;
-    const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
-    const int col = (isP ? p0 : q0) + panel * 64 + ((lane & 7) ^ (key << 1)) * 8;
-    const bool colok = col < (isP ? P.cp : P.cq);
-    const int ld = isP ? P.ldp : P.ldq;
-    const int grp_i = isP ? P.pgroup : P.qgroup, lrow = mbeg + row;
-    const int frow = grp_i ? (lrow / grp_i) * (isP ? P.pstride : P.qstride) + (isP ? P.poffset : P.qoffset) + lrow % grp_i : lrow;
-    pbase[i] = colok ? (isP ? P.P : P.Q) + (size_t)frow * ld + col : zerop;
-    pstep[i] = colok ? (size_t)64 * ld : 0;
-    prow[i] = colok ? row : (1 << 30);                       // invalid columns never leave the zero page
-    pdst[i] = (isP ? 0 : 2 * 8192) + q * 1024;
-  }
-  const int rows_total = mend - mbeg;
-  // running source pointers: stages are issued strictly in order, one 64-row step each.  The zero page's address is
-  // held in an opaque register pair (left to the compiler it is rebuilt with s_getpc + exec masking per piece).
-  const char* zp = zero;
-  asm volatile("" : "+v"(zp));
-  const char* pcur[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) pcur[i] = reinterpret_cast<const char*>(pbase[i]);
-  // bytes per 64-row step, uniform per side (lanes on columns outside the matrix walk a pointer they never use)
-  const int pincP = __builtin_amdgcn_readfirstlane(64 * P.ldp * (int)sizeof(h16));
-  const int pincQ = __builtin_amdgcn_readfirstlane(64 * P.ldq * (int)sizeof(h16));
-  int left = rows_total;                                      // rows of this split from the next stage to issue on
-  // row-mapped sides: position of the NEXT stage to issue inside its group, and the extra step at a group boundary
-  int gposP = P.pgroup ? mbeg % P.pgroup : 0, gposQ = P.qgroup ? mbeg % P.qgroup : 0;
-  const int extraP = P.pgroup ? (P.pstride - P.pgroup) * P.ldp * (int)sizeof(h16) : 0;
-  const int extraQ = P.qgroup ? (P.qstride - P.qgroup) * P.ldq * (int)sizeof(h16) : 0;
-  int incP = pincP, incQ = pincQ;                             // byte step from the stage being issued to the next one
-  auto next_stage_steps = [&]() __attribute__((always_inline)) {                             // call once per issued stage, before its pieces
-    gposP += 64;
-    gposQ += 64;
-    incP = pincP;
-    incQ = pincQ;
-    if (P.pgroup && gposP >= P.pgroup) { gposP = 0; incP += extraP; }
-    if (P.qgroup && gposQ >= P.qgroup) { gposQ = 0; incQ += extraQ; }
-  };
-  // one piece of the next stage to issue (rows past the split and columns outside the matrix read the zero page)
-  auto issue_piece = [&](int i, char* sb) __attribute__((always_inline)) {
-    const char* src = prow[i] < left ? pcur[i] : zp;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(sb + pdst[i]), 16, 0, 0);
-    pcur[i] += i < 4 ? incP : incQ;
-    asm volatile("" : "+v"(pcur[i]));      // keep it a running pointer (hipcc otherwise rebuilds base + k * step per piece)
-  };
-  auto issue = [&](int stage) __attribute__((always_inline)) {
-    char* sb = smem + stage * STG;
-    next_stage_steps();
-#pragma unroll
-    for (int i = 0; i < 10; ++i) issue_piece(i, sb);
-    left -= 64;
-  };
-
-  // transposed-read addresses: rows wt*32 + 8g + q (+4), column block i of a panel at 32*(i ^ key) + 8*(lane&3)
-  const uint32_t lbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int rowl = wt * 32 + 8 * (lane >> 4) + ((lane >> 2) & 3);
-  const int keyl = ((rowl >> 1) & 1) | (((rowl >> 3) & 1) << 1);
-  uint32_t toff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) toff[i] = lbase + rowl * 128 + 32 * (i ^ keyl) + 8 * (lane & 3);
-
-  f32x4 acc[4][12], accb[12];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 12; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 12; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // bias: sum of the dY-side columns, via one extra MFMA per dY block against a ones fragment
-  const bool biasP = P.db != nullptr && !P.swapped && q0 == 0;           // dY on the P side (4 blocks of this wave)
-  const bool biasQ = P.db != nullptr && P.swapped && p0 == 0 && wh == 0;  // dY on the Q side (12 blocks)
-  u32x4 ones;
-  {
-    h16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (h16)1.0f;
-    ones = __builtin_bit_cast(u32x4, o);
-  }
-
-  const int nstage = (mend - mbeg + 63) / 64;
-  // Software pipeline (one wave per SIMD, so nothing else hides a stall): while the 48 MFMAs of stage s run, the wave
-  // reads the fragments of stage s + 1 into the other register set and issues the DMA pieces of stage s + 3 -- one
-  // transposed read pair after every third MFMA, one DMA piece after every fourth.  Measured before this: stage time =
-  // reads + DMA issue + MFMAs in sequence (removing the MFMAs saved exactly their own 103 us, tools/README.md).
-  // A stage is ALWAYS issued and always read (past the end: zero page into a slot nobody reads, stale LDS into registers
-  // nobody uses), so the loop has no conditions and the wait in front of every stage is the constant vmcnt(10).
-  struct Frags {
-    u32x2 pl[4], ph[4], ql[12], qh[12];
-  };
-  Frags fa, fb;
-  // read pair r of a stage: r < 4 -> P fragment r (panel wh), r >= 4 -> Q fragment r - 4 (panels 2..4)
-  auto read_pair = [&](Frags& f, int r, uint32_t so) __attribute__((always_inline)) {
-    if (r < 4) {
-      const uint32_t a = toff[r] + so + wh * 8192;
-      asm volatile(SITK_WB_TR2("%0", "%1", "%2", 0, 512) : "=&v"(f.pl[r]), "=&v"(f.ph[r]) : "v"(a));
-    } else {
-      const int j = r - 4;
-      const uint32_t a = toff[j & 3] + so;
-      if (j < 4) asm volatile(SITK_WB_TR2("%0", "%1", "%2", 16384, 16896) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
-      else if (j < 8) asm volatile(SITK_WB_TR2("%0", "%1", "%2", 24576, 25088) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
-      else asm volatile(SITK_WB_TR2("%0", "%1", "%2", 32768, 33280) : "=&v"(f.ql[j]), "=&v"(f.qh[j]) : "v"(a));
-    }
-  };
-  for (int i = 0; i < NSTG - 1; ++i) issue(i);
-  asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) read_pair(fa, r, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // The stage loop exists in three instantiations (no bias / dY on the P side / dY on the Q side), chosen once per
-  // workgroup: with the bias MFMAs under a run-time condition inside ONE loop, hipcc carried the 12 bias tiles
-  // through VGPR copies of their AGPRs in every stage (441 v_accvgpr moves per 64 MFMAs).
-  auto stage_body = [&](Frags& cur, Frags& nxt, int s, auto bp, auto bq) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");          // stage s + 1 has landed (s + 2 may be in flight)
-    __builtin_amdgcn_s_barrier();
-    char* sb = smem + ((s + NSTG - 1) % NSTG) * STG;           // slot of stage s - 1: every wave has its fragments
-    const uint32_t so = ((s + 1) % NSTG) * STG;
-    next_stage_steps();
-    u32x4 fp[4], fqv[12];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fp[i] = u32x4{cur.pl[i][0], cur.pl[i][1], cur.ph[i][0], cur.ph[i][1]};
-#pragma unroll
-    for (int j = 0; j < 12; ++j) fqv[j] = u32x4{cur.ql[j][0], cur.ql[j][1], cur.qh[j][0], cur.qh[j][1]};
-#pragma unroll
-    for (int m = 0; m < 48; ++m) {
-      mma_acc_v(acc[m / 12][m % 12], fp[m / 12], fqv[m % 12]);
-      if (m % 3 == 0) read_pair(nxt, m / 3, so);
-      if (m % 4 == 3 && m / 4 < 10) issue_piece(m / 4, sb);
-    }
-    left -= 64;
-    if constexpr (decltype(bp)::value) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mma_acc_v(accb[i], fp[i], ones);
-    }
-    if constexpr (decltype(bq)::value) {
-#pragma unroll
-      for (int j = 0; j < 12; ++j) mma_acc_v(accb[j], ones, fqv[j]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  auto stages = [&](auto bp, auto bq) __attribute__((always_inline)) {
-    // stages in pairs (the two fragment sets swap roles); an odd count runs one all-zero padding stage
-    for (int s = 0; s < nstage; s += 2) {
-      stage_body(fa, fb, s, bp, bq);
-      stage_body(fb, fa, s + 1, bp, bq);
-    }
-  };
-  if (biasP) stages(std::true_type{}, std::false_type{});
-  else if (biasQ) stages(std::false_type{}, std::true_type{});
-  else stages(std::false_type{}, std::false_type{});
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the padding stages issued past the end
-  __builtin_amdgcn_s_barrier();   // every wave is done with the ring: reuse it for the token-half reduction
-
-  // acc[i][j][jj] <-> P column (row of the tile) wh*64 + 16i + 4fq + jj, Q column 16j + fr
-  const int fr = lane & 15, fq = lane >> 4;
-  float* red = reinterpret_cast<float*>(smem) + wh * (64 * 192);
-  if (wt == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 12; ++j)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) red[(16 * i + 4 * fq + jj) * 192 + 16 * j + fr] = acc[i][j][jj];
-  }
-  __syncthreads();
-  if (wt == 0) {                                      // the whole 128 x 192 tile, both token halves, now in LDS
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 12; ++j)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) red[(16 * i + 4 * fq + jj) * 192 + 16 * j + fr] += acc[i][j][jj];
-  }
-  __syncthreads();
-  // Write-out by all 256 threads in 16-byte pieces.  A tile that covers ALL tokens of its problem (splits == 1: the 12-layer
-  // launch of one GPU) is added straight into dW; token-split tiles go to the slab and are summed by the reduce kernel.
-  const float* til = reinterpret_cast<const float*>(smem);
-  const bool vec_ok = (P.lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(P.dW) & 15) == 0;
-  if (P.splits > 1) {
-    float* out = slab + (size_t)bid * WB_TILE_ELEMS;
-    for (int e4 = tid * 4; e4 < WB_TILE_ELEMS; e4 += 1024) *reinterpret_cast<f32x4*>(out + e4) = *reinterpret_cast<const f32x4*>(til + e4);
-  } else if (!P.swapped) {                            // dW rows = P columns
-    for (int e4 = tid * 4; e4 < WB_TILE_ELEMS; e4 += 1024) {
-      const int r = e4 / 192, c = e4 % 192, pc = p0 + r, qc = q0 + c;
-      if (pc >= P.cp || qc >= P.cq) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(til + e4);
-      float* dst = P.dW + (size_t)pc * P.lddw + qc;
-      if (qc + 3 < P.cq && vec_ok) {
-        *reinterpret_cast<f32x4*>(dst) += v;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (qc + e < P.cq) dst[e] += v[e];
-      }
-    }
-  } else {                                            // dW rows = Q columns: 4 consecutive P columns per thread
-    for (int t = tid; t < WB_TILE_ELEMS / 4; t += 256) {
-      const int c = t % 192, r0 = (t / 192) * 4, qc = q0 + c, pc = p0 + r0;
-      if (qc >= P.cq || pc >= P.cp) continue;
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = til[(r0 + e) * 192 + c];
-      float* dst = P.dW + (size_t)qc * P.lddw + pc;
-      if (pc + 3 < P.cp && vec_ok) {
-        *reinterpret_cast<f32x4*>(dst) += v;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (pc + e < P.cp) dst[e] += v[e];
-      }
-    }
-  }
-  // Bias gradient.  Each of the two token halves of the workgroup (wt) holds its own partial column sums: a tile over all
-  // tokens adds them to db with float atomics (two addends on a zeroed or already final value: the order cannot change
-  // the result bits ... of a two-term sum, fp addition being commutative); token-split tiles store them behind the tile
-  // slabs -- [block][wt][192] -- and the reduce kernel adds them in a fixed order.
-  float* bslab = slab + (size_t)gridDim.x * WB_TILE_ELEMS + ((size_t)bid * 2 + wt) * 192;
-  if (biasP && fr == 0) {   // column sums of dY blocks on the P side: accb[i][jj] <-> n = p0 + wh*64 + 16i + 4fq + jj
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int n = p0 + wh * 64 + 16 * i + 4 * fq + jj;
-        if (P.splits > 1) bslab[wh * 64 + 16 * i + 4 * fq + jj] = accb[i][jj];
-        else if (n < P.cp) unsafeAtomicAdd(P.db + n, accb[i][jj]);
-      }
-  }
-  if (biasQ && fq == 0) {   // dY on the Q side: every row of the ones product holds the sums; row 0 = (fq 0, jj 0)
-#pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      const int n = q0 + 16 * j + fr;
-      if (P.splits > 1) bslab[16 * j + fr] = accb[j][0];
-      else if (n < P.cq) unsafeAtomicAdd(P.db + n, accb[j][0]);
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------
-// The 128 x 384 form for dims 384 / 768 (every Linear of SiT-small / -base has one side that is a multiple of 384 and
-// the other a multiple of 128).  Counters of the 128 x 192 kernel at those sizes: 11.6 TB/s between L2 and the CUs
-// (640 B of operands per token and tile: 90 GB per step of config 5) with the matrix pipe a third busy -- the tile, not
-// the MFMA schedule, sets the time.  Twice the tile area on the Q side: 512 B of operands per token for twice the
-// products (0.8 x the bytes per flop).  Same wave tile (64 x 192 accumulator, 48 MFMAs per 32 tokens) and the same
-// hand-interleaved stage body; the four waves are 2 (P halves) x 2 (Q halves) and ALL of them take every token, so
-// a stage is 32 tokens (8 panels of 32 rows x 128 B = 32 KB), the ring is five stages deep (all 160 KB, four in flight)
-// and there is no token-half reduction.  The finished tile leaves through LDS in its two 128 x 192 halves, which are
-// exactly two adjacent tiles of the 128 x 192 numbering: WbProblem stays in those units (tiles, tiles_q, block_begin)
-// and the slab layout and the reduce kernel are shared.
+// Two forms of the double tile:
+//   WIDE  128 x 384 (0.8 x the operand bytes per flop of one block): dims 384 / 768, where every Linear has one side that
+//         is a multiple of 384 and the other a multiple of 128; the four waves are 2 (P halves) x 2 (Q halves);
+//   TALL  256 x 192 (0.7 x): dim 192 (576 = 2.25 x 256 and 192 = 0.75 x 256 are padded: 11 % more MFMAs, which were idle);
+//         the four waves are the four P quarters and share the Q fragments.
+// ALL four waves take every token of a stage (no token-half reduction at the end).  Software pipeline (one wave per SIMD, so
+// nothing else hides a stall): while the 48 MFMAs of stage s run, the wave reads the fragments of stage s + 1 into the
+// other register set and issues its DMA pieces of stage s + 4 -- one transposed read pair after every third MFMA, one DMA
+// piece after every sixth.  A stage is ALWAYS issued and always read (past the end: zero page into a slot nobody reads,
+// stale LDS into registers nobody uses), so the loop has no conditions and the wait in front of every stage is constant.
+// The stage loop exists in three instantiations (no bias / dY on the P side / dY on the Q side), chosen once per wave: with
+// the bias MFMAs under a run-time condition inside ONE loop, hipcc carried the bias tiles through VGPR copies of their
+// AGPRs in every stage.  The finished tile leaves through LDS in two 128 x 192 halves = two blocks of the block numbering
+// (side by side / one above the other; TALL rounds the P side up to an even number of block rows).
+// Measured (MI355X): config 5's 12-layer launch 7.82 -> 7.04 ms (matrix pipe 52 % busy at the 1.85 GHz the chip holds
+// under it), config 3's 1.85 -> 1.3 ms; SiT-tiny's two-layer side-stream launches 340 -> 260 us, its tail launch 180 -> 154 us.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __restrict__ slab) {
-  constexpr int PNL = 4096;       // one panel: 32 rows x 128 B
-  constexpr int STG = 8 * PNL;    // P0 P1 Q0 .. Q5
+template <bool TALL>
+__global__ __launch_bounds__(256) void wgrad_x2_kernel(WbGroup grp, float* __restrict__ slab) {
+  constexpr int PNL = 4096;                       // one panel: 32 rows x 128 B
+  constexpr int NPP = TALL ? 4 : 2, NQP = TALL ? 3 : 6;   // panels of the P / Q side = DMA pieces per wave of each side
+  constexpr int PCS = NPP + NQP;
+  constexpr int STG = PCS * PNL;
   constexpr int NSTG = 5;
-  constexpr int PCS = 8;          // DMA pieces per wave and stage: 2 of the P side, 6 of the Q side
   __shared__ __attribute__((aligned(256))) char smem[NSTG * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wq = wave & 1, wp = wave >> 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);            // in units of 128 x 384 tiles = two 128 x 192 blocks
+  const int wq = TALL ? 0 : (wave & 1), wp = TALL ? wave : (wave >> 1);
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);            // in units of double tiles = two 128 x 192 blocks
   int pi = 0;
   for (int i = 1; i < grp.count; ++i)
     if (2 * bid >= grp.p[i].block_begin) pi = i;
   const WbProblem P = grp.p[pi];
-  const int tiles_r = P.tiles >> 1, tq_r = P.tiles_q >> 1;
+  const int tiles_r = P.tiles >> 1, tq_r = TALL ? P.tiles_q : (P.tiles_q >> 1);
   const int local = bid - (P.block_begin >> 1);
   const int split = local / tiles_r, tile = local % tiles_r;
-  const int p0 = (tile / tq_r) * 128, q0 = (tile % tq_r) * 384;
+  const int pr = tile / tq_r, qr = tile % tq_r;
+  const int p0 = pr * (TALL ? 256 : 128), q0 = qr * (TALL ? 192 : 384);
   const int mbeg = split * P.chunk, mend = min(P.M, mbeg + P.chunk);
   const char* zero = reinterpret_cast<const char*>(g_zero_page_wb);
 
@@ -369,8 +109,8 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
   int prow[PCS], pdst[PCS];
 #pragma unroll
   for (int i = 0; i < PCS; ++i) {
-    const bool isP = i < 2;
-    const int q = isP ? wave * 2 + i : wave * 6 + (i - 2);
+    const bool isP = i < NPP;
+    const int q = isP ? wave * NPP + i : wave * NQP + (i - NPP);
     const int panel = q >> 2, row = (q & 3) * 8 + r8;
     const int key = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
     const int col = (isP ? p0 : q0) + panel * 64 + ((lane & 7) ^ (key << 1)) * 8;
@@ -380,7 +120,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
     const int frow = grp_i ? (lrow / grp_i) * (isP ? P.pstride : P.qstride) + (isP ? P.poffset : P.qoffset) + lrow % grp_i : lrow;
     pbase[i] = colok ? (isP ? P.P : P.Q) + (size_t)frow * ld + col : zerop;
     prow[i] = colok ? row : (1 << 30);
-    pdst[i] = (isP ? 0 : 2 * PNL) + q * 1024;
+    pdst[i] = (isP ? 0 : NPP * PNL) + q * 1024;
   }
   const char* zp = zero;
   asm volatile("" : "+v"(zp));
@@ -406,7 +146,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
     const char* src = prow[i] < left ? pcur[i] : zp;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sb + pdst[i]), 16, 0, 0);
-    pcur[i] += i < 2 ? incP : incQ;
+    pcur[i] += i < NPP ? incP : incQ;
     asm volatile("" : "+v"(pcur[i]));
   };
   auto issue = [&](int stage) __attribute__((always_inline)) {
@@ -425,7 +165,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
   for (int i = 0; i < 4; ++i) {
     const uint32_t t = lbase + rowl * 128 + 32 * (i ^ keyl) + 8 * (lane & 3);
     toffp[i] = t + wp * PNL;
-    toffq[i] = t + (2 + 3 * wq) * PNL;
+    toffq[i] = t + (NPP + 3 * wq) * PNL;
   }
 
   f32x4 acc[4][12], accb[12];
@@ -435,8 +175,10 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
     for (int j = 0; j < 12; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 12; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool biasP = P.db != nullptr && !P.swapped && q0 == 0 && wq == 0;   // dY on the P side: the 4 blocks of this P half
-  const bool biasQ = P.db != nullptr && P.swapped && p0 == 0 && wp == 0;    // dY on the Q side: the 12 blocks of this Q half
+  // bias: column sums of the dY side through one extra MFMA per dY block against a ones fragment, by the waves that own
+  // the columns once (P side: every wave its 64 columns, on the first Q tile; Q side: the waves of the first P quarter / half)
+  const bool biasP = P.db != nullptr && !P.swapped && q0 == 0 && wq == 0;
+  const bool biasQ = P.db != nullptr && P.swapped && p0 == 0 && wp == 0;
   u32x4 ones;
   {
     h16x8 o;
@@ -463,13 +205,13 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
     }
   };
   for (int i = 0; i < NSTG - 1; ++i) issue(i);
-  asm volatile("s_waitcnt vmcnt(24)" ::: "memory");            // stage 0 has landed (1..3 in flight)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PCS) : "memory");   // stage 0 has landed (1..3 in flight)
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int r = 0; r < 16; ++r) read_pair(fa, r, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   auto stage_body = [&](Frags& cur, Frags& nxt, int s, auto bp, auto bq) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");          // stage s + 1 has landed (s + 2, s + 3 may be in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PCS) : "memory");   // stage s + 1 has landed (s + 2, s + 3 may be in flight)
     __builtin_amdgcn_s_barrier();
     char* sb = smem + ((s + NSTG - 1) % NSTG) * STG;           // slot of stage s - 1: every wave has its fragments
     const uint32_t so = ((s + 1) % NSTG) * STG;
@@ -483,7 +225,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
     for (int m = 0; m < 48; ++m) {
       mma_acc_v(acc[m / 12][m % 12], fp[m / 12], fqv[m % 12]);
       if (m % 3 == 0) read_pair(nxt, m / 3, so);
-      if (m % 6 == 5) issue_piece(m / 6, sb);
+      if (m % 6 == 5 && m / 6 < PCS) issue_piece(m / 6, sb);
     }
     left -= 32;
     if constexpr (decltype(bp)::value) {
@@ -508,30 +250,32 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  // acc[i][j][jj] <-> P column wp*64 + 16i + 4fq + jj, Q column wq*192 + 16j + fr.  Half h of the tile (the waves with
-  // wq == h) = block `blk0 + h` of the 128 x 192 numbering.
+  // acc[i][j][jj] <-> P column wp*64 + 16i + 4fq + jj, Q column wq*192 + 16j + fr of the double tile.  Half h (WIDE: the
+  // waves with wq == h; TALL: those with wp / 2 == h) = one block of the 128 x 192 numbering:
   const int fr = lane & 15, fq = lane >> 4;
-  const size_t blk0 = (size_t)P.block_begin + (size_t)split * P.tiles + (size_t)tile * 2;
+  const size_t blk_base = (size_t)P.block_begin + (size_t)split * P.tiles;
+  auto blk_of = [&](int h) -> size_t { return blk_base + (TALL ? (size_t)(2 * pr + h) * P.tiles_q + qr : (size_t)tile * 2 + h); };
   const size_t total_blocks = (size_t)gridDim.x * 2;
   const bool vec_ok = (P.lddw & 3) == 0 && (reinterpret_cast<uintptr_t>(P.dW) & 15) == 0;
   float* til = reinterpret_cast<float*>(smem);
+  const int myh = TALL ? (wp >> 1) : wq, myrow = (TALL ? (wp & 1) : wp) * 64;
   for (int h = 0; h < 2; ++h) {
-    if (wq == h) {
+    if (myh == h) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 12; ++j)
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) til[(wp * 64 + 16 * i + 4 * fq + jj) * 192 + 16 * j + fr] = acc[i][j][jj];
+          for (int jj = 0; jj < 4; ++jj) til[(myrow + 16 * i + 4 * fq + jj) * 192 + 16 * j + fr] = acc[i][j][jj];
     }
     __syncthreads();
-    const int qh0 = q0 + 192 * h;
+    const int ph0 = p0 + (TALL ? 128 * h : 0), qh0 = q0 + (TALL ? 0 : 192 * h);
     if (P.splits > 1) {
-      float* out = slab + (blk0 + h) * WB_TILE_ELEMS;
+      float* out = slab + blk_of(h) * WB_TILE_ELEMS;
       for (int e4 = tid * 4; e4 < WB_TILE_ELEMS; e4 += 1024) *reinterpret_cast<f32x4*>(out + e4) = *reinterpret_cast<const f32x4*>(til + e4);
     } else if (!P.swapped) {
       for (int e4 = tid * 4; e4 < WB_TILE_ELEMS; e4 += 1024) {
-        const int r = e4 / 192, c = e4 % 192, pc = p0 + r, qc = qh0 + c;
+        const int r = e4 / 192, c = e4 % 192, pc = ph0 + r, qc = qh0 + c;
         if (pc >= P.cp || qc >= P.cq) continue;
         const f32x4 v = *reinterpret_cast<const f32x4*>(til + e4);
         float* dst = P.dW + (size_t)pc * P.lddw + qc;
@@ -545,7 +289,7 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
       }
     } else {
       for (int t = tid; t < WB_TILE_ELEMS / 4; t += 256) {
-        const int c = t % 192, r0 = (t / 192) * 4, qc = qh0 + c, pc = p0 + r0;
+        const int c = t % 192, r0 = (t / 192) * 4, qc = qh0 + c, pc = ph0 + r0;
         if (qc >= P.cq || pc >= P.cp) continue;
         f32x4 v;
 #pragma unroll
@@ -565,20 +309,22 @@ __global__ __launch_bounds__(256) void wgrad_wide_kernel(WbGroup grp, float* __r
   // Bias gradient: this kernel has no token halves -- the whole sum goes to slot 0 of the block's [2][192] pair, zeros to slot 1
   float* bs = slab + total_blocks * WB_TILE_ELEMS;
   if (biasP && fr == 0) {
+    const size_t blk = blk_of(myh);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
-        const int c = wp * 64 + 16 * i + 4 * fq + jj, n = p0 + c;
-        if (P.splits > 1) { bs[(blk0 * 2 + 0) * 192 + c] = accb[i][jj]; bs[(blk0 * 2 + 1) * 192 + c] = 0.f; }
+        const int c = myrow + 16 * i + 4 * fq + jj, n = p0 + (TALL ? 128 * myh : 0) + c;
+        if (P.splits > 1) { bs[(blk * 2 + 0) * 192 + c] = accb[i][jj]; bs[(blk * 2 + 1) * 192 + c] = 0.f; }
         else if (n < P.cp) unsafeAtomicAdd(P.db + n, accb[i][jj]);
       }
   }
   if (biasQ && fq == 0) {
+    const size_t blk = blk_of(TALL ? 0 : wq);
 #pragma unroll
     for (int j = 0; j < 12; ++j) {
       const int c = 16 * j + fr, n = q0 + 192 * wq + c;
-      if (P.splits > 1) { bs[((blk0 + wq) * 2 + 0) * 192 + c] = accb[j][0]; bs[((blk0 + wq) * 2 + 1) * 192 + c] = 0.f; }
+      if (P.splits > 1) { bs[(blk * 2 + 0) * 192 + c] = accb[j][0]; bs[(blk * 2 + 1) * 192 + c] = 0.f; }
       else if (n < P.cq) unsafeAtomicAdd(P.db + n, accb[j][0]);
     }
   }
@@ -663,18 +409,24 @@ static bool wb_wide(const sitk_wgrad_desc* d, int count) {
   return true;
 }
 
-// Plans a launch in units of 128 x 192 blocks.  wide: every tile is a PAIR of such blocks side by side (128 x 384); the Q
-// side must then be a multiple of 384, and rounds are counted in pairs.
-static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks, int& tiles_total, int cus = 256, bool wide = false) {
+// Plans a launch in units of 128 x 192 blocks; a workgroup takes a PAIR of them (WIDE: side by side, the Q side is then
+// a multiple of 384; TALL: one above the other, the P side rounded up to an even number of block rows) and rounds are
+// counted in pairs.
+enum { WB_WIDE = 1, WB_TALL = 2 };
+static int wb_mode(const sitk_wgrad_desc* d, int count) { return wb_wide(d, count) ? WB_WIDE : WB_TALL; }
+
+static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks, int& tiles_total, int cus, int mode) {
   tiles_total = 0;
+  const bool wide = mode == WB_WIDE, tall = mode == WB_TALL;
   const int qm = wide ? 384 : 192;
+  auto prows = [&](int cp) { return tall ? 2 * cdiv(cp, 256) : cdiv(cp, 128); };   // block rows of the P side (TALL: an even number)
   for (int i = 0; i < count; ++i) {
     WbProblem& p = g.p[i];
     // Q side (192-column tiles) = X columns (k) or dY columns (n): whichever orientation needs fewer 128 x 192 tiles
     // (net.3 of dim 192: dY 192 x X 768 is 2 x 4 tiles with dY on the 128 side, half of them half empty, but 6 x 1
     // the other way round)
-    const int tiles_normal = d[i].K % qm == 0 ? cdiv(d[i].N, 128) * (d[i].K / 192) : (1 << 30);
-    const int tiles_swapped = d[i].N % qm == 0 ? cdiv(d[i].K, 128) * (d[i].N / 192) : (1 << 30);
+    const int tiles_normal = d[i].K % qm == 0 ? prows(d[i].N) * (d[i].K / 192) : (1 << 30);
+    const int tiles_swapped = d[i].N % qm == 0 ? prows(d[i].K) * (d[i].N / 192) : (1 << 30);
     const bool normal = tiles_normal <= tiles_swapped;
     p.swapped = normal ? 0 : 1;
     p.P = reinterpret_cast<const h16*>(normal ? d[i].dY : d[i].X);
@@ -691,19 +443,19 @@ static int wb_plan(const sitk_wgrad_desc* d, int count, WbGroup& g, int& blocks,
       (normal ? p.poffset : p.qoffset) = d[i].dymap.offset;
     }
     p.tiles_q = p.cq / 192;
-    p.tiles = cdiv(p.cp, 128) * p.tiles_q;
+    p.tiles = prows(p.cp) * p.tiles_q;
     tiles_total += p.tiles;
   }
   g.count = count;
   blocks = 0;
   // Token splits.  Up to one round of tiles (one workgroup per CU): split until the 256 CUs are covered.  More than one
   // round: every tile is the same amount of work, so the launch takes ceil(blocks / 256) rounds; 2 - 4 token splits
-  // shorten the rounds and fill the last one (config 3: 864 tiles = 3.4 rounds run as 4; split in two, 6.75 as 7:
+  // shorten the rounds and fill the last one (3.4 rounds run as 4; split in two, 6.75 as 7:
   // -12 %), at the price of one slab write + read per block (~1.5 % of a block's operand bytes per split).
   // cus < 256: the launch is meant to run BESIDE another kernel chain on the CUs that chain leaves idle (encoder.hip's side
   // streams): it may occupy `cus` CUs, not the chip
   int many = 1;
-  const int units = wide ? tiles_total / 2 : tiles_total;      // workgroups per split
+  const int units = tiles_total / 2;                            // workgroups per split (two blocks each)
   if (units > cus) {
     double best = 1e30;
     for (int sp = 1; sp <= 4; ++sp) {
@@ -736,7 +488,7 @@ extern "C" size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int c
     if (!wb_eligible(d[i])) return 0;
   WbGroup g;
   int blocks, tiles;
-  wb_plan(d, count, g, blocks, tiles, 256, wb_wide(d, count));             // (a launch for fewer CUs checks its own plan against the size it is given)
+  wb_plan(d, count, g, blocks, tiles, 256, wb_mode(d, count));             // (a launch for fewer CUs checks its own plan against the size it is given)
   return (size_t)blocks * (WB_TILE_ELEMS + 2 * 192) * sizeof(float);      // tile slabs + bias partials of split tiles
 }
 
@@ -762,13 +514,13 @@ extern "C" int sitk_gemm_wgrad_group_ws_cus(const sitk_wgrad_desc* d, int count,
     SITK_REQUIRE(d[i].dY && d[i].X && d[i].dW, "gemm_wgrad_group_ws: null operand in problem %d", i);
   WbGroup g;
   int blocks, tiles;
-  const bool wide = wb_wide(d, count);
-  wb_plan(d, count, g, blocks, tiles, cus, wide);
+  const int mode = wb_mode(d, count);
+  wb_plan(d, count, g, blocks, tiles, cus, mode);
   SITK_REQUIRE((size_t)blocks * (WB_TILE_ELEMS + 2 * 192) * sizeof(float) <= ws_bytes, "gemm_wgrad_group_ws: workspace of %zu bytes, "
                "%d blocks planned for %d CUs", ws_bytes, blocks, cus);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (wide) hipLaunchKernelGGL(wgrad_wide_kernel, dim3(blocks / 2), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
-  else hipLaunchKernelGGL(wgrad_big_kernel, dim3(blocks), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
+  if (mode == WB_WIDE) hipLaunchKernelGGL(wgrad_x2_kernel<false>, dim3(blocks / 2), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
+  else hipLaunchKernelGGL(wgrad_x2_kernel<true>, dim3(blocks / 2), dim3(256), 0, s, g, reinterpret_cast<float*>(ws));
   SITK_LAUNCH_CHECK("wgrad_big");
   bool any_split = false;
   for (int i = 0; i < count; ++i) any_split |= g.p[i].splits > 1;

@@ -135,7 +135,7 @@ class TrainEngine:
                   the CUs its one-wave kernels leave idle (sitk_encoder_bwd_overlap); 0 = off.  Needs eager launches.
     use_graph:    True = the step is replayed from hipGraph(s) (one per segment); False = eager launches.
                   None (default) with wgrad_overlap None: the faster of the two forms measured for the configuration --
-                  eager + 7 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192), hipGraph
+                  eager + 8 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192), hipGraph
                   replay without a side stream everywhere else (other widths, data parallelism: there the idle CUs belong
                   to the gradient all-reduce).
 
@@ -259,7 +259,7 @@ class TrainEngine:
 
         # backward slices (last layer first) and the gradient ranges that become final after each
         fused = self.dtype != rt.F32 and bool(rt.lib.sitk_mlp_fused_supported(self.D, tr.mlp_dim, self.dtype))
-        # Data parallelism on the 16-bit fused path, eager launches (the default there): TWO slices -- the first 7 / 12 of the
+        # Data parallelism on the 16-bit fused path, eager launches (the default there): TWO slices -- the first 2 / 3 of the
         # layers, whose weight gradients all go to the side stream beside the rest of the chain exactly as on one GPU, and the
         # rest, whose weight gradients run on the main stream behind the chain.  The first slice's bucket is all-reduced from the
         # side stream's context (the process group's stream then waits for the side stream, the main chain for nothing), the
@@ -267,7 +267,7 @@ class TrainEngine:
         self.dp_side = bool(self.dp and fused and wgrad_overlap is None and use_graph is not True and bwd_slices is None
                             and tr.depth >= 2)
         if self.dp_side:
-            k = min(tr.depth - 1, max(1, round(7 / 12 * tr.depth)))
+            k = min(tr.depth - 1, max(1, round(2 / 3 * tr.depth)))
             self.slices = [(tr.depth - k, tr.depth), (0, tr.depth - k)]
             bwd_slices = 2
         if bwd_slices is None:
@@ -279,9 +279,10 @@ class TrainEngine:
             self.slices = [(bounds[i], bounds[i + 1]) for i in range(bwd_slices)][::-1]
         auto = wgrad_overlap is None
         if auto:
-            # measured on MI355X (tiny, B = 64, eager launches): 2.56 ms without, 2.49 with 6 - 7 of 12 layers on the side
-            # stream, 2.55 with 8, 2.66 with 9 (the side stream then finishes after the chain's own tail launch)
-            wgrad_overlap = round(7 / 12 * tr.depth) if (use_graph is not True and fused and not self.dp and bwd_slices == 1) else 0
+            # measured on MI355X (tiny, B = 64, eager launches, 256 x 192 weight-gradient tiles): 2.56 ms without, 2.45 with 7 of
+            # 12 layers on the side stream, 2.43 with 8, 2.46 with 9, 2.52 with 10 (the side stream then finishes after the chain's
+            # own tail launch); with round 2's 128 x 192 tiles the optimum was 7
+            wgrad_overlap = round(2 / 3 * tr.depth) if (use_graph is not True and fused and not self.dp and bwd_slices == 1) else 0
         if wgrad_overlap > 0 and (self.dp or bwd_slices != 1 or use_graph):
             # A step with a forked side stream is enqueued eagerly: replayed from a hipGraph, ROCm 7.2 runs the two branches on
             # two queues but the chain's own kernels then start late (2.82 ms per step against 2.49 eager; the host needs ~0.4

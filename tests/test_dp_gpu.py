@@ -319,7 +319,7 @@ def _rccl_side_worker(port, dtype, q):
     x, y = _data320()
     eng = engine.TrainEngine(_make_model320(dtype), B320, input_layout="patched", lr=LR320, momentum=0.9,
                              process_group=dist.group.WORLD, device="cuda:0")
-    assert eng.dp and eng.dp_side and not eng.use_graph and eng.slices == [(2, 4), (0, 2)] and eng.wgrad_overlap == 2
+    assert eng.dp and eng.dp_side and not eng.use_graph and eng.slices == [(1, 4), (0, 1)] and eng.wgrad_overlap == 3
     losses = []
     for _ in range(3):
         losses.append(float(eng.step(x.cuda(), y.cuda())))
