@@ -129,8 +129,8 @@ int sitk_gemm_nt(const sitk_gemm_desc* d, int dtype, sitk_stream_t stream);
 
 /* Weight gradient: dW[n][k] += sum_m dY[m][n] X[m][k], optionally db[n] += sum_m dY[m][n]; fp32 accumulation.
  * sitk_gemm_wgrad / _group (64 x 64 tiles, any shape): token chunks are summed into dW with float atomics (the result
- * depends on arrival order in the last bits).  sitk_gemm_wgrad_group_ws on eligible shapes (the encoder's): 128 x 192
- * tiles, no float atomics -- a tile that covers all tokens is added straight into dW, token-split tiles go through a
+ * depends on arrival order in the last bits).  sitk_gemm_wgrad_group_ws on eligible shapes (the encoder's): 256 x 192 /
+ * 128 x 384 tiles, no float atomics -- a tile that covers all tokens is added straight into dW, token-split tiles go through a
  * slab in the workspace and a fixed-order reduction.
  *   dY (M, N): `dtype` or fp32 (dy_is_f32); X (M, K) `dtype`; row maps as above.  The large-tile path reads whole
  * 16-byte vectors: when N (or K) is not a multiple of 8, columns [N, round_up(N, 8)) of dY (X) must exist (lddy / ldx
@@ -154,7 +154,7 @@ int sitk_gemm_wgrad(const sitk_wgrad_desc* d, int dtype, sitk_stream_t stream);
 /* Up to 4 independent weight gradients (the four Linears of one encoder layer) in ONE launch. */
 int sitk_gemm_wgrad_group(const sitk_wgrad_desc* d, int count, int dtype, sitk_stream_t stream);
 /* Same, with a caller-provided workspace: when every problem is bf16 with a dimension that is a multiple
- * of 192 the large-tile kernel (128 x 192 tiles, partial tiles reduced through the workspace instead of
+ * of 192 the large-tile kernel (256 x 192 or 128 x 384 tiles, token-split tiles reduced through the workspace instead of
  * float atomics) runs; otherwise, or if `ws` is NULL / too small, this is sitk_gemm_wgrad_group.
  * sitk_gemm_wgrad_group_ws_bytes returns the workspace size that selects the large-tile path (0 = n/a). */
 size_t sitk_gemm_wgrad_group_ws_bytes(const sitk_wgrad_desc* d, int count, int dtype);
