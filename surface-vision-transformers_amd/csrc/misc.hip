@@ -368,48 +368,95 @@ SITK_DEV void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 SITK_DEV float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0, 1), 24 bits
 
 // One workgroup per sample.  corrupted_sequence: EXACTLY n_mask patches per sample, the n_mask largest of P uniform
-// scores (models/mpp.py:25-33, get_mask_from_prob: rand -> topk -> scatter_), found by ranking (ties by index); swap draw
-// U < p_swap, random_patches uniform in [0, P), replace draw U < p_replace (models/mpp.py:36-43, 95-110).
+// scores (models/mpp.py:25-33, get_mask_from_prob: rand -> topk -> scatter_; ties by index: the patch with the smaller
+// index wins); swap draw U < p_swap, random_patches uniform in [0, P), replace draw U < p_replace (models/mpp.py:36-43,
+// 95-110).  The scores are 24-bit integers (u01 keeps 24 bits), so the n_mask-th largest is found by a RADIX SELECT --
+// three passes of a 256-bucket histogram in LDS over the keys that still match the prefix, one wave locating the bucket
+// that holds the n_mask-th key -- instead of ranking every patch against every other (rounds 1 - 2: O(P^2), 206 us at
+// P = 1280 with every one of P / 64 blocks per sample re-drawing all P scores; now O(P), one block per sample).  Same
+// flags as the ranking produced, bit for bit.
 constexpr int MPP_MAX_P = 2048;
 __global__ __launch_bounds__(256) void mpp_draw_kernel(const uint64_t* __restrict__ state, uint8_t* __restrict__ masked,
                                                        uint8_t* __restrict__ swap_draw, int32_t* __restrict__ random_patches,
                                                        uint8_t* __restrict__ replace_draw, uint8_t* __restrict__ replaced_full,
                                                        int P, int n_mask, float p_swap, float p_replace) {
-  __shared__ float score[MPP_MAX_P];
-  const int b = blockIdx.x, i_begin = blockIdx.y * 64;      // grid (B, ceil(P / 64)): every block scores the whole sample (cheap)
-  const uint64_t seed = state[0], draw = state[1];          // and ranks / flags 64 of its patches
+  __shared__ uint32_t key[MPP_MAX_P];
+  __shared__ int hist[256];
+  __shared__ int sel[2];                                      // chosen bucket, keys still to take from it and below
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint64_t seed = state[0], draw = state[1];
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  for (int i = threadIdx.x; i < P; i += 256) {
-    uint32_t c[4] = {(uint32_t)draw, (uint32_t)i, (uint32_t)(draw >> 32), (uint32_t)b};
-    philox4x32(c, k0, k1);
-    score[i] = u01(c[0]);
-    if (i >= i_begin && i < i_begin + 64) {
+  uint8_t rep[MPP_MAX_P / 256];
+#pragma unroll
+  for (int t = 0; t < MPP_MAX_P / 256; ++t) {
+    const int i = tid + 256 * t;
+    rep[t] = 0;
+    if (i < P) {
+      uint32_t c[4] = {(uint32_t)draw, (uint32_t)i, (uint32_t)(draw >> 32), (uint32_t)b};
+      philox4x32(c, k0, k1);
+      key[i] = c[0] >> 8;                                     // u01(c[0]) = key / 2^24: the same order
       const size_t row = (size_t)b * P + i;
       if (swap_draw) { swap_draw[row] = u01(c[1]) < p_swap; random_patches[row] = (int32_t)(((uint64_t)c[2] * (uint32_t)P) >> 32); }
-      replace_draw[row] = u01(c[3]) < p_replace;
+      rep[t] = u01(c[3]) < p_replace;
+      replace_draw[row] = rep[t];
     }
   }
-  __syncthreads();
-  // rank of score i = number of scores that beat it (ties by index); four lanes share one i and a quarter of the j each
-  const int q4 = threadIdx.x & 3;
-  {
-    const int i = i_begin + (threadIdx.x >> 2);
-    const float si = i < P ? score[i] : 0.f;
-    int rank = 0;
-    for (int j = q4; j < P; j += 4) {
-      const float sj = score[j];
-      rank += (sj > si) || (sj == si && j < i);
+  // the key T of rank n_mask - 1 (0-based, descending) and r = how many keys equal to T are taken (those of lowest index)
+  uint32_t prefix = 0, known = 0;
+  int need = n_mask;
+  if (n_mask > 0 && n_mask < P) {
+    for (int pass = 2; pass >= 0; --pass) {
+      hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < P; i += 256)
+        if (((key[i] ^ prefix) & known) == 0) atomicAdd(&hist[(key[i] >> (8 * pass)) & 255], 1);
+      __syncthreads();
+      if (tid < 64) {                                         // lane l owns buckets 255 - 4l .. 252 - 4l (descending order)
+        int h[4], s = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { h[e] = hist[255 - 4 * tid - e]; s += h[e]; }
+        int incl = s;                                         // inclusive prefix over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(incl, d, 64);
+          if (tid >= d) incl += o;
+        }
+        int above = incl - s;                                 // keys in buckets above this lane's
+        if (above < need && need <= incl) {                   // exactly one lane: the bucket with the need-th key is here
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (above < need && need <= above + h[e]) { sel[0] = 255 - 4 * tid - e; sel[1] = need - above; }
+            above += h[e];
+          }
+        }
+      }
+      __syncthreads();
+      prefix |= (uint32_t)sel[0] << (8 * pass);
+      known |= 255u << (8 * pass);
+      need = sel[1];
+      __syncthreads();
     }
-    rank += __shfl_xor(rank, 1, 64);
-    rank += __shfl_xor(rank, 2, 64);
-    if (i < P && q4 == 0) {
+  }
+  const uint32_t T = prefix;
+#pragma unroll
+  for (int t = 0; t < MPP_MAX_P / 256; ++t) {
+    const int i = tid + 256 * t;
+    if (i < P) {
+      uint8_t m;
+      if (n_mask <= 0) m = 0;
+      else if (n_mask >= P) m = 1;
+      else if (key[i] != T) m = key[i] > T;
+      else {                                                  // a tie on the threshold (rare): the `need` lowest indices win
+        int before = 0;
+        for (int j = 0; j < i; ++j) before += key[j] == T;
+        m = before < need;
+      }
       const size_t row = (size_t)b * P + i;
-      const uint8_t m = rank < n_mask;
       masked[row] = m;
-      replaced_full[(size_t)b * (P + 1) + 1 + i] = m && replace_draw[row];
+      replaced_full[(size_t)b * (P + 1) + 1 + i] = m && rep[t];
     }
   }
-  if (threadIdx.x == 0 && blockIdx.y == 0) replaced_full[(size_t)b * (P + 1)] = 0;
+  if (tid == 0) replaced_full[(size_t)b * (P + 1)] = 0;
 }
 
 // Patch gather (tools/preprocessing.py:74-84 + Rearrange, as gather_tokens_kernel) fused with the corruption of
@@ -868,7 +915,7 @@ extern "C" int sitk_mpp_draw(const uint64_t* state, uint8_t* masked, uint8_t* sw
   SITK_REQUIRE(state && masked && replace_draw && replaced_full, "mpp_draw: null pointer");
   SITK_REQUIRE((swap_draw == nullptr) == (random_patches == nullptr), "mpp_draw: swap_draw and random_patches go together");
   SITK_REQUIRE(B > 0 && P > 0 && P <= MPP_MAX_P && n_mask >= 0 && n_mask <= P, "mpp_draw: bad shape (P <= %d)", MPP_MAX_P);
-  hipLaunchKernelGGL(mpp_draw_kernel, dim3(B, cdiv(P, 64)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), state, masked, swap_draw,
+  hipLaunchKernelGGL(mpp_draw_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), state, masked, swap_draw,
                      random_patches, replace_draw, replaced_full, P, n_mask, p_swap, p_replace);
   return check_launch("mpp_draw");
 }

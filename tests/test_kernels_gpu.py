@@ -624,6 +624,79 @@ def test_mpp_device_draws_statistics_and_fresh_masks():
     assert not torch.equal(m, m3) and (m3.sum(1) == n_mask).all()
 
 
+def _philox4x32_10(c, k0, k1):
+    """numpy Philox4x32-10 (Salmon et al., SC'11): c = four uint32 arrays, key (k0, k1)."""
+    import numpy as np
+    c = [x.astype(np.uint64) for x in c]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    M = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c[0], np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & M, p1 & M, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & M, p0 & M]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & M, (k1 + np.uint64(0xBB67AE85)) & M
+    return c
+
+
+@pytest.mark.parametrize("B,P,n_mask", [(32, 1280, 960), (5, 2048, 1), (3, 100, 99), (4, 320, 0), (4, 320, 320), (64, 320, 240),
+                                        (2, 1283, 641)])
+def test_mpp_draw_is_the_exact_top_k_of_its_scores(B, P, n_mask):
+    """The radix select of sitk_mpp_draw against a host replay of its Philox scores: the n_mask largest 24-bit scores of every
+    sample, ties to the lower index (models/mpp.py:25-33: rand -> topk -> scatter_), bit for bit; and a forced tie."""
+    import numpy as np
+    from sitk import runtime as rt
+    seed, draw = 0x1234567 + (99 << 32), 17
+    state = torch.tensor([seed, draw], dtype=torch.int64, device=DEV)
+    m = torch.full((B * P,), 9, dtype=torch.uint8, device=DEV)
+    re_ = torch.zeros(B * P, dtype=torch.uint8, device=DEV)
+    rf = torch.zeros((B, P + 1), dtype=torch.uint8, device=DEV)
+    rt.check(rt.lib.sitk_mpp_draw(state.data_ptr(), m.data_ptr(), None, None, re_.data_ptr(), rf.data_ptr(), B, P, n_mask, 0.0, 0.5,
+                                  rt.stream_ptr()))
+    bb, ii = np.meshgrid(np.arange(B, dtype=np.uint32), np.arange(P, dtype=np.uint32), indexing="ij")
+    c = _philox4x32_10([np.full_like(bb, draw & 0xFFFFFFFF), ii, np.full_like(bb, draw >> 32), bb], seed & 0xFFFFFFFF, seed >> 32)
+    key = (c[0] >> np.uint64(8)).astype(np.int64)
+    order = np.lexsort((np.broadcast_to(np.arange(P), (B, P)), -key), axis=1)      # descending key, ties by ascending index
+    want = np.zeros((B, P), dtype=np.uint8)
+    np.put_along_axis(want, order[:, :n_mask], 1, axis=1)
+    got = m.view(B, P).cpu().numpy()
+    assert (got == want).all(), int((got != want).sum())
+    rep = ((c[3] >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0) < np.float32(0.5)).astype(np.uint8)
+    assert (re_.view(B, P).cpu().numpy() == rep).all()
+    assert (rf[:, 1:].cpu().numpy() == (want & rep)).all() and int(rf[:, 0].sum()) == 0
+
+
+def test_mpp_draw_breaks_a_tie_on_the_threshold_by_index():
+    """P = 2048 scores of 24 bits collide in about one sample of eight: take n_mask so that the top-k boundary falls BETWEEN the
+    two patches of a tied pair (host replay of the scores) -- the lower index is masked, the higher is not."""
+    import numpy as np
+    from sitk import runtime as rt
+    B, P = 64, 2048
+    seed, draw = 424242, 3
+    bb, ii = np.meshgrid(np.arange(B, dtype=np.uint32), np.arange(P, dtype=np.uint32), indexing="ij")
+    c = _philox4x32_10([np.full_like(bb, draw), ii, np.zeros_like(bb), bb], seed, 0)
+    key = (c[0] >> np.uint64(8)).astype(np.int64)
+    order = np.lexsort((np.broadcast_to(np.arange(P), (B, P)), -key), axis=1)
+    n_mask = None
+    for b in range(B):
+        ks = key[b][order[b]]
+        dup = np.nonzero(ks[1:] == ks[:-1])[0]
+        if len(dup):
+            n_mask, b_tie, lo, hi = int(dup[0]) + 1, b, int(order[b][dup[0]]), int(order[b][dup[0] + 1])
+            break
+    assert n_mask is not None, "no tied scores in 64 samples of 2048 (expected in ~1 of 8)"
+    assert lo < hi and key[b_tie][lo] == key[b_tie][hi]
+    state = torch.tensor([seed, draw], dtype=torch.int64, device=DEV)
+    m = torch.zeros(B * P, dtype=torch.uint8, device=DEV)
+    re_ = torch.zeros(B * P, dtype=torch.uint8, device=DEV)
+    rf = torch.zeros((B, P + 1), dtype=torch.uint8, device=DEV)
+    rt.check(rt.lib.sitk_mpp_draw(state.data_ptr(), m.data_ptr(), None, None, re_.data_ptr(), rf.data_ptr(), B, P, n_mask, 0.0, 0.5,
+                                  rt.stream_ptr()))
+    want = np.zeros((B, P), dtype=np.uint8)
+    np.put_along_axis(want, order[:, :n_mask], 1, axis=1)
+    got = m.view(B, P).cpu().numpy()
+    assert got[b_tie][lo] == 1 and got[b_tie][hi] == 0
+    assert (got == want).all() and (got.sum(1) == n_mask).all()
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_mpp_gather_corrupt_equals_gather_then_corrupt(ops, dtype):
     """One pass (engine) == sitk_gather_tokens(fp32) + sitk_mpp_corrupt, bit for bit, and the draw counter advances."""
