@@ -173,6 +173,9 @@ class TrainEngine:
         tr = sit.transformer
         if tr.p_dropout > 0 or sit.dropout.p > 0:
             raise rt.SitkError("TrainEngine: dropout > 0 is not implemented on the fused path")
+        if tr.depth and (tr.layers[0][0].fn.dim_head != 64 or not tr.layers[0][0].fn.project_out):
+            raise rt.SitkError("TrainEngine: the fused path needs dim_head = 64 and a projected attention output "
+                               "(the modules run other head widths stage by stage)")
         self.depth = tr.depth
         self.opt = dict(kind=optimizer, lr=lr, momentum=momentum, wd=weight_decay, nesterov=nesterov, betas=betas, eps=eps)
         self.keep_grads = keep_grads

@@ -202,28 +202,28 @@ class LayerNormFn(torch.autograd.Function):
 
 
 class AttentionFn(torch.autograd.Function):
-    """softmax(q k^T dim_head^-0.5) v for qkv (B, N, 3 H 64) fp32 laid out [q | k | v], each (h d) h-major -> (B, N, H 64) fp32."""
+    """softmax(q k^T scale) v for qkv (B, N, 3 H 64) fp32 laid out [q | k | v], each (h d) h-major -> (B, N, H 64) fp32."""
 
     @staticmethod
-    def forward(ctx, qkv, heads, dtype):
+    def forward(ctx, qkv, heads, dtype, scale=0.125):
         B, N, _ = qkv.shape
         code = rt.dtype_code(dtype)
         qc = qkv.detach().reshape(B * N, -1).to(rt.torch_dtype(code)).contiguous()
-        o, lse = ops.attention_fwd(qc, B, N, heads, 0.125, dtype)
+        o, lse = ops.attention_fwd(qc, B, N, heads, float(scale), dtype)
         ctx.save_for_backward(qc, o, lse)
-        ctx.meta = (B, N, heads, dtype)
+        ctx.meta = (B, N, heads, dtype, float(scale))
         return o.float().view(B, N, heads * 64)
 
     @staticmethod
     def backward(ctx, d_o):
         qc, o, lse = ctx.saved_tensors
-        B, N, heads, dtype = ctx.meta
+        B, N, heads, dtype, scale = ctx.meta
         S = _f16_scale(d_o, dtype)
         dob = (d_o if S is None else d_o * S).reshape(B * N, -1).to(qc.dtype).contiguous()
-        dqkv = ops.attention_bwd(qc, o, dob, lse, B, N, heads, 0.125, dtype).float()
+        dqkv = ops.attention_bwd(qc, o, dob, lse, B, N, heads, scale, dtype).float()
         if S is not None:
             dqkv = dqkv * (1.0 / S)
-        return dqkv.view(B, N, -1), None, None
+        return dqkv.view(B, N, -1), None, None, None
 
 
 class GeluFn(torch.autograd.Function):

@@ -34,14 +34,16 @@ class PreNorm(nn.Module):
 class Attention(nn.Module):
     def __init__(self, dim, heads, dim_head, dropout):
         super().__init__()
-        if dim_head != 64:
-            raise SitkError(f"dim_head={dim_head}: the attention kernels are specialised for dim_head=64 "
-                            "(every reference config: config/SiT/training/hparams.yml:33-45)")
+        if dim_head > 64 or dim_head < 1:
+            raise SitkError(f"dim_head={dim_head}: the attention kernels hold 64 features per head (every reference config uses "
+                            "64: config/SiT/training/hparams.yml:33-45); smaller heads run zero-padded, larger ones are not implemented")
         inner = heads * dim_head
         self.heads, self.dim_head = heads, dim_head
         self.scale = dim_head ** -0.5
         self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
-        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+        # vit_pytorch: no output projection for a single head as wide as the model
+        self.project_out = not (heads == 1 and dim_head == dim)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout)) if self.project_out else nn.Identity()
 
 
 class FeedForward(nn.Module):
@@ -75,26 +77,44 @@ class Transformer(nn.Module):
                         ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias])
         return out
 
-    def _forward_with_dropout(self, x):
-        """Training with dropout > 0 (the three nn.Dropout of a vit_pytorch block: behind to_out.0, behind GELU, behind net.3):
-        the block stage by stage -- LayerNorm, Linear, attention, GELU and dropout + residual each as its own libsitk launch --
-        instead of the fused per-block kernels, which have no mask plumbing.  Every reference configuration sets dropout 0.0
-        (config/SiT/training/hparams.yml:46): this path exists so that the constructor argument is honoured, not for speed.
-        The masks come from a device-side Philox stream seeded from torch's seed at first use."""
-        dt, p = self.compute_dtype, self.p_dropout
+    def fused_ok(self):
+        """The fused per-block kernels cover dropout 0, 64 features per head and a projected attention output -- every
+        reference configuration; anything else runs stage by stage."""
+        a = self.layers[0][0].fn if len(self.layers) else None
+        return not (self.training and self.p_dropout > 0) and (a is None or (a.dim_head == 64 and a.project_out))
+
+    def _forward_staged(self, x):
+        """The block stage by stage -- LayerNorm, Linear, attention, GELU and dropout + residual each as its own libsitk launch
+        -- instead of the fused per-block kernels, for what those do not cover: training with dropout > 0 (the three
+        nn.Dropout of a vit_pytorch block: behind to_out.0, behind GELU, behind net.3; the fused kernels have no mask
+        plumbing), heads narrower than 64 features (q, k, v zero-padded to 64: the scores and the first dim_head output
+        features are unchanged) and the projection-free single head.  Every reference configuration sets dropout 0.0 and
+        dim_head 64 (config/SiT/training/hparams.yml:33-46): this path exists so that the constructor arguments are honoured,
+        not for speed.  The masks come from a device-side Philox stream seeded from torch's seed at first use."""
+        dt = self.compute_dtype
+        p = self.p_dropout if self.training else 0.0
         if self._drop_state is None or self._drop_state.device != x.device:
             self._drop_state = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=x.device)
         st = self._drop_state
         x = x.float()
+        B, N, _ = x.shape
         for attn, ff in self.layers:
+            a = attn.fn
+            H, dh = a.heads, a.dim_head
             h = Fn.LayerNormFn.apply(x, attn.norm.weight, attn.norm.bias)
-            qkv = Fn.LinearFn.apply(h, attn.fn.to_qkv.weight, None, dt)
-            o = Fn.AttentionFn.apply(qkv, self.heads, dt)
-            y = Fn.LinearFn.apply(o, attn.fn.to_out[0].weight, attn.fn.to_out[0].bias, dt)
+            qkv = Fn.LinearFn.apply(h, a.to_qkv.weight, None, dt)
+            if dh != 64:                                       # (h d) per q | k | v: zero features 'dh..63' of every head
+                qkv = torch.nn.functional.pad(qkv.view(B, N, 3 * H, dh), (0, 64 - dh)).view(B, N, 3 * H * 64)
+            o = Fn.AttentionFn.apply(qkv, H, dt, a.scale)
+            if dh != 64:
+                o = o.view(B, N, H, 64)[..., :dh].reshape(B, N, H * dh)
+            y = Fn.LinearFn.apply(o, a.to_out[0].weight, a.to_out[0].bias, dt) if a.project_out else o
             x = Fn.DropoutResidualFn.apply(y, x, p, st)
             h = Fn.LayerNormFn.apply(x, ff.norm.weight, ff.norm.bias)
             u = Fn.LinearFn.apply(h, ff.fn.net[0].weight, ff.fn.net[0].bias, dt)
-            g = Fn.DropoutResidualFn.apply(Fn.GeluFn.apply(u), None, p, st)
+            g = Fn.GeluFn.apply(u)
+            if p > 0:
+                g = Fn.DropoutResidualFn.apply(g, None, p, st)
             y = Fn.LinearFn.apply(g, ff.fn.net[3].weight, ff.fn.net[3].bias, dt)
             x = Fn.DropoutResidualFn.apply(y, x, p, st)
         return x
@@ -102,8 +122,8 @@ class Transformer(nn.Module):
     def forward(self, x):
         if not x.is_cuda:
             raise SitkError("sitk Transformer: input must be on the GPU (no CPU path)")
-        if self.training and self.p_dropout > 0:
-            return self._forward_with_dropout(x)
+        if not self.fused_ok():
+            return self._forward_staged(x)
         flat = [p for layer in self.layer_tensors() for p in layer]
         cfg = (self.dim, self.depth, self.heads, self.mlp_dim, self.compute_dtype)
         return Fn.EncoderFn.apply(x.float(), cfg, *flat)
