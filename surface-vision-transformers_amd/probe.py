@@ -177,7 +177,7 @@ def layer_kernels(eng, nset):
         probs, nl = probs[:4], 1
         nb_all = rt.lib.sitk_gemm_wgrad_group_ws_bytes(*_desc_array(probs), rt.dtype_code(dt))
     ws_all = torch.empty(max(nb_all, 16), dtype=torch.uint8, device=dev)
-    add(f"weight gradients of {nl} layer(s), one launch", "wgrad_big_kernel" if nb_all else "wgrad_kernel",
+    add(f"weight gradients of {nl} layer(s), one launch", "wgrad_x2_kernel" if nb_all else "wgrad_kernel",
         lambda i: ops.gemm_wgrad_group(probs, dt, workspace=ws_all if nb_all else None), wg_flops * nl,
         nl * R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L // nl, "wgrad")
     if fused_qkv:
