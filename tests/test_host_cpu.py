@@ -84,7 +84,11 @@ def test_ctor_validation(sitk_pkg):
     with pytest.raises(AssertionError):
         SiT(dim=192, depth=1, heads=3, mlp_dim=768, pool="max")
     with pytest.raises(SitkError):
-        SiT(dim=192, depth=1, heads=3, mlp_dim=768, dim_head=32)
+        SiT(dim=192, depth=1, heads=3, mlp_dim=768, dim_head=128)  # the kernels hold 64 features per head; narrower heads are padded
+    m = SiT(dim=192, depth=1, heads=3, mlp_dim=768, dim_head=32)
+    assert m.transformer.layers[0][0].fn.to_qkv.weight.shape == (3 * 3 * 32, 192) and not m.transformer.fused_ok()
+    single = SiT(dim=64, depth=1, heads=1, mlp_dim=128, dim_head=64)    # vit_pytorch: no output projection, no to_out.* keys
+    assert not any("to_out" in k for k in single.state_dict())
     with pytest.raises(TypeError):
         SiT(192, 1, 3, 768)                                     # keyword-only, like models/sit.py:26
 
