@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (no side stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="A/B: the patch gather on the main stream, in front of the patch embedding")
     ap.add_argument("--wgrad-overlap", type=int, default=None,
                     help="layers whose weight gradients run on a side stream beside the backward chain (default: engine's choice)")
     ap.add_argument("--dp-form", action="store_true",
@@ -188,7 +189,7 @@ def main():
                                          channels=4, num_vertices=V)
     eng = engine.TrainEngine(model, B, task=args.task, input_layout="surface", lr=1e-5, momentum=0.9,
                              process_group=pg, use_graph=(True if args.graph else (False if args.no_graph else None)), device=dev,
-                             wgrad_overlap=args.wgrad_overlap)
+                             wgrad_overlap=args.wgrad_overlap, prefetch_gather=not args.no_prefetch)
     g = torch.Generator(device=dev).manual_seed(100 + rank)   # every rank its own synthetic shard
     x = torch.randn((B, 40962, 4), device=dev, generator=g)
     y = torch.randn((B,), device=dev, generator=g) * 2 + 40 if args.task == "regression" else None

@@ -133,6 +133,8 @@ class TrainEngine:
 
     wgrad_overlap: number of layers whose weight gradients run on a side stream BESIDE the rest of the backward chain, on
                   the CUs its one-wave kernels leave idle (sitk_encoder_bwd_overlap); 0 = off.  Needs eager launches.
+    prefetch_gather: with a side stream, enqueue the patch gather of a regression step there (it then runs beside the previous
+                  step's tail); False = in front of the patch embedding on the main stream.
     use_graph:    True = the step is replayed from hipGraph(s) (one per segment); False = eager launches.
                   None (default) with wgrad_overlap None: the faster of the two forms measured for the configuration --
                   eager + 8 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192), hipGraph
@@ -147,7 +149,7 @@ class TrainEngine:
     def __init__(self, model, batch_size, *, task="regression", input_layout="surface", loss="mse", optimizer="sgd",
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
-                 wgrad_overlap=None):
+                 wgrad_overlap=None, prefetch_gather=True):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -299,7 +301,16 @@ class TrainEngine:
         self.wgrad_overlap = int(wgrad_overlap)
         self._overlap = rt.lib.sitk_overlap_create(max_side, 42, 1) if wgrad_overlap > 0 else None
         self._side = rt.lib.sitk_overlap_stream(self._overlap) if self._overlap else None
-        self._side_torch = torch.cuda.ExternalStream(self._side, device=self.device) if self.dp_side else None
+        self._side_torch = torch.cuda.ExternalStream(self._side, device=self.device) if self._overlap else None
+        # With a side stream the patch gather of a regression step -- which reads the input batch and the patch table, no
+        # parameter -- is enqueued THERE, in front of the fork that orders the weight staging behind the previous step's
+        # optimizer pass: it runs as soon as the side stream has finished the previous step's work, i.e. beside that step's
+        # tail launch and optimizer, instead of in front of the patch embedding (30 us of the chain).  The previous step's
+        # tail still reads ITS tokens (the patch embedding's weight gradient): two token buffers, alternating.
+        self._prefetch = bool(prefetch_gather and self._overlap and self.layout == "surface" and task == "regression")
+        if self._prefetch:
+            self._tok_bufs = (self.tokens, torch.zeros_like(self.tokens))
+            self._ev_gather, self._ev_inp, self._inp_dirty = torch.cuda.Event(), torch.cuda.Event(), False
         if use_graph is None:
             use_graph = not self._overlap
         self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices), len(self.slices))
@@ -337,8 +348,17 @@ class TrainEngine:
         lin = sit.to_patch_embedding[1]
         if self.keep_grads:
             self.fp.grad_all.zero_()                    # gradients + loss + padded embedding gradient
+        if self._prefetch:
+            self.tokens = self._tok_bufs[self.nsteps & 1]
+            if self._inp_dirty:                         # load_batch() / the index copy of this step, enqueued on the main stream
+                self._side_torch.wait_event(self._ev_inp)
+                self._inp_dirty = False
+            self._gather(self.tokens, ld, dt, stream=self._side)
+            self._ev_gather.record(self._side_torch)
         save = self._stage_beside()
-        if self.layout == "surface":
+        if self._prefetch:
+            torch.cuda.current_stream(self.device).wait_event(self._ev_gather)
+        elif self.layout == "surface":
             self._gather(self.tokens, ld, dt)
         else:
             rt.check(L.sitk_patchify(self.inp.data_ptr(), self.tokens.data_ptr(), B, self.Cc, P, self.V, ld, dt, s))
@@ -354,10 +374,10 @@ class TrainEngine:
                                           self.ncls, self.pool_mean, int(self.loss_kind == "l1"), self.head_ws.data_ptr(),
                                           self.gscale.data_ptr() if self.loss_scaled else None, s))
 
-    def _gather(self, out, ld, dt):
+    def _gather(self, out, ld, dt, stream=None):
         """patch gather of the batch: from the static input buffer, or -- after load_dataset() -- straight from the resident
         data set through the step's sample indices (their labels ride along); per-channel normalisation fused if set."""
-        L, s = rt.lib, self._s()
+        L, s = rt.lib, (stream if stream is not None else self._s())
         mean, std = (self.norm[0].data_ptr(), self.norm[1].data_ptr()) if self.norm else (None, None)
         if self.dataset is not None:
             x_all, t_all = self.dataset
@@ -589,6 +609,13 @@ class TrainEngine:
         self.inp.copy_(x, non_blocking=True)
         if target is not None:
             self.target.copy_(target.reshape(self.target.shape), non_blocking=True)
+        self._mark_input()
+
+    def _mark_input(self):
+        """The step's gather runs on the side stream (see _prefetch): it must see the input / index copy enqueued just now."""
+        if getattr(self, "_prefetch", False):
+            self._ev_inp.record(torch.cuda.current_stream(self.device))
+            self._inp_dirty = True
 
     def load_dataset(self, x_all, targets_all=None):
         """Keep a whole data set resident in HBM: x_all (S, 40962, C) fp32 raw (un-normalised if `normalise` was given)
@@ -605,6 +632,7 @@ class TrainEngine:
             assert self.task != "regression" or t_all.shape[1] == self.ncls
         self.dataset = (x_all, t_all)
         self.idx.zero_()
+        self._mark_input()
         self._graphs = None                               # the gather node changes: capture again
 
     def unload_dataset(self):
@@ -631,7 +659,12 @@ class TrainEngine:
                 torch._assert_async(((idx >= 0) & (idx < S)).all())
             elif idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= S):
                 raise rt.SitkError(f"step(indices=...): indices must lie in [0, {S}), got [{int(idx.min())}, {int(idx.max())}]")
-            self.idx.copy_(idx.to(torch.int32), non_blocking=True)
+            if getattr(self, "_prefetch", False) and not idx.is_cuda:
+                with torch.cuda.stream(self._side_torch):           # host indices: the copy rides in front of the gather on ITS stream
+                    self.idx.copy_(idx.to(torch.int32), non_blocking=True)
+            else:
+                self.idx.copy_(idx.to(torch.int32), non_blocking=True)
+                self._mark_input()
         elif x is not None:
             if self.dataset is not None:
                 raise rt.SitkError("step(x, ...): a resident data set is loaded (load_dataset); select samples with "

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-SITK_PARITY_RECORD=1 timeout -k 10 600 python -m pytest tests/test_models_gpu.py -m gpu -q -k "narrow or wide_heads or dropout" > gpurun_out/r3_one.log 2>&1; rc=$?
-tail -25 gpurun_out/r3_one.log
-grep "parity bf16 dropout" gpurun_out/r3_one.log
-exit $rc
+for rep in 1 2 3 4; do
+timeout -k 10 200 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-probe 2>/dev/null | python -c "import sys,json;d=json.loads([l for l in sys.stdin if l.startswith('{')][0]);print('prefetch   ', d['ms_per_step'], d['value'])"
+timeout -k 10 200 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-probe --no-prefetch 2>/dev/null | python -c "import sys,json;d=json.loads([l for l in sys.stdin if l.startswith('{')][0]);print('no prefetch', d['ms_per_step'], d['value'])"
+done
