@@ -134,7 +134,9 @@ class TrainEngine:
     wgrad_overlap: number of layers whose weight gradients run on a side stream BESIDE the rest of the backward chain, on
                   the CUs its one-wave kernels leave idle (sitk_encoder_bwd_overlap); 0 = off.  Needs eager launches.
     prefetch_gather: with a side stream, enqueue the patch gather of a regression step there (it then runs beside the previous
-                  step's tail); False = in front of the patch embedding on the main stream.
+                  step's tail); False = in front of the patch embedding on the main stream.  Inputs must then reach the
+                  engine through load_batch() / step(x, ...) / step(indices=...), which order that gather behind their copy
+                  (a direct write into `eng.inp` on another stream is not seen by the side stream).
     use_graph:    True = the step is replayed from hipGraph(s) (one per segment); False = eager launches.
                   None (default) with wgrad_overlap None: the faster of the two forms measured for the configuration --
                   eager + 8 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192), hipGraph
