@@ -519,6 +519,23 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams
     }
     SITK_NST(4)                                                // fragment reads + MFMAs
   }
+  // GELU' epilogue: the saved u of this wave's two 16 x 96 blocks is requested HERE, as whole 192-byte row segments (3 x 16
+  // bytes per lane and block), and turned into accumulator layout through the wave's staging slot below.  Read in accumulator
+  // layout (8 bytes per lane: 16 rows x 32 bytes per wave instruction, six of them per block) the same bytes cost 23 us of
+  // the 112 us of config 3's d net.3 product (profiles/r03_gemm_experiments.txt).
+  u32x4 urow[2][3];
+  if constexpr (EPI == SITK_EPI_DGELU) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int it = 0; it < 3; ++it) {
+        const int c = it * 64 + lane, row = c / 12, cc = c % 12, m = m0 + wm * 32 + 16 * j + row;
+        urow[j][it] = u32x4{0u, 0u, 0u, 0u};
+        if (m < p.M)
+          urow[j][it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux +
+                                                        n0 + wn * 96 + cc * 8);
+      }
+  }
   __builtin_amdgcn_s_barrier();
   SITK_NST(5)
   // epilogue through a wave-private staging area (the k-tile stages are free now)
@@ -527,12 +544,32 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams
   for (int j = 0; j < 2; ++j) {
     const int mrow = m0 + wm * 32 + 16 * j;
     f32x4 v1[6], v2[6];
+    if constexpr (EPI == SITK_EPI_DGELU) {
+      constexpr int PU = 96 * 2 + 16;                              // padded row pitch of the u block in the slot
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int n = n0 + wn * 96 + 16 * i + 4 * fq, m = mrow + fr;
-      v1[i] = acc[i][j];
-      v2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (m < p.M && n < p.N) epilogue_math<T, EPI, true>(p, m, n, v1[i], v2[i]);     // (the residual joins in row layout below)
+      for (int it = 0; it < 3; ++it) {
+        const int c = it * 64 + lane;
+        *reinterpret_cast<u32x4*>(slot + (c / 12) * PU + (c % 12) * 16) = urow[j][it];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const f32x4 u = load4(reinterpret_cast<const T*>(slot + fr * PU) + 16 * i + 4 * fq);
+        v1[i] = acc[i][j];
+        if (p.bias) v1[i] += load4(p.bias + n0 + wn * 96 + 16 * i + 4 * fq);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const GeluParts gp = gelu_parts<T>(u[e]);
+          v1[i][e] *= fmaf(u[e], gp.pdf, gp.cdf);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int n = n0 + wn * 96 + 16 * i + 4 * fq, m = mrow + fr;
+        v1[i] = acc[i][j];
+        v2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < p.M && n < p.N) epilogue_math<T, EPI, true>(p, m, n, v1[i], v2[i]);     // (the residual joins in row layout below)
+      }
     }
     staged_rows_store<TO, 96, EPI == SITK_EPI_BIAS_RES>(slot, v1, reinterpret_cast<TO*>(p.out), p, mrow, n0 + wn * 96, lane);
     if constexpr (EPI == SITK_EPI_BIAS_GELU) staged_rows_store<T, 96>(slot, v2, reinterpret_cast<T*>(p.out2), p, mrow, n0 + wn * 96, lane);
@@ -606,7 +643,7 @@ static int launch_gemm_nt(const GemmParams& p, hipStream_t s) {
         (sizeof(TO) == 4 || p.ldo % 8 == 0))
       return launch_gemm_nt_wres<TO, EPI>(p, s);
     if (p.K > 192 && p.N % 192 == 0 && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 && p.M >= 1024 &&
-        (sizeof(TO) == 4 || p.ldo % 8 == 0))
+        (sizeof(TO) == 4 || p.ldo % 8 == 0) && (EPI != SITK_EPI_DGELU || p.ldaux % 8 == 0))
       return launch_gemm_nt_n192<TO, EPI>(p, s);
   }
   const bool wide = (p.N % 128 == 0) || p.N > 1024;
