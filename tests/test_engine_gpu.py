@@ -384,6 +384,40 @@ def test_resident_dataset_pipeline(pk):
         assert torch.equal(e2.target.cpu(), torch.from_numpy(labels[picks[-1]]))
 
 
+@pytest.mark.parametrize("feed", ["batches", "indices_host", "indices_device"])
+def test_prefetched_gather_sees_every_new_batch(pk, feed):
+    """With a side stream the patch gather of step t + 1 is enqueued there and runs beside step t's tail (two token buffers;
+    load_batch() / the index copy order it behind the new input).  A DIFFERENT batch every step, fed through step(x, y) or
+    through a resident data set with host / device indices: losses and parameters bit-equal to an engine whose gather sits
+    in front of the patch embedding on the main stream."""
+    sit, _, engine = pk
+    S, B, steps = 12, 8, 5
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=3, num_patches=320, num_vertices=153, num_channels=4)
+    base = sit.SiT(**kw, compute_dtype="bf16")
+    _load(base, 17)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    xs = torch.randn((S, 40962, 4), device=DEV, generator=g)
+    ys = torch.randn((S, 1), device=DEV, generator=g) + 40
+    picks = [torch.randperm(S, generator=torch.Generator().manual_seed(i))[:B] for i in range(steps)]
+    out = []
+    for prefetch in (True, False):
+        eng = engine.TrainEngine(copy.deepcopy(base), B, input_layout="surface", lr=1e-3, momentum=0.9, prefetch_gather=prefetch)
+        assert bool(eng._overlap) and eng._prefetch == prefetch
+        if feed != "batches":
+            eng.load_dataset(xs, ys)
+        losses = []
+        for idx in picks:
+            if feed == "batches":
+                losses.append(eng.step(xs[idx.to(DEV)], ys[idx.to(DEV)]).clone())
+            else:
+                losses.append(eng.step(indices=idx.to(DEV) if feed == "indices_device" else idx.numpy()).clone())
+        torch.cuda.synchronize()
+        out.append((torch.cat(losses), eng.fp.flat.clone()))
+    assert torch.equal(out[0][0], out[1][0]), (out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1])
+    assert len(set(float(v) for v in out[0][0])) == steps          # the batches did differ
+
+
 @pytest.mark.parametrize("tscale", [1e-4, 1.0, 1e4])
 def test_f16_loss_scale_follows_the_batch(pk, tscale):
     """f16 compute mode: the gradient stream is scaled by a power of two the fused head + loss call picks from THIS batch's
