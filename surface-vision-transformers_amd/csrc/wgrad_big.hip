@@ -78,7 +78,7 @@ SITK_DEV void mma_acc_v(f32x4& acc, u32x4 a, u32x4 b) {
 // AGPRs in every stage.  The finished tile leaves through LDS in two 128 x 192 halves = two blocks of the block numbering
 // (side by side / one above the other; TALL rounds the P side up to an even number of block rows).
 // Measured (MI355X): config 5's 12-layer launch 7.82 -> 7.04 ms (matrix pipe 52 % busy at the 1.85 GHz the chip holds
-// under it), config 3's 1.85 -> 1.3 ms; SiT-tiny's two-layer side-stream launches 340 -> 260 us, its tail launch 180 -> 154 us.
+// under it), config 3's 1.85 -> 1.71 ms; SiT-tiny's 12-layer launch 337 -> 302 us, its two-layer side-stream launches 340 -> 260 us.
 // ------------------------------------------------------------------------------------------
 template <bool TALL>
 __global__ __launch_bounds__(256) void wgrad_x2_kernel(WbGroup grp, float* __restrict__ slab) {
