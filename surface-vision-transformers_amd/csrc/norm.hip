@@ -277,7 +277,11 @@ static int launch_colsum(const TI* in, int ld, const uint8_t* fa, const uint8_t*
     hipLaunchKernelGGL((colsum_det_kernel<TI>), dim3(cdiv(c4n, 64)), dim3(256), 0, s, in, ld, fa, fb, (int)rows, cols, out, out2, cols2);
     return check_launch("colsum_det");
   }
-  int cg = 256;                                             // threads across columns: a power of two covering cols / 4, <= 256
+  // threads across columns: 16 (a 256-byte row segment per workgroup row; a power of two covering cols / 4 when that is
+  // less).  Narrow column groups mean MORE workgroups for the same number of atomics per output address: with one group
+  // of 256 threads across the 768 columns of config 5's d mask_token sum only 64 workgroups read its 126 MB (266 us);
+  // 12 groups x 42 row ranges read them in ~35 us
+  int cg = 16;
   while (cg / 2 >= c4n && cg > 1) cg /= 2;
   const int gx = cdiv(c4n, cg);
   // row ranges: enough workgroups to fill the chip once, at most ~64 atomics per output address
