@@ -13,6 +13,7 @@ all-reduced (RCCL, on the process group's own stream) while the remaining slices
 Unlike tools/train.py:293-296 nothing here synchronises with the host: `step()` returns a device
 scalar (the loss) and never calls .item().
 """
+import contextlib
 import ctypes as C
 import math
 
@@ -418,6 +419,13 @@ class TrainEngine:
         # sitk_encoder_bwd_overlap left behind the chain's last kernel) they run beside the tail weight-gradient launch.
         rt.check(rt.lib.sitk_colsum_f32_dup(self.dx.data_ptr(), B, N * D, N * D, gpos.data_ptr(),
                                             g(sit.cls_token).data_ptr(), D, self._side if self._overlap else self._s()))
+        if self.task == "mpp":
+            # d mask_token = (sum of dx over the replaced rows) W_embed: reads the chain's final dx like the sums above, so with a
+            # side stream it runs there too, beside the tail weight-gradient launch (27 us at the end of the step otherwise)
+            with (torch.cuda.stream(self._side_torch) if self._overlap else contextlib.nullcontext()):
+                ops.masked_colsum(self.dx, self.replaced_full.view(-1), None, self.rsum, "f32")
+                rt.check(rt.lib.sitk_stage_weight(lin.weight.data_ptr(), D, K, None, 0, self.we_t.data_ptr(), D, dt, self._s()))
+                ops.gemm_nt(self.rsum, self.we_t, g(self.ssl.mask_token).view(1, K), dt, M=1, N=K, K=D)
         if self._overlap:
             rt.check(rt.lib.sitk_overlap_join(self._overlap, self._s()))      # every gradient of the step is behind this point
 
@@ -503,9 +511,6 @@ class TrainEngine:
                 lo = ssl.to_original
                 ops.gemm_wgrad(self.dout_c, self.enc_out, self.fp.g(lo.weight), dt, db=self.fp.g(lo.bias), M=self.B * self.P,
                                N=K, K=D)
-            ops.masked_colsum(self.dx, self.replaced_full.view(-1), None, self.rsum, "f32")
-            rt.check(L.sitk_stage_weight(lin.weight.data_ptr(), D, K, None, 0, self.we_t.data_ptr(), D, dt, s))
-            ops.gemm_nt(self.rsum, self.we_t, self.fp.g(ssl.mask_token).view(1, K), dt, M=1, N=K, K=D)
 
     @property
     def last_randoms(self):
