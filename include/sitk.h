@@ -40,7 +40,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 8
+#define SITK_ABI_VERSION 9
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -102,8 +102,9 @@ typedef struct {
 
 #define SITK_EPI_STORE 0     /* out = acc (+bias)                                  out_dtype any  */
 #define SITK_EPI_BIAS_RES 1  /* out(f32) = acc + bias + aux(f32)   residual / pos-embedding add   */
-#define SITK_EPI_BIAS_GELU 2 /* out = u = acc + bias ; out2 = gelu_erf(u)          both `dtype`   */
-#define SITK_EPI_DGELU 3     /* out = acc * gelu_erf'(aux)          aux = saved u, both `dtype`   */
+#define SITK_EPI_BIAS_GELU 2 /* u = acc + bias; out = gelu_erf'(u) - 1/2, out2 = gelu_erf(u)  both `dtype` (ABI 9: the centred
+                                derivative is saved, not u -- backward needs u only through it)                   */
+#define SITK_EPI_DGELU 3     /* out = acc * (aux + 1/2)   aux = the value saved by BIAS_GELU, both `dtype`         */
 
 typedef struct {
   int M, N, K;
@@ -191,16 +192,18 @@ int sitk_layernorm_bwd(const void* dy, const float* x, const float* mean, const 
  *   forward : out = x + gelu(LN(x) W1^T + b1) W2^T + b2
  *     x (rows, D) fp32; w1_c (M, D), w2_c (D, M) `dtype` copies; out (rows, D) fp32 (may not alias x)
  *     saved for backward (each may be NULL): h = LN(x) (rows, D) `dtype`, mean/rstd (rows) fp32,
- *     u (rows, M) `dtype` pre-activation; g = gelu(u) (rows, M) `dtype` only when asked for.
- *   backward: dx = dy + LN'(dh), dh = du W1, du = (dy W2) * gelu'(u)
- *     dy fp32 + dy_c its `dtype` copy; x/mean/rstd/u as saved; w2t_c = W2^T (M, D), w1t_c = W1^T (D, M);
- *     writes du and (when g != NULL) g = gelu(u) (rows, M) `dtype` -- the operands of the two weight
- *     gradients; pass NULL when forward saved g --, dx fp32 and
- *     dx_c its `dtype` copy, and per-workgroup LayerNorm dgamma/dbeta sums to `partials`
- *     (sitk_mlp_bwd_partial_floats(rows) floats, layout [workgroup][2][D], workgroup = 128 rows).   */
+ *     gd = gelu'(u) - 1/2 (rows, M) `dtype`, u = the pre-activation LN(x) W1^T + b1 (ABI 9: the DERIVATIVE is saved,
+ *     not u itself -- forward has Phi(u) in hand, backward's elementwise phase becomes one multiply-add; centred so that
+ *     the 16-bit rounding is finest near u = 0, where most pre-activations are);
+ *     g = gelu(u) (rows, M) `dtype`, the operand of net.3's weight gradient.
+ *   backward: dx = dy + LN'(dh), dh = du W1, du = (dy W2) * (gd + 1/2)
+ *     dy fp32 + dy_c its `dtype` copy; x/mean/rstd/gd as saved; w2t_c = W2^T (M, D), w1t_c = W1^T (D, M);
+ *     writes du (rows, M) `dtype` (operand of net.0's weight gradient), dx fp32 and dx_c its `dtype` copy, and
+ *     per-workgroup LayerNorm dgamma/dbeta sums to `partials`
+ *     (sitk_mlp_bwd_partial_floats(rows) floats, layout [workgroup][2][D], workgroup = 96 or 128 rows).   */
 int sitk_mlp_fused_supported(int D, int M, int dtype);
 int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b, const void* w1_c, const float* b1,
-                 const void* w2_c, const float* b2, void* h, float* mean, float* rstd, void* u, void* g,
+                 const void* w2_c, const float* b2, void* h, float* mean, float* rstd, void* gd, void* g,
                  float* out, int64_t rows, int D, int M, int dtype, sitk_stream_t stream);
 /* forward with the attention output projection folded in (state-dict keys layers.i.0.fn.to_out.0 + the first
  * residual add of the block): x_mid = x + o Wo^T + bo is computed in the kernel's prologue, written to `xmid`
@@ -209,22 +212,21 @@ int sitk_mlp_fwd(const float* x, const float* ln_w, const float* ln_b, const voi
 int sitk_attn_out_mlp_fused_supported(int64_t rows, int D, int I, int M, int dtype);
 int sitk_attn_out_mlp_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
                           const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
-                          const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
+                          const float* b2, void* h, float* mean, float* rstd, void* gd, void* g, float* out,
                           int64_t rows, int D, int I, int M, int dtype, sitk_stream_t stream);
 /* ... and with the NEXT block's LayerNorm + to_qkv appended (layers.{i+1}.0.norm, layers.{i+1}.0.fn.to_qkv):
  * n_h = LN(out) (may be NULL), n_mean/n_rstd, n_qkv = n_h Wqkv^T (rows, N3) -- one launch from the attention
  * output of block i to the attention input of block i + 1.                                                    */
 int sitk_attn_out_mlp_next_fwd(const void* o_c, const void* wo_c, const float* bo, const float* x, float* xmid,
                                const float* ln_w, const float* ln_b, const void* w1_c, const float* b1, const void* w2_c,
-                               const float* b2, void* h, float* mean, float* rstd, void* u, void* g, float* out,
+                               const float* b2, void* h, float* mean, float* rstd, void* gd, void* g, float* out,
                                const float* n_ln_w, const float* n_ln_b, const void* n_wqkv_c, void* n_h, float* n_mean,
                                float* n_rstd, void* n_qkv, int N3, int64_t rows, int D, int I, int M, int dtype,
                                sitk_stream_t stream);
 size_t sitk_mlp_bwd_partial_floats(int64_t rows);
 int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
-                 const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,
-                 float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
-                 sitk_stream_t stream);
+                 const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du, float* dx,
+                 void* dx_c, float* partials, int64_t rows, int D, int M, int dtype, sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused LayerNorm + bias-free projection of the attention half of a block, PreNorm(LayerNorm, Attention)

@@ -169,7 +169,7 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
     a.xmid = (float*)take(R * D * 4);
     a.h1 = take(R * D * es); a.qkv = take(R * 3 * I * es); a.o = take(R * I * es);
     a.h2 = take(R * D * es); a.u = take(R * M * es);
-    a.g = (mlp_fused(c) && !g_in_fwd()) ? nullptr : take(R * M * es);   // the fused MLP recomputes gelu(u) in backward
+    a.g = take(R * M * es);
   }
   L.acts_bytes = off;
   off = 0;
@@ -187,7 +187,7 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
   L.scratch.dxAc.resize(nslot); L.scratch.dxBc.resize(nslot);
   for (int i = 0; i < nslot; ++i) {
     L.scratch.du[i] = stake(R * M * es);
-    L.scratch.g[i] = (mlp_fused(c) && !g_in_fwd()) ? stake(R * M * es) : nullptr;
+    L.scratch.g[i] = nullptr;
     L.scratch.dqkv[i] = stake(R * 3 * I * es);
     L.scratch.dxAc[i] = stake(R * D * es);
     L.scratch.dxBc[i] = stake(R * D * es);
@@ -503,8 +503,8 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
     float* part2 = S.ln_partials + (size_t)(2 * l + 1) * S.ln_partial_floats;
     const void* gact = a.g;
     if (mlp_fused(c)) {
-      SITK_TRY(sitk_mlp_bwd(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, a.g ? nullptr : S.g[sl], S.dxB, dxBc,
-                            part2, R, D, M, dt, stream));
+      SITK_TRY(sitk_mlp_bwd(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, S.dxB, dxBc, part2, R, D, M, dt,
+                            stream));
       SITK_MARK("mlp_bwd");
       ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, (int)(sitk_mlp_bwd_partial_floats(R) / (2 * D))});
       gact = a.g ? a.g : S.g[sl];

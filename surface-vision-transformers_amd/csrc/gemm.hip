@@ -75,23 +75,22 @@ SITK_DEV void gemm_epilogue(const GemmParams& p, int m, int n, f32x4 v) {
     const f32x4 r = load4(reinterpret_cast<const float*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
     store4(reinterpret_cast<float*>(p.out) + orow, v + r);
   } else if constexpr (EPI == SITK_EPI_BIAS_GELU) {
-    store4(reinterpret_cast<T*>(p.out) + orow, v);
     f32x4 g;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) g[i] = v[i] * gelu_parts<T>(v[i]).cdf;
+    for (int i = 0; i < 4; ++i) {
+      const GeluParts gp = gelu_parts<T>(v[i]);
+      g[i] = v[i] * gp.cdf;
+      v[i] = fmaf(v[i], gp.pdf, gp.cdf) - 0.5f;              // gelu'(u) - 1/2 = Phi(u) - 1/2 + u phi(u): saved instead of u
+    }
+    store4(reinterpret_cast<T*>(p.out) + orow, v);
     store4(reinterpret_cast<T*>(p.out2) + orow, g);
   } else if constexpr (EPI == SITK_EPI_DGELU) {
-    const f32x4 u = load4(reinterpret_cast<const T*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const GeluParts gp = gelu_parts<T>(u[i]);
-      v[i] *= fmaf(u[i], gp.pdf, gp.cdf);
-    }
+    v *= load4(reinterpret_cast<const T*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n) + 0.5f;   // aux = the saved gelu'(u) - 1/2
     store4(reinterpret_cast<T*>(p.out) + orow, v);
   }
 }
 
-// Epilogue math only (no stores): v <- acc (+bias) (+residual | * gelu'(u)); v2 <- gelu(v) for BIAS_GELU.
+// Epilogue math only (no stores): v <- acc (+bias) (+residual | * aux); BIAS_GELU: v2 <- gelu(v), v <- gelu'(v).
 template <typename T, int EPI, bool RES_LATER = false>
 SITK_DEV void epilogue_math(const GemmParams& p, int m, int n, f32x4& v, f32x4& v2) {
   if (p.bias) v += load4(p.bias + n);
@@ -99,14 +98,13 @@ SITK_DEV void epilogue_math(const GemmParams& p, int m, int n, f32x4& v, f32x4& 
     if constexpr (!RES_LATER) v += load4(reinterpret_cast<const float*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
   } else if constexpr (EPI == SITK_EPI_BIAS_GELU) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v2[i] = v[i] * gelu_parts<T>(v[i]).cdf;
-  } else if constexpr (EPI == SITK_EPI_DGELU) {
-    const f32x4 u = load4(reinterpret_cast<const T*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n);
-#pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const GeluParts gp = gelu_parts<T>(u[i]);
-      v[i] *= fmaf(u[i], gp.pdf, gp.cdf);
+      const GeluParts gp = gelu_parts<T>(v[i]);
+      v2[i] = v[i] * gp.cdf;
+      v[i] = fmaf(v[i], gp.pdf, gp.cdf) - 0.5f;              // gelu'(u) - 1/2, saved instead of u
     }
+  } else if constexpr (EPI == SITK_EPI_DGELU) {
+    v *= load4(reinterpret_cast<const T*>(p.aux) + (size_t)map_row(p.auxmap, m) * p.ldaux + n) + 0.5f;   // aux = the saved gelu'(u) - 1/2
   }
 }
 
@@ -519,7 +517,7 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams
     }
     SITK_NST(4)                                                // fragment reads + MFMAs
   }
-  // GELU' epilogue: the saved u of this wave's two 16 x 96 blocks is requested HERE, as whole 192-byte row segments (3 x 16
+  // GELU' epilogue: the saved gelu'(u) of this wave's two 16 x 96 blocks is requested HERE, as whole 192-byte row segments (3 x 16
   // bytes per lane and block), and turned into accumulator layout through the wave's staging slot below.  Read in accumulator
   // layout (8 bytes per lane: 16 rows x 32 bytes per wave instruction, six of them per block) the same bytes cost 23 us of
   // the 112 us of config 3's d net.3 product (profiles/r03_gemm_experiments.txt).
@@ -556,11 +554,7 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_nt_n192_kernel(GemmParams
         const f32x4 u = load4(reinterpret_cast<const T*>(slot + fr * PU) + 16 * i + 4 * fq);
         v1[i] = acc[i][j];
         if (p.bias) v1[i] += load4(p.bias + n0 + wn * 96 + 16 * i + 4 * fq);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const GeluParts gp = gelu_parts<T>(u[e]);
-          v1[i][e] *= fmaf(u[e], gp.pdf, gp.cdf);
-        }
+        v1[i] *= u + 0.5f;                                       // u = the gelu'(.) - 1/2 values the forward pass saved
       }
     } else {
 #pragma unroll

@@ -3,9 +3,13 @@
 //   forward   h   = LayerNorm(x)                          layers.i.1.norm
 //             u   = h W1^T + b1 ;  g = gelu_erf(u)        layers.i.1.fn.net.0 / GELU
 //             out = g W2^T + b2 + x                       layers.i.1.fn.net.3 + residual
+//             saved: g (operand of net.3's weight gradient) and gd = gelu'(u) - 1/2 -- NOT u: nothing in backward needs the
+//             pre-activation except through gelu', forward has Phi(u) in hand (one more interpolation and one FMA per
+//             element give gelu' = Phi + u phi), and backward's elementwise phase shrinks from table look-ups and 11
+//             vector instructions per element to one multiplication (round 4: these kernels are bound by vector +
+//             matrix ISSUE at three waves per SIMD, profiles/r02_mlp_stamps.txt)
 //
-//   backward  du  = (dy W2) * gelu'(u)                    (g = gelu(u): written by forward when the caller passes `g`
-//                                                          there -- the encoder does --, else recomputed and written here)
+//   backward  du  = (dy W2) * (gd + 1/2)
 //             dh  = du W1
 //             dx  = dy + LayerNorm'(dh)                   + per-workgroup dgamma / dbeta partials
 //
@@ -50,8 +54,8 @@ struct MlpParams {
   h16* h;             // (R,192) LN output, saved         | unused
   float* mean;         // (R) written                      | read
   float* rstd;
-  h16* u;             // (R,M) pre-activation written     | read
-  h16* g;             // (R,M) gelu(u) written (or null)  | written (scratch for the weight gradient)
+  h16* u;             // (R,M) gd = gelu'(pre-activation) - 1/2: written | read
+  h16* g;             // (R,M) gelu(pre-activation) written (or null) | unused
   float* out;          // (R,192) fp32                     | dx (R,192) fp32
   // backward only
   const h16* dyc;     // (R,192) compute-dtype copy of dy
@@ -133,9 +137,9 @@ constexpr int MLP_W2B = MLP_D * 128;           // Wb chunk: 192 rows x 64 hidden
 constexpr int MLP_OFF_H = 2 * (MLP_W1B + MLP_W2B);   // operand strip: 3 k-panels x 128 rows x 128 B = 48 KB
 constexpr int MLP_OFF_B1 = MLP_OFF_H + 3 * 128 * 128;
 constexpr int MLP_MAX_M = 1024;
-constexpr int MLP_OFF_TAB_F = MLP_OFF_B1 + MLP_MAX_M * 4;        // forward: {Phi, dPhi} x 768 = 6 KB after the bias
-constexpr int MLP_OFF_TAB_B = MLP_OFF_B1;                        // backward (no bias): {Phi, dPhi, pdf, dpdf} x 768 = 12 KB
-constexpr int MLP_SMEM = MLP_OFF_B1 + 12288;
+constexpr int MLP_OFF_TAB_F = MLP_OFF_B1 + MLP_MAX_M * 4;        // forward: {Phi, dPhi, pdf, dpdf} x 768 = 12 KB after the bias
+constexpr int MLP_SMEM = MLP_OFF_TAB_F + MLP_TAB_N * 16;         // = 163 840 B: all of a CU's LDS
+static_assert(MLP_SMEM <= 163840, "LDS plan");
 
 // TG = token groups (of 16 TT rows = 2 waves) per workgroup; (TG, TT) = (4, 2): 128 rows, 8 waves; (6, 1): 96 rows,
 // 12 waves; (3, 2): 96 rows, 6 waves (A/B only).  See fused_block_rows() in fused_epilogue.h.
@@ -194,27 +198,24 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   //      (in front of which hipcc drains every outstanding load: LDS-DMA aliasing) after the LayerNorm rows
   //      have been requested too, so that the prologue pays one memory latency, not three. ----
   float tv[2][2][2];
+  if constexpr (!BWD) {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int i = tid + NT * k;
-    const int ii = i < MLP_TAB_N ? i : 0;
-    tv[k][0][0] = g_gelu_table[ii][0]; tv[k][0][1] = g_gelu_table[ii][1];
-    tv[k][1][0] = g_gelu_table[ii + 1][0]; tv[k][1][1] = g_gelu_table[ii + 1][1];
+    for (int k = 0; k < 2; ++k) {
+      const int i = tid + NT * k;
+      const int ii = i < MLP_TAB_N ? i : 0;
+      tv[k][0][0] = g_gelu_table[ii][0]; tv[k][0][1] = g_gelu_table[ii][1];
+      tv[k][1][0] = g_gelu_table[ii + 1][0]; tv[k][1][1] = g_gelu_table[ii + 1][1];
+    }
   }
   auto store_tables = [&]() {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int i = tid + NT * k;
-      if (i < MLP_TAB_N) {
-        if constexpr (!BWD)
-          *reinterpret_cast<f32x2*>(smem + MLP_OFF_TAB_F + i * 8) = f32x2{tv[k][0][0], tv[k][1][0] - tv[k][0][0]};
-        else
-          *reinterpret_cast<f32x4*>(smem + MLP_OFF_TAB_B + i * 16) =
-              f32x4{tv[k][0][0], tv[k][1][0] - tv[k][0][0], tv[k][0][1], tv[k][1][1] - tv[k][0][1]};
-      }
+      if (i < MLP_TAB_N)
+        *reinterpret_cast<f32x4*>(smem + MLP_OFF_TAB_F + i * 16) =
+            f32x4{tv[k][0][0], tv[k][1][0] - tv[k][0][0], tv[k][0][1], tv[k][1][1] - tv[k][0][1]};
     }
   };
-  if constexpr (BWD) store_tables();
 
   // Row-indexed global traffic goes through buffer descriptors of THIS workgroup's rows (base = its first
   // row, num_records = its valid rows): rows past R fall outside num_records, so their loads return 0 and
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     aw1[ks] = lbase + (32 * hh + fr) * 128 + ((ks * 64 + fq * 16) ^ (keyl << 5));   // + kt*8192 + i*2048 (+ buffer)
   const uint32_t aw2 = lbase + W1B + fr * 128 + ((hh * 64 + fq * 16) ^ (keyl << 5));  // + dt*2048 (+ buffer)
   const uint32_t ab1 = lbase + MLP_OFF_B1 + (32 * hh + 8 * fq) * 4;                   // + c*256
-  const uint32_t ltabf = lbase + MLP_OFF_TAB_F, ltabb = lbase + MLP_OFF_TAB_B;
+  const uint32_t ltabf = lbase + MLP_OFF_TAB_F;
 
   f32x4 yacc[12][TT];                                         // accumulators of the second product
 #pragma unroll
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   if (wave < TG) __builtin_amdgcn_s_setprio(2);
   // global stores each wave issues per chunk after the next chunk's DMA
   // backward adds the 2 u loads issued at the end of the elementwise phase
-  const int nstores = TT * (BWD ? (p.g ? 3 : 2) : (p.u ? 1 : 0) + (p.g ? 1 : 0));
+  const int nstores = TT * (BWD ? 2 : (p.u ? 1 : 0) + (p.g ? 1 : 0));
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
 #define SITK_STAMP(i)                                                                    \
   if constexpr (VAR == 6) {                                                              \
@@ -479,31 +480,35 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     if constexpr (!BWD) {
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        const f32x4 v0 = uacc[0][t], v1 = uacc[1][t];
-        float xs[8], fw[8];
-        uint32_t ad[8];
-        u32x2 te[8];
+        float gv[8], dv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xs[e] = e < 4 ? v0[e] : v1[e - 4];
-          const float tp = tab_pos(xs[e]);
-          fw[e] = __builtin_amdgcn_fractf(tp);
-          ad[e] = ltabf + ((uint32_t)tp << 3);
-        }
-        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %9\n\tds_read_b64 %2, %10\n\tds_read_b64 %3, %11\n\t"
-                     "ds_read_b64 %4, %12\n\tds_read_b64 %5, %13\n\tds_read_b64 %6, %14\n\tds_read_b64 %7, %15\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(te[0]), "=&v"(te[1]), "=&v"(te[2]), "=&v"(te[3]), "=&v"(te[4]), "=&v"(te[5]), "=&v"(te[6]), "=&v"(te[7])
-                     : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
-                     : "memory");
-        float gv[8];
+        for (int hf4 = 0; hf4 < 2; ++hf4) {                     // 4 elements at a time (register budget)
+          float fw[4];
+          uint32_t ad[4];
+          u32x4 te[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const f32x2 en = __builtin_bit_cast(f32x2, te[e]);
-          gv[e] = xs[e] * fmaf(fw[e], en[1], en[0]);
+          for (int e = 0; e < 4; ++e) {
+            const float tp = tab_pos(uacc[hf4][t][e]);
+            fw[e] = __builtin_amdgcn_fractf(tp);
+            ad[e] = ltabf + ((uint32_t)tp << 4);
+          }
+          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(te[0]), "=&v"(te[1]), "=&v"(te[2]), "=&v"(te[3])
+                       : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
+                       : "memory");
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 en = __builtin_bit_cast(f32x4, te[e]);
+            const float xv = uacc[hf4][t][e];
+            const float cdf = fmaf(fw[e], en[1], en[0]), pdf = fmaf(fw[e], en[3], en[2]);
+            gv[4 * hf4 + e] = xv * cdf;                          // gelu(u)
+            dv[4 * hf4 + e] = fmaf(xv, pdf, cdf) - 0.5f;         // gelu'(u) - 1/2 = Phi(u) - 1/2 + u phi(u): centred, so that
+                                                                 // the 16-bit rounding is finest where most u are (near 0)
+          }
         }
         pf[t] = u32x4{pack_h16(gv[0], gv[1]), pack_h16(gv[2], gv[3]), pack_h16(gv[4], gv[5]), pack_h16(gv[6], gv[7])};
-        sd[t] = u32x4{pack_h16(v0[0], v0[1]), pack_h16(v0[2], v0[3]), pack_h16(v1[0], v1[1]), pack_h16(v1[2], v1[3])};
+        sd[t] = u32x4{pack_h16(dv[0], dv[1]), pack_h16(dv[2], dv[3]), pack_h16(dv[4], dv[5]), pack_h16(dv[6], dv[7])};
         if (p.u) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_u, vo[t], so, 0);
         if (p.g) __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_g, vo[t], so, 0);
       }
@@ -525,41 +530,21 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       else asm volatile("" : "+v"(uc[0]) : : "memory");
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        float dv[8], gv[8];
+        float dv[8];
 #pragma unroll
-        for (int hf4 = 0; hf4 < 2; ++hf4) {                     // 4 elements at a time (register budget)
-          float us[4], fw[4];
-          uint32_t ad[4];
-          u32x4 te[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t w = uc[t][2 * hf4 + (e >> 1)];
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t w = uc[t][e >> 1];
 #ifdef SITK_TU_F16
-            us[e] = (float)__builtin_bit_cast(h16x2, w)[e & 1];                       // v_cvt_f32_f16 (word select)
+          const float gd = (float)__builtin_bit_cast(h16x2, w)[e & 1];                        // v_cvt_f32_f16 (word select)
 #else
-            us[e] = __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));   // bf16 -> f32 is a 16-bit shift
+          const float gd = __builtin_bit_cast(float, (e & 1) ? (w & 0xffff0000u) : (w << 16));   // bf16 -> f32 is a 16-bit shift
 #endif
-            const float tp = tab_pos(us[e]);
-            fw[e] = __builtin_amdgcn_fractf(tp);
-            ad[e] = ltabb + ((uint32_t)tp << 4);
-          }
-          asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
-                       "s_waitcnt lgkmcnt(0)"
-                       : "=&v"(te[0]), "=&v"(te[1]), "=&v"(te[2]), "=&v"(te[3])
-                       : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3])
-                       : "memory");
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const f32x4 en = __builtin_bit_cast(f32x4, te[e]);
-            const float cdf = fmaf(fw[e], en[1], en[0]), pdf = fmaf(fw[e], en[3], en[2]);
-            dv[4 * hf4 + e] = uacc[hf4][t][e] * fmaf(us[e], pdf, cdf);
-            gv[4 * hf4 + e] = us[e] * cdf;
-          }
+          const float a = uacc[e >> 2][t][e & 3];
+          dv[e] = fmaf(a, gd, 0.5f * a);                         // du = (dy W2) gelu'(u); forward saved gelu'(u) - 1/2
         }
         pf[t] = u32x4{pack_h16(dv[0], dv[1]), pack_h16(dv[2], dv[3]), pack_h16(dv[4], dv[5]), pack_h16(dv[6], dv[7])};
-        sd[t] = u32x4{pack_h16(gv[0], gv[1]), pack_h16(gv[2], gv[3]), pack_h16(gv[4], gv[5]), pack_h16(gv[6], gv[7])};
+        sd[t] = pf[t];
         __builtin_amdgcn_raw_buffer_store_b128(pf[t], r_du, vo[t], so, 0);
-        if (p.g) __builtin_amdgcn_raw_buffer_store_b128(sd[t], r_g, vo[t], so, 0);
       }
       if (c + 1 < nchunks) { const int so_next = so + 128; SITK_MLP_LOAD_U(so_next); }
     }
@@ -842,17 +827,17 @@ extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) {
 
 SITK_F16_TWIN(sitk_mlp_bwd)
 extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
-                            const float* ln_w, const void* w2t_c, const void* w1t_c, const void* u, void* du, void* g,
+                            const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du,
                             float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
                             sitk_stream_t stream) {
-  SITK_FORWARD_F16(dtype, sitk_mlp_bwd, dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, du, g, dx, dx_c, partials, rows, D, M, dtype, stream);
-  SITK_REQUIRE(dy && dy_c && x && mean && rstd && ln_w && w2t_c && w1t_c && u && du && dx && dx_c && partials,
+  SITK_FORWARD_F16(dtype, sitk_mlp_bwd, dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, du, dx, dx_c, partials, rows, D, M, dtype, stream);
+  SITK_REQUIRE(dy && dy_c && x && mean && rstd && ln_w && w2t_c && w1t_c && gd && du && dx && dx_c && partials,
                "mlp_bwd: null pointer");
   SITK_TRY(mlp_check("mlp_bwd", rows, D, M, dtype));
   MlpParams p = {};
   p.x = x; p.gamma = ln_w; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
   p.wa = reinterpret_cast<const h16*>(w2t_c); p.wb = reinterpret_cast<const h16*>(w1t_c);
-  p.u = const_cast<h16*>(reinterpret_cast<const h16*>(u)); p.g = reinterpret_cast<h16*>(g);
+  p.u = const_cast<h16*>(reinterpret_cast<const h16*>(gd));
   p.du = reinterpret_cast<h16*>(du); p.dy = dy; p.dyc = reinterpret_cast<const h16*>(dy_c);
   p.out = dx; p.outc = reinterpret_cast<h16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.M = M;

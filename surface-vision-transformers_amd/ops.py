@@ -181,7 +181,8 @@ def mlp_fused_supported(D, M, dtype):
 
 
 def mlp_fwd(x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
-    """out = x + gelu(LN(x) W1^T + b1) W2^T + b2; returns (out, h, mean, rstd, u, g) (saved tensors or None)."""
+    """out = x + gelu(LN(x) W1^T + b1) W2^T + b2; returns (out, h, mean, rstd, gd, g) (saved tensors or None):
+    gd = gelu'(u), g = gelu(u) of the pre-activation u = LN(x) W1^T + b1 (the derivative is saved, not u)."""
     rt.require_cuda(x, ln_w, ln_b, w1_c, b1, w2_c, b2)
     rows, D = x.shape
     M = w1_c.shape[0]
@@ -205,7 +206,7 @@ def attn_out_mlp_fused_supported(rows, D, I, M, dtype):
 
 def attn_out_mlp_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
     """x_mid = x + o Wo^T + bo; out = x_mid + gelu(LN(x_mid) W1^T + b1) W2^T + b2.
-    Returns (out, xmid, h, mean, rstd, u, g)."""
+    Returns (out, xmid, h, mean, rstd, gd, g) (gd = gelu'(u), see mlp_fwd)."""
     rt.require_cuda(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2)
     rows, D = x.shape
     M, I = w1_c.shape[0], o_c.shape[1]
@@ -246,23 +247,20 @@ def attn_out_mlp_next_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, n_ln
     return out, xmid, h, mean, rstd, u, g, n_h, n_mean, n_rstd, n_qkv
 
 
-def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, u, dtype, want_g=True):
-    """returns (dx, dx_c, du, g, partials (workgroups, 2, D)); g = gelu(u) is recomputed and returned when want_g
-    (callers that saved g in forward pass want_g=False: g is None)"""
+def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, dtype):
+    """gd = the gelu'(u) saved by the fused forward.  Returns (dx, dx_c, du, partials (workgroups, 2, D))."""
     rows, D = x.shape
-    M = u.shape[1]
+    M = gd.shape[1]
     code = rt.dtype_code(dtype)
-    du = torch.empty_like(u)
-    g = torch.empty_like(u) if want_g else None
+    du = torch.empty_like(gd)
     dx = torch.empty_like(x)
-    dx_c = torch.empty((rows, D), dtype=u.dtype, device=x.device)
+    dx_c = torch.empty((rows, D), dtype=gd.dtype, device=x.device)
     nfl = rt.lib.sitk_mlp_bwd_partial_floats(rows)
     partials = torch.empty(nfl, dtype=torch.float32, device=x.device)
     rt.check(rt.lib.sitk_mlp_bwd(dy.data_ptr(), dy_c.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                 ln_w.data_ptr(), w2t_c.data_ptr(), w1t_c.data_ptr(), u.data_ptr(), du.data_ptr(),
-                                 rt.ptr(g), dx.data_ptr(), dx_c.data_ptr(), partials.data_ptr(), rows, D, M, code,
-                                 rt.stream_ptr()))
-    return dx, dx_c, du, g, partials.view(-1, 2, D)
+                                 ln_w.data_ptr(), w2t_c.data_ptr(), w1t_c.data_ptr(), gd.data_ptr(), du.data_ptr(),
+                                 dx.data_ptr(), dx_c.data_ptr(), partials.data_ptr(), rows, D, M, code, rt.stream_ptr()))
+    return dx, dx_c, du, partials.view(-1, 2, D)
 
 
 # ---- fused LayerNorm + to_qkv ----------------------------------------------------------------------

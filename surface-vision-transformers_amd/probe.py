@@ -140,8 +140,8 @@ def layer_kernels(eng, nset):
     # ---- backward ----
     if fused_mlp:
         add("d net.3 x GELU' + d net.0 + norm backward (fused)", "mlp_kernel<true>",
-            lambda i: ops.mlp_bwd(S[i].dx32, S[i].dxc, S[i].x32, S[i].mean, S[i].rstd, S[i].gam, S[i].w2_t, S[i].w1_t, S[i].u, dt,
-                                  want_g=False), mlp_flops, R * (D * es + 2 * M * es + 12 * D + D * es), L)
+            lambda i: ops.mlp_bwd(S[i].dx32, S[i].dxc, S[i].x32, S[i].mean, S[i].rstd, S[i].gam, S[i].w2_t, S[i].w1_t, S[i].u, dt),
+            mlp_flops, R * (D * es + 2 * M * es + 12 * D + D * es), L)
     else:
         add("d net.3 (x GELU')", "gemm_nt", lambda i: ops.gemm_nt(S[i].dxc, S[i].w2_t, torch.empty_like(S[i].u), dt, epilogue=ops.EPI_DGELU,
                                                                    aux=S[i].u), 2.0 * R * D * M, R * (D + 2 * M) * es, L)

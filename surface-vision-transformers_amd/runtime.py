@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SITK_LIB") or os.path.join(_HERE, "libsitk.so")
 
 F32, BF16, F16 = 0, 1, 2
 EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class SitkError(RuntimeError):
@@ -85,7 +85,7 @@ _SIGS = {
     "sitk_attn_out_mlp_fwd": (C.c_int, [_P] * 17 + [_L, _I, _I, _I, _I, _P]),
     "sitk_attn_out_mlp_next_fwd": (C.c_int, [_P] * 24 + [_I, _L, _I, _I, _I, _I, _P]),
     "sitk_mlp_bwd_partial_floats": (_Z, [_L]),
-    "sitk_mlp_bwd": (C.c_int, [_P] * 14 + [_L, _I, _I, _I, _P]),
+    "sitk_mlp_bwd": (C.c_int, [_P] * 13 + [_L, _I, _I, _I, _P]),
     "sitk_ln_gemm_fused_supported": (C.c_int, [_I, _I, _I]),
     "sitk_ln_gemm_fwd": (C.c_int, [_P] * 8 + [_L, _I, _I, _I, _P]),
     "sitk_ln_gemm_bwd_partial_floats": (_Z, [_L]),

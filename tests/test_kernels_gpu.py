@@ -138,15 +138,16 @@ def test_gemm_nt_epilogues(ops, dtype, M, N, K):
     # BIAS_GELU
     u = torch.empty((M, N), dtype=td, device=DEV)
     g = torch.empty((M, N), dtype=td, device=DEV)
-    ops.gemm_nt(Ad, Wd, u, dtype, epilogue=ops.EPI_BIAS_GELU, bias=bias, out2=g)
-    assert rel(u, base + bias) < tol
+    ops.gemm_nt(Ad, Wd, u, dtype, epilogue=ops.EPI_BIAS_GELU, bias=bias, out2=g)      # `u` receives gelu'(acc + bias) - 1/2 (ABI 9)
+    uf = (base + bias).double().requires_grad_(True)
+    torch.nn.functional.gelu(uf).backward(torch.ones_like(uf))
+    assert rel(u, uf.grad - 0.5) < tol
     assert rel(g, torch.nn.functional.gelu(base + bias)) < tol
-    # DGELU (A fp32)
+    # DGELU (A fp32): out = acc * aux, aux = the saved derivative
     o4 = torch.empty((M, N), dtype=td, device=DEV)
     ops.gemm_nt(A, Wd, o4, dtype, epilogue=ops.EPI_DGELU, aux=u)
-    uf = u.float().requires_grad_(True)
-    torch.nn.functional.gelu(uf).backward(torch.ones_like(uf))
-    assert rel(o4, base * uf.grad) < tol
+    assert rel(o4, base * (u.double() + 0.5)) < tol
+    assert rel(o4, base * uf.grad) < 2 * tol
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -321,7 +322,10 @@ def _attn_ref(qkv, B, N, H, scale):
                                    # LDS-ring kernels (bf16, 384 < N <= 2048): every waves-per-workgroup variant, ragged
                                    # tails (N % 64 = 1, 20, 0, 63, 33), several (batch, head) pairs; above 2048: tiled kernels
                                    (2, 1281, 6), (1, 385, 2), (1, 500, 1), (2, 640, 2), (1, 1023, 1), (1, 2048, 1), (1, 1313, 3),
-                                   (1, 2100, 1)])
+                                   (1, 2100, 1),
+                                   # unit-packed kernels (h16, 320 < N <= 336): workgroups of one and of two heads, a padding
+                                   # wave (3 x 21 = 63 units), every width's head count, all tails of the last 16-row block
+                                   (5, 321, 3), (2, 321, 6), (1, 321, 12), (3, 330, 3), (2, 336, 2), (1, 322, 1), (2, 321, 1)])
 def test_attention_fwd_bwd(ops, dtype, B, N, H):
     td = tdt(dtype)
     qkv = rnd("at/qkv", (B * N, 3 * H * 64), 1.0).to(td)
@@ -370,6 +374,28 @@ def test_attention_large_scores_online_softmax(ops):
     o, lse = ops.attention_fwd(qkv, B, N, H, 0.125, "f32")
     oref, lref = _attn_ref(qkv, B, N, H, 0.125)
     assert rel(o, oref) < 2e-5 and rel(lse, lref) < 1e-5
+
+
+@pytest.mark.parametrize("h16", H16S)
+def test_attention_packed_large_scores_take_the_shift_branch(ops, h16):
+    """Unit-packed forward (N = 321): the row maximum is subtracted only when it leaves [-8, 8] log2 units -- rows with a
+    dominant key (query 10 / key 300 in head 0, query 320 / key 0 in head 2) and rows whose scores are all far BELOW zero
+    (head 1: keys anti-aligned with every query) must agree with the softmax reference; lse too."""
+    B, N, H = 2, 321, 3
+    qkv = rnd("at4/qkv", (B * N, 3 * H * 64), 0.3)
+    qkv[:, 0:192] *= 4.0
+    qkv[300, 192:256] = 6.0 * qkv[10, 0:64]                  # sample 0, head 0
+    qkv[N + 0, 320:384] = 5.0 * qkv[N + 320, 128:192]        # sample 1, head 2
+    qkv[:N, 64:128] += 1.0                                   # sample 0, head 1: a common component in every query and, negated,
+    qkv[:N, 256:320] -= 1.5                                  # in every key -> all scores around -17 log2 units
+    qb = qkv.to(tdt(h16))
+    o, lse = ops.attention_fwd(qb, B, N, H, 0.125, h16)
+    oref, lref = _attn_ref(qb, B, N, H, 0.125)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    assert rel(o, oref) < 1e-2 and rel(lse, lref) < 2e-3
+    assert rel(o.float().view(B, N, H, 64)[0, 10, 0], oref.view(B, N, H, 64)[0, 10, 0]) < 1e-2
+    assert rel(o.float().view(B, N, H, 64)[1, 320, 2], oref.view(B, N, H, 64)[1, 320, 2]) < 1e-2
+    assert rel(o.float().view(B, N, H, 64)[0, :, 1], oref.view(B, N, H, 64)[0, :, 1]) < 1e-2
 
 
 @pytest.mark.parametrize("h16", H16S)

@@ -57,6 +57,12 @@ def r16(t):
     return t.to(_H.td).double()
 
 
+def gelu_grad(u):
+    """d/du [u Phi(u)] = Phi(u) + u phi(u) (float64); the fused forward saves this MINUS 1/2 instead of u (ABI 9)."""
+    u = u.double()
+    return 0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+
+
 def params(tag, M):
     ln_w, ln_b = rnd(tag + "/lw", (D,), 0.3) + 1.0, rnd(tag + "/lb", (D,), 0.2)
     w1, b1 = rnd(tag + "/w1", (M, D), D ** -0.5), rnd(tag + "/b1", (M,), 0.1)
@@ -85,7 +91,7 @@ def test_mlp_fused_fwd(ops, rows, M):
     config-2 shape (20544 x 768)."""
     x = rnd("mlpf/x", (rows, D), 1.5)
     ln_w, ln_b, w1, b1, w2, b2 = params("mlpf", M)
-    out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name, want_g=True)
+    out, h, mean, rstd, gd, g = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name, want_g=True)
     torch.cuda.synchronize()
     xd = x.double()
     h_r = torch.nn.functional.layer_norm(xd, (D,), ln_w.double(), ln_b.double(), 1e-5)
@@ -93,7 +99,8 @@ def test_mlp_fused_fwd(ops, rows, M):
     assert rel(mean, xd.mean(1)) < 1e-5
     assert rel(rstd, (xd.var(1, unbiased=False) + 1e-5).rsqrt()) < 1e-5
     u_r = h.double() @ r16(w1).T + b1.double()                 # from the kernel's own (bf16) h: isolates the product
-    assert rel(u, u_r) < 4e-3
+    assert rel(gd, gelu_grad(u_r) - 0.5) < 4e-3                # the saved (centred) derivative: fp32 gelu'(u) - 1/2, one rounding
+    assert float((gd.double() + 0.5 - gelu_grad(u_r)).abs().max()) < (6e-3 if _H.name == "bf16" else 1e-3)
     g_r = torch.nn.functional.gelu(u_r)
     assert rel(g, g_r) < 6e-3
     br_r = r16(g_r) @ r16(w2).T + b2.double()
@@ -112,10 +119,11 @@ def test_mlp_fused_fwd_integer_exact(ops):
     ln_w, ln_b = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
     w1, w2 = ints("mlpi/w1", (M, D), -2, 3), ints("mlpi/w2", (D, M), -2, 3)
     b1, b2 = ints("mlpi/b1", (M,)), ints("mlpi/b2", (D,))
-    out, h, mean, rstd, u, g = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name, want_g=True)
+    out, h, mean, rstd, gd, g = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name, want_g=True)
     torch.cuda.synchronize()
-    u_r = h.double() @ w1.double().T + b1.double()
-    assert rel(u, u_r) < 3e-3                                  # one bf16 rounding of the stored u
+    u_r = h.double() @ w1.double().T + b1.double()            # exact in fp32: integer weights, 16-bit h
+    assert rel(gd, gelu_grad(u_r) - 0.5) < 3e-3                # one 16-bit rounding of the stored (centred) derivative
+    assert rel(g, torch.nn.functional.gelu(u_r)) < 3e-3
     out_r = x.double() + g.double() @ w2.double().T + b2.double()
     assert rel(out, out_r) < 3e-6                              # fp32 accumulation of exactly representable products
 
@@ -125,17 +133,15 @@ def test_mlp_fused_bwd(ops, rows, M):
     x = rnd("mlpb/x", (rows, D), 1.5)
     ln_w, ln_b, w1, b1, w2, b2 = params("mlpb", M)
     dy = rnd("mlpb/dy", (rows, D), 1.0)
-    out, h, mean, rstd, u, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name)
+    out, h, mean, rstd, gd, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name)
     w2t = w2.to(_H.td).T.contiguous()                         # (M, D)
     w1t = w1.to(_H.td).T.contiguous()                         # (D, M)
-    dx, dx_c, du, g, partials = ops.mlp_bwd(dy, dy.to(_H.td), x, mean, rstd, ln_w, w2t, w1t, u, _H.name)
+    dx, dx_c, du, partials = ops.mlp_bwd(dy, dy.to(_H.td), x, mean, rstd, ln_w, w2t, w1t, gd, _H.name)
     torch.cuda.synchronize()
-    ud = u.double()                                            # the saved (bf16) pre-activation is what backward sees
-    cdf = 0.5 * (1 + torch.erf(ud / math.sqrt(2)))
-    pdf = torch.exp(-0.5 * ud * ud) / math.sqrt(2 * math.pi)
-    du_r = (r16(dy) @ r16(w2)) * (cdf + ud * pdf)
+    du_r = (r16(dy) @ r16(w2)) * (gd.double() + 0.5)           # the saved (16-bit, centred) derivative is what backward sees
     assert rel(du, du_r) < 5e-3
-    assert rel(g, ud * cdf) < 5e-3
+    u_r = h.double() @ r16(w1).T + b1.double()                 # ... and against the exact derivative of the exact pre-activation
+    assert rel(du, (r16(dy) @ r16(w2)) * gelu_grad(u_r)) < 7e-3
     # LayerNorm backward from the kernel's own du (bf16): autograd in float64
     xd = x.double().requires_grad_(True)
     lw = ln_w.double().requires_grad_(True)
@@ -160,9 +166,9 @@ def test_mlp_fused_bwd_zero_gradient_rows(ops):
     ln_w, ln_b, w1, b1, w2, b2 = params("mlpz", M)
     dy = rnd("mlpz/dy", (rows, D), 1.0)
     dy[::3] = 0
-    out, h, mean, rstd, u, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name)
-    dx, dx_c, du, g, partials = ops.mlp_bwd(dy, dy.to(_H.td), x, mean, rstd, ln_w, w2.to(_H.td).T.contiguous(),
-                                            w1.to(_H.td).T.contiguous(), u, _H.name)
+    out, h, mean, rstd, gd, _ = ops.mlp_fwd(x, ln_w, ln_b, w1.to(_H.td), b1, w2.to(_H.td), b2, _H.name)
+    dx, dx_c, du, partials = ops.mlp_bwd(dy, dy.to(_H.td), x, mean, rstd, ln_w, w2.to(_H.td).T.contiguous(),
+                                         w1.to(_H.td).T.contiguous(), gd, _H.name)
     assert float(dx[::3].abs().max()) == 0.0 and float(du[::3].float().abs().max()) == 0.0
     assert bool(torch.isfinite(dx).all()) and bool(torch.isfinite(partials).all())
 

@@ -28,7 +28,7 @@ def kern(name, t):
     if name == "mlp_fwd":
         return lambda: ops.mlp_fwd(t["x32"], t["bD"], t["bD"], t["w1"], t["bM"], t["w2"], t["bD"], dt, want_g=True)
     if name == "mlp_bwd":
-        return lambda: ops.mlp_bwd(t["x32"], t["dxc"], t["x32"], t["mean"], t["rstd"], t["bD"], t["w2t"], t["w1t"], t["u"], dt, want_g=False)
+        return lambda: ops.mlp_bwd(t["x32"], t["dxc"], t["x32"], t["mean"], t["rstd"], t["bD"], t["w2t"], t["w1t"], t["u"], dt)
     if name == "lnqkv_fwd":
         return lambda: ops.ln_gemm_fwd(t["x32"], t["bD"], t["bD"], t["wqkv"], dt)
     if name == "attn_fwd":

@@ -30,7 +30,7 @@ def make(B):
 
 
 def layer_bwd(t):
-    ops.mlp_bwd(t["x32"], t["dxc"], t["x32"], t["mean"], t["rstd"], t["bD"], t["w2t"], t["w1t"], t["u"], dt, want_g=False)
+    ops.mlp_bwd(t["x32"], t["dxc"], t["x32"], t["mean"], t["rstd"], t["bD"], t["w2t"], t["w1t"], t["u"], dt)
     ops.attention_bwd_proj(t["qkv"], t["o_att"], t["dxc"], t["wo_t"], t["lse"], t["B"], N, H, 0.125, dt)
     ops.ln_gemm_bwd(t["qkv"], t["wqkv_t"], t["x32"], t["mean"], t["rstd"], t["bD"], t["x32"], dt)
 

@@ -25,11 +25,11 @@ def dump(path):
     for R in ROWS:
         x, dy = rn(R, D, sc=1.0), rn(R, D, sc=1.0)
         o, h, mean, rstd, u, gg = ops.mlp_fwd(x, lw, lb, w1, b1, w2, b2, "bf16", want_g=True)
-        dx, dxc, du, g2, part = ops.mlp_bwd(dy, dy.bfloat16(), x, mean, rstd, lw, w2.T.contiguous(), w1.T.contiguous(), u, "bf16")
+        dx, dxc, du, part = ops.mlp_bwd(dy, dy.bfloat16(), x, mean, rstd, lw, w2.T.contiguous(), w1.T.contiguous(), u, "bf16")
         dqkv = rn(R, N3, sc=1.0).bfloat16()
         dx2, dxc2, part2 = ops.ln_gemm_bwd(dqkv, wq.T.contiguous(), x, mean, rstd, lw, dy, "bf16")
         torch.cuda.synchronize()
-        for k, v in dict(o=o, h=h, mean=mean, rstd=rstd, u=u, g=gg, dx=dx, dxc=dxc, du=du, g2=g2, psum=part.sum(0), dx2=dx2,
+        for k, v in dict(o=o, h=h, mean=mean, rstd=rstd, u=u, g=gg, dx=dx, dxc=dxc, du=du, psum=part.sum(0), dx2=dx2,
                          dxc2=dxc2, psum2=part2.sum(0)).items():
             out[f"{R}/{k}"] = v.float().cpu()
     torch.save(out, path)

@@ -60,7 +60,7 @@ def side_launch(k, cus, reps):
 
 def main_chain(n=24):
     for _ in range(n):
-        ops.mlp_bwd(dy, dyc, x, mean, rstd, lw, w2t, w1t, u, "bf16", want_g=False)
+        ops.mlp_bwd(dy, dyc, x, mean, rstd, lw, w2t, w1t, u, "bf16")
 
 
 def timed(fn):
