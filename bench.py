@@ -12,6 +12,9 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or typed bare -
 launcher as a CHILD process (before anything touches the GPU), relays its output and exits with its return code.
 
 Prints ONE JSON line (rank 0).  Extra objects:
+  also         : (default N = 1 run only) the other numbers the docs quote, timed behind the headline under the same clock --
+                 f16 mode, the data-parallel form of the step, BASELINE configs 3 and 5 (child processes, 10 steps each) and
+                 the headline with a new batch loaded every step
   roofline     : the dominant kernel (by time share in profiles/) timed live with HIP events on the launch
                  stream, with its algorithmic FLOPs per launch
   cpu_baseline : the CPU oracle (oracle/sit_oracle.py, "port") on this host's cores, config
@@ -104,6 +107,38 @@ def cpu_baseline(seconds=15.0):
                       f"({med * 1e3:.1f} ms/step), torch {torch.__version__} CPU"}
 
 
+ALSO_SPECS = {
+    # name: extra arguments of the child bench process (10 timed steps each, no probe, no CPU baseline)
+    "f16": ["--dtype", "f16"],                                   # the 1e-3-compliant compute mode at the headline shape
+    "dp_form": ["--dp-form"],                                    # what each rank of an N > 1 run executes (one-rank RCCL group)
+    "cfg3": ["--model", "small", "--patches", "1280", "--batch", "32"],
+    "cfg5": ["--model", "base", "--patches", "1280", "--batch", "32", "--task", "mpp"],
+}
+
+
+def also_lines(timeout_s=240):
+    """The other configurations DESIGN.md / profiles/ quote, measured under the SAME driver clock as the headline: each one a
+    child process of this bench (started after the headline's timed loop has ended; the parent idles meanwhile), its JSON line
+    reduced to a few fields.  A child that fails or times out is reported as {"error": ...} -- never silently dropped."""
+    out = {}
+    for name, extra in ALSO_SPECS.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-probe", "--no-cpu-baseline",
+               "--no-also"] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-200:]}"}
+                continue
+            d = json.loads(lines[-1])
+            out[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "step_mfma_frac": d["step_mfma_frac"],
+                         "dtype": d["dtype"], "steps": d["steps"], "workload": d["config"]["workload"],
+                         "parallelism": d["config"]["parallelism"], "hip_graph": d["config"]["hip_graph"]}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"timeout after {timeout_s} s"}
+    return out
+
+
 def self_launch_command(n, argv):
     """`python bench.py --gpus N` typed bare: the one-rank-per-GPU launcher to start as a child process."""
     import socket
@@ -134,6 +169,8 @@ def main():
     ap.add_argument("--dp-form", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the step (3 backward slices, one hipGraph per segment, every bucket "
                          "all-reduced over a ONE-rank RCCL group) -- what each rank of an N > 1 run executes, minus the wire time")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the `also` object (f16, data-parallel form, configs 3 and 5 as child processes behind the headline)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (gloo: rehearsal of the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
@@ -246,6 +283,22 @@ def main():
                             out["roofline"]["traffic_source"] = e["source"] + "; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes"
             except (OSError, KeyError, ValueError):
                 pass
+        headline = (world == 1 and args.model == "tiny" and args.patches == 320 and args.batch == 64 and args.task == "regression"
+                    and args.dtype == "bf16" and not args.dp_form and not args.graph and not args.no_graph)
+        if headline and not args.no_also:
+            # a new batch EVERY step (load_batch of device tensors + step): the prefetched gather then waits for the copy, i.e.
+            # the form a training loop with a host-side loader runs; 10 steps, in this process
+            x2 = torch.randn((B, 40962, 4), device=dev, generator=g)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(10):
+                eng.load_batch(x2 if i % 2 else x, y)
+                eng.step()
+            torch.cuda.synchronize()
+            nb_ms = (time.perf_counter() - t1) / 10 * 1e3
+            out["also"] = {"new_batch_every_step": {"ms_per_step": round(nb_ms, 4), "value": round(B / nb_ms * 1e3, 1),
+                                                    "step_mfma_frac": round(B / nb_ms * gf / PEAK_BF16_TFLOPS, 4)}}
+            out["also"].update(also_lines())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -498,14 +498,18 @@ int sitk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * index keep_idx (the step's loss; < 0: none) is copied to keep_dst first.  With n_extra > 0 the accumulators start at
  * grad + n and are cleared in 16-byte pieces: n % 4 == 0 is required (the engine pads every parameter to 64 floats).
  * inv_loss_scale (device pointer or NULL): the gradients are additionally multiplied by *inv_loss_scale, the 1 / S that
- * sitk_head_loss_fwd_bwd left behind (f16 mode), read on the device so that a captured graph follows it.              */
+ * sitk_head_loss_fwd_bwd left behind (f16 mode), read on the device so that a captured graph follows it.
+ * nonfinite (device int or NULL; ABI 9): a gradient that is not finite -- an f16 intermediate that overflowed behind the loss
+ * scale -- never reaches the parameters or the optimizer state: its element (SGD: the 16-byte vector it sits in) is skipped,
+ * zeroed like every consumed gradient, and counted in *nonfinite (atomic add; the caller polls it when it likes).       */
 int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state, float momentum,
                       float weight_decay, int nesterov, float grad_scale, int zero_grad, int64_t n_extra,
-                      int64_t keep_idx, float* keep_dst, const float* inv_loss_scale, sitk_stream_t stream);
+                      int64_t keep_idx, float* keep_dst, const float* inv_loss_scale, int* nonfinite,
+                      sitk_stream_t stream);
 int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double* state,
                        float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, float grad_scale,
                        int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst, const float* inv_loss_scale,
-                       sitk_stream_t stream);
+                       int* nonfinite, sitk_stream_t stream);
 
 #ifdef __cplusplus
 }

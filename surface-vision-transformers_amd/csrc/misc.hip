@@ -667,33 +667,48 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 __global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                                                       int64_t n, const double* __restrict__ state, float momentum, float wd,
                                                       int nesterov, float gscale, int zero, int64_t n_extra, int64_t keep_idx,
-                                                      float* __restrict__ keep_dst, const float* __restrict__ inv_gscale) {
+                                                      float* __restrict__ keep_dst, const float* __restrict__ inv_gscale,
+                                                      int* __restrict__ nonfinite) {
   if (inv_gscale) gscale *= inv_gscale[0];               // the step's loss scale (f16 compute mode), undone here
   const float lr = (float)state[0];
   const int64_t nvec = n >> 2;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  // A gradient that is not finite (an f16 intermediate that overflowed behind the loss scale) must not reach the parameters or
+  // the momentum: the vector it sits in is skipped (zeroed like every consumed gradient) and counted in `nonfinite`.
+  int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
     f32x4 pv = load4(p + 4 * i);
-    f32x4 gv = load4(g + 4 * i) * gscale + pv * wd;
+    const f32x4 graw = load4(g + 4 * i) * gscale;
+    if (zero) store4(g + 4 * i, z);
+    if (!(fabsf(graw[0]) <= 3.0e38f && fabsf(graw[1]) <= 3.0e38f && fabsf(graw[2]) <= 3.0e38f && fabsf(graw[3]) <= 3.0e38f)) {
+      ++bad;
+      continue;
+    }
+    f32x4 gv = graw + pv * wd;
     if (momentum != 0.f) {
       f32x4 bv = load4(buf + 4 * i) * momentum + gv;
       store4(buf + 4 * i, bv);
       gv = nesterov ? gv + bv * momentum : bv;
     }
     store4(p + 4 * i, pv - gv * lr);
-    if (zero) store4(g + 4 * i, z);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (nvec << 2) + threadIdx.x;
-    float gv = g[i] * gscale + p[i] * wd;
-    if (momentum != 0.f) {
-      const float bv = buf[i] * momentum + gv;
-      buf[i] = bv;
-      gv = nesterov ? gv + bv * momentum : bv;
-    }
-    p[i] -= lr * gv;
+    const float graw = g[i] * gscale;
     if (zero) g[i] = 0.f;
+    if (fabsf(graw) <= 3.0e38f) {
+      float gv = graw + p[i] * wd;
+      if (momentum != 0.f) {
+        const float bv = buf[i] * momentum + gv;
+        buf[i] = bv;
+        gv = nesterov ? gv + bv * momentum : bv;
+      }
+      p[i] -= lr * gv;
+    } else {
+      ++bad;
+    }
   }
+  if (bad && nonfinite) atomicAdd(nonfinite, bad);
   if (zero)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra; i += (int64_t)gridDim.x * 256) {
       if (i == keep_idx && keep_dst) keep_dst[0] = g[n + i];
@@ -711,12 +726,18 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, fl
                                                        float* __restrict__ v, int64_t n, const double* __restrict__ state,
                                                        float b1, float b2, float eps, float wd, int decoupled, float gscale,
                                                        int zero, int64_t n_extra, int64_t keep_idx, float* __restrict__ keep_dst,
-                                                       const float* __restrict__ inv_gscale) {
+                                                       const float* __restrict__ inv_gscale, int* __restrict__ nonfinite) {
   if (inv_gscale) gscale *= inv_gscale[0];               // the step's loss scale (f16 compute mode), undone here
   const float lr = (float)state[0];
   const float bc1 = (float)(1.0 - state[1]), bc2_sqrt = (float)sqrt(1.0 - state[2]);
+  int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float pv = p[i], gv = g[i] * gscale;
+    if (!(fabsf(gv) <= 3.0e38f)) {                       // not finite: skipped and counted (see sgd_dev_kernel)
+      ++bad;
+      if (zero) g[i] = 0.f;
+      continue;
+    }
     if (decoupled) pv *= (1.f - lr * wd);
     else gv += wd * pv;
     const float mv = b1 * m[i] + (1.f - b1) * gv;
@@ -727,6 +748,7 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, fl
     p[i] = pv - (lr / bc1) * (mv / denom);
     if (zero) g[i] = 0.f;
   }
+  if (bad && nonfinite) atomicAdd(nonfinite, bad);
   if (zero)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra; i += (int64_t)gridDim.x * 256) {
       if (i == keep_idx && keep_dst) keep_dst[0] = g[n + i];
@@ -882,21 +904,21 @@ extern "C" int sitk_adam_step(float* param, const float* grad, float* exp_avg, f
 extern "C" int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state,
                                  float momentum, float weight_decay, int nesterov, float grad_scale, int zero_grad,
                                  int64_t n_extra, int64_t keep_idx, float* keep_dst, const float* inv_loss_scale,
-                                 sitk_stream_t stream) {
+                                 int* nonfinite, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(param && grad && state && n > 0 && n_extra >= 0, "sgd_step_dev: bad arguments");
   SITK_REQUIRE(momentum == 0.f || momentum_buf, "sgd_step_dev: momentum needs a buffer");
   SITK_REQUIRE(n % 4 == 0 || n_extra == 0, "sgd_step_dev: accumulators behind the gradients need n %% 4 == 0");
   hipLaunchKernelGGL(sgd_dev_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      param, grad, momentum_buf, n, state, momentum, weight_decay, nesterov, grad_scale, zero_grad, n_extra,
-                     keep_idx, keep_dst, inv_loss_scale);
+                     keep_idx, keep_dst, inv_loss_scale, nonfinite);
   return check_launch("sgd_step_dev");
 }
 
 extern "C" int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double* state,
                                   float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, float grad_scale,
                                   int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst,
-                                  const float* inv_loss_scale, sitk_stream_t stream) {
+                                  const float* inv_loss_scale, int* nonfinite, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && n > 0 && n_extra >= 0, "adam_step_dev: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -904,7 +926,7 @@ extern "C" int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, flo
   SITK_LAUNCH_CHECK("adam_advance");
   hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, state,
                      beta1, beta2, eps, weight_decay, decoupled_wd, grad_scale, zero_grad, n_extra, keep_idx, keep_dst,
-                     inv_loss_scale);
+                     inv_loss_scale, nonfinite);
   return check_launch("adam_step_dev");
 }
 

@@ -6,9 +6,11 @@
 It drives the same C-ABI kernels as the drop-in modules, but without autograd: parameters, gradients
 and optimizer state live in three flat fp32 buffers (the module's nn.Parameters are re-pointed at
 views of them, so state_dict()/checkpoints keep working), every activation buffer is allocated
-once, and the whole step is enqueued with ~30 host calls and replayed from a hipGraph.  With
-data parallelism the backward is cut into layer slices; each finished slice's gradient range is
-all-reduced (RCCL, on the process group's own stream) while the remaining slices run.
+once.  Launch form (TrainEngine(use_graph=None) picks it): the 16-bit fused path (dim 192) is enqueued EAGERLY, ~110 launches
+per step, because it forks 8 of 12 layers' weight gradients, the weight staging and the next step's gather onto a side stream
+beside the backward chain (a forked step replayed from ONE hipGraph starts the chain's kernels late: 2.82 against 2.49 ms);
+every other configuration is replayed from hipGraph(s).  With data parallelism the backward is cut into layer slices; each
+finished slice's gradient range is all-reduced (RCCL, on the process group's own stream) while the remaining slices run.
 
 Unlike tools/train.py:293-296 nothing here synchronises with the host: `step()` returns a device
 scalar (the loss) and never calls .item().
@@ -137,12 +139,17 @@ class TrainEngine:
     prefetch_gather: with a side stream, enqueue the patch gather of a regression step there (it then runs beside the previous
                   step's tail); False = in front of the patch embedding on the main stream.  Inputs must then reach the
                   engine through load_batch() / step(x, ...) / step(indices=...), which order that gather behind their copy
-                  (a direct write into `eng.inp` on another stream is not seen by the side stream).
+                  (a direct write into `eng.inp` on another stream is not seen by the side stream).  The gather hides behind
+                  the previous step's tail only when the batch is static or selected by HOST indices of a resident data set
+                  (bench.py's headline; -11 us per step): after load_batch() / step(x, ...) / device indices it has to wait
+                  for that copy, which sits behind the whole previous step on the main stream -- no overlap, one more event
+                  (bench.py reports this form too: also.new_batch_every_step).
     use_graph:    True = the step is replayed from hipGraph(s) (one per segment); False = eager launches.
                   None (default) with wgrad_overlap None: the faster of the two forms measured for the configuration --
-                  eager + 8 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192), hipGraph
-                  replay without a side stream everywhere else (other widths, data parallelism: there the idle CUs belong
-                  to the gradient all-reduce).
+                  eager + 8 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192); under a process
+                  group the same path runs its two-slice `dp_side` form (eager: layers 4..11's weight gradients on the side
+                  stream, their bucket all-reduced beside the rest of the chain, layers 0..3 + the patch embedding on the main
+                  stream); hipGraph replay without a side stream everywhere else (other widths, f32, use_graph=True).
 
     The learning rate (and Adam's step count) live in device memory: `set_lr()` takes effect in captured graphs too,
     so the schedulers of tools/pretrain.py:42-50 can drive the engine.  `load_dataset()` keeps a whole data set
@@ -186,6 +193,8 @@ class TrainEngine:
         self.keep_grads = keep_grads
         # {lr, beta1^t, beta2^t, t} in device memory: read by the optimizer kernels, so captured graphs follow set_lr()
         self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
+        # gradient elements the optimizer pass found not finite and skipped (device counter; `nonfinite_count` reads it)
+        self.nonfinite = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self.norm = None
         if normalise is not None:
             if input_layout != "surface":
@@ -243,7 +252,7 @@ class TrainEngine:
             self.wo_c = torch.zeros((ld, D), dtype=self.tdt, device=dev)     # to_original (K, D), zero rows up to ld: the
             self.bo_pad = torch.zeros((ld,), dtype=f32, device=dev)          # GEMM runs on N = ld columns (16-byte stores)
             self.wo_t = torch.empty((D, ops.pad8(K)), dtype=self.tdt, device=dev)
-            self.we_t = torch.empty((K, D), dtype=self.tdt, device=dev)      # embedding weight^T (for d mask_token)
+            self.we_t = torch.empty((K, D), dtype=torch.float32 if self.loss_scaled else self.tdt, device=dev)   # embedding weight^T (for d mask_token)
             self.out_pad = torch.empty((B * P, ld), dtype=f32, device=dev)   # batch_out in rows of ld floats
             self.out = self.out_pad[:, :K]                                   # (B * P, K) view: models/mpp.py:129's batch_out
             self.dout_c = torch.zeros((B * P, ld), dtype=self.tdt, device=dev)   # d batch_out, compute dtype; pad columns stay 0
@@ -314,6 +323,14 @@ class TrainEngine:
         if self._prefetch:
             self._tok_bufs = (self.tokens, torch.zeros_like(self.tokens))
             self._ev_gather, self._ev_inp, self._inp_dirty = torch.cuda.Event(), torch.cuda.Event(), False
+        if self.dp_side:
+            # Bucket i of this form becomes final when the SIDE stream has finished slice i's weight gradients and LayerNorm
+            # reduction: an event recorded there right behind the slice's launches.  The all-reduce is issued from a small
+            # stream of its own that waits for THAT event only -- not from the side stream's context, whose tail by then holds
+            # later slices' work that waits for the end of the whole chain (the 58 % bucket could not start
+            # before all of backward had finished).
+            self._ev_slice = [torch.cuda.Event() for _ in self.slices[:-1]]
+            self._ar_stream = torch.cuda.Stream(device=self.device)
         if use_graph is None:
             use_graph = not self._overlap
         self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices), len(self.slices))
@@ -424,8 +441,11 @@ class TrainEngine:
             # side stream it runs there too, beside the tail weight-gradient launch (27 us at the end of the step otherwise)
             with (torch.cuda.stream(self._side_torch) if self._overlap else contextlib.nullcontext()):
                 ops.masked_colsum(self.dx, self.replaced_full.view(-1), None, self.rsum, "f32")
-                rt.check(rt.lib.sitk_stage_weight(lin.weight.data_ptr(), D, K, None, 0, self.we_t.data_ptr(), D, dt, self._s()))
-                ops.gemm_nt(self.rsum, self.we_t, g(self.ssl.mask_token).view(1, K), dt, M=1, N=K, K=D)
+                # f16 mode: rsum is a sum over ALL replaced rows (~25 k at config 5) of a gradient that carries the loss scale
+                # -- far beyond f16's range as a GEMM operand: this 1 x D x K product runs in the exact-f32 kernel there
+                pdt = rt.F32 if self.loss_scaled else dt
+                rt.check(rt.lib.sitk_stage_weight(lin.weight.data_ptr(), D, K, None, 0, self.we_t.data_ptr(), D, pdt, self._s()))
+                ops.gemm_nt(self.rsum, self.we_t, g(self.ssl.mask_token).view(1, K), pdt, M=1, N=K, K=D)
         if self._overlap:
             rt.check(rt.lib.sitk_overlap_join(self._overlap, self._s()))      # every gradient of the step is behind this point
 
@@ -549,6 +569,12 @@ class TrainEngine:
         self.replaced_full.zero_()
         self.replaced_full[:, 1:] = (m & r).to(torch.uint8)
 
+    @property
+    def nonfinite_count(self):
+        """Gradient elements skipped so far because they were not finite (a host read: syncs).  Not zero in f16 mode means an
+        intermediate overflowed behind the loss scale: the parameters are intact (the optimizer pass skips such elements)."""
+        return int(self.nonfinite.item())
+
     def set_lr(self, lr):
         """New learning rate from the next step on (a device-side write: captured graphs read it from memory)."""
         self.opt["lr"] = float(lr)
@@ -566,12 +592,12 @@ class TrainEngine:
         if o["kind"] == "sgd":
             rt.check(L.sitk_sgd_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), rt.ptr(self.state[0]), fp.total,
                                          self.hyper.data_ptr(), o["momentum"], o["wd"], int(o["nesterov"]), scale, zero,
-                                         n_extra, self._loss_extra_idx, keep_dst, inv_s, s))
+                                         n_extra, self._loss_extra_idx, keep_dst, inv_s, self.nonfinite.data_ptr(), s))
         else:
             rt.check(L.sitk_adam_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), self.state[0].data_ptr(),
                                           self.state[1].data_ptr(), fp.total, self.hyper.data_ptr(), o["betas"][0],
                                           o["betas"][1], o["eps"], o["wd"], int(o["kind"] == "adamw"), scale, zero, n_extra,
-                                          self._loss_extra_idx, keep_dst, inv_s, s))
+                                          self._loss_extra_idx, keep_dst, inv_s, self.nonfinite.data_ptr(), s))
 
     # ---- segments: [fwd + loss + head/backward slice 0], [slice 1], ..., [finish + optimizer] ------------
     def _segment_fns(self):
@@ -667,6 +693,9 @@ class TrainEngine:
             elif idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= S):
                 raise rt.SitkError(f"step(indices=...): indices must lie in [0, {S}), got [{int(idx.min())}, {int(idx.max())}]")
             if getattr(self, "_prefetch", False) and not idx.is_cuda:
+                if self._inp_dirty:       # load_dataset()'s index reset (main stream) must not land BEHIND this copy
+                    self._side_torch.wait_event(self._ev_inp)
+                    self._inp_dirty = False
                 with torch.cuda.stream(self._side_torch):           # host indices: the copy rides in front of the gather on ITS stream
                     self.idx.copy_(idx.to(torch.int32), non_blocking=True)
             else:
@@ -692,17 +721,21 @@ class TrainEngine:
             return self.loss
         for i, fn in enumerate(segs):
             self._run(fn, i)
-            if i < len(segs) - 1 and not self.dp_side:
+            if i < len(segs) - 1 and self.dp_side:
+                self._ev_slice[i].record(self._side_torch)      # slice i's weight gradients + LayerNorm reduction end here
+            elif i < len(segs) - 1:
                 for lo, hi in self.bucket_plan[i]:      # final now: reduce while the remaining slices run
                     self._allreduce(lo, hi)
         if self.dp_side:
-            # The first slice's weight gradients and LayerNorm reduction are on the SIDE stream: its bucket is reduced from that
-            # stream's context (the process group's stream waits for the side stream).  Issued only now, behind the host's
-            # enqueue of the whole chain: should the process group's stream share a hardware queue with the main stream (ROCm
-            # maps streams of one priority onto few queues), its wait sits BEHIND the chain's launches in that queue instead of
-            # in front of them (issued right after the first slice it stalled the chain for 350 us: 3.14 ms per step).
-            with torch.cuda.stream(self._side_torch):
-                for i in range(len(segs) - 1):
+            # The early slices' weight gradients and LayerNorm reductions are on the SIDE stream: each bucket is reduced behind
+            # the event recorded there at the end of ITS slice (see __init__), so it runs beside the rest of the chain.  The
+            # collectives are ISSUED only now, behind the host's enqueue of the whole chain: should the process group's stream
+            # (or the small stream below) share a hardware queue with the main stream (ROCm maps streams of one priority onto
+            # few queues), its wait sits BEHIND the chain's launches in that queue instead of in front of them (issued right
+            # after the first slice it stalled the chain for 350 us: 3.14 ms per step).
+            for i in range(len(segs) - 1):
+                self._ar_stream.wait_event(self._ev_slice[i])
+                with torch.cuda.stream(self._ar_stream):
                     for lo, hi in self.bucket_plan[i]:
                         self._allreduce(lo, hi)
         self._run(self._finish_backward, "finish")

@@ -135,8 +135,8 @@ _SIGS = {
     "sitk_gelu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "sitk_sgd_step": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _I, _F, _P]),
     "sitk_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _F, _P]),
-    "sitk_sgd_step_dev": (C.c_int, [_P, _P, _P, _L, _P, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P]),
-    "sitk_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P]),
+    "sitk_sgd_step_dev": (C.c_int, [_P, _P, _P, _L, _P, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P, _P]),
+    "sitk_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 

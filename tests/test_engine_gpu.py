@@ -287,18 +287,21 @@ def test_engine_config3_width_bf16_against_f32_mode(pk):
     check("engine/cfg3_b32_d2", "update_rel", "bf16", worst[0], "grad")
 
 
-def test_mpp_engine_config5_width_bf16_against_f32_mode(pk):
+@pytest.mark.parametrize("h16", ["bf16", "f16"])
+def test_mpp_engine_config5_width_16bit_against_f32_mode(pk, h16):
     """BASELINE config 5's per-GPU share at its full width -- SiT-base MPP, 1280 patches x 45 vertices, 32 samples --
-    depth 1: the bf16 MPP engine step (device draws, fused gather + corruption, padded to_original, masked loss, weight
+    depth 1: the 16-bit MPP engine step (device draws, fused gather + corruption, padded to_original, masked loss, weight
     gradients in the batched launch, mask_token gradient) against the same engine in f32 compute mode on the SAME draws
-    (models/mpp.py:77-134).  Loss and every gradient."""
+    (models/mpp.py:77-134).  Loss and every gradient.  f16: the fixed 1e-3 bars, nothing may overflow behind the loss scale
+    (d mask_token sums ~25 k loss-scaled rows: its 1 x D x K product runs in the f32 kernel there) and the optimizer's
+    non-finite counter stays 0."""
     sit, mpp, engine = pk
     B, P, V = 32, 1280, 45
     kw = dict(sit_oracle.MODEL_SIZES["base"], depth=1, num_patches=P, num_vertices=V, num_channels=4)
     g = torch.Generator(device=DEV).manual_seed(3)
     x = torch.randn((B, 4, P, V), device=DEV, generator=g)
     res = {}
-    for dtype in ("f32", "bf16"):
+    for dtype in ("f32", h16):
         model = sit.SiT(**kw, compute_dtype=dtype)
         model.allow_synthetic_table = True
         ssl = mpp.masked_patch_pretraining(model, 768, 4 * V, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
@@ -309,15 +312,52 @@ def test_mpp_engine_config5_width_bf16_against_f32_mode(pk):
         loss = float(eng.step(x))
         rnd = eng.last_randoms
         res[dtype] = (loss, {k: p.grad.detach().cpu().clone() for k, p in ssl.named_parameters()}, rnd)
+        assert eng.nonfinite_count == 0 and all(bool(torch.isfinite(v).all()) for v in res[dtype][1].values())
     l32, g32, r32 = res["f32"]
-    l16, g16, r16 = res["bf16"]
+    l16, g16, r16 = res[h16]
     for k in r32:
         assert torch.equal(r32[k], r16[k]), k                  # same Philox stream in both modes
     assert int(r32["corrupted_sequence"].sum()) == B * 960
-    check("engine/cfg5_mpp_b32_d1", "loss", "bf16", abs(l16 - l32) / abs(l32), "out")
+    check("engine/cfg5_mpp_b32_d1", "loss", h16, abs(l16 - l32) / abs(l32), "out")
     worst = max((rel(g16[k], g32[k]), k) for k in g32 if float(g32[k].abs().max()) > 0)
     print("worst gradient:", worst)
-    check("engine/cfg5_mpp_b32_d1", "grad_rel", "bf16", worst[0], "grad")
+    check("engine/cfg5_mpp_b32_d1", "grad_rel", h16, worst[0], "grad")
+
+
+@pytest.mark.parametrize("optimizer", ["sgd", "adam"])
+def test_optimizer_skips_and_counts_nonfinite_gradients(pk, optimizer):
+    """A gradient element that is not finite (an f16 intermediate that overflowed behind the loss scale) must not reach the
+    parameters or the optimizer state: the fused optimizer pass skips it, zeroes it like every consumed gradient and counts
+    it; every other element is updated as usual (tools/train.py:291's optimizer.step() has no such guard: the reference
+    computes in fp32)."""
+    from sitk import runtime as rt
+    n = 4096 + 64
+    g0 = torch.Generator(device=DEV).manual_seed(5)
+    p = torch.randn(n, device=DEV, generator=g0)
+    g = torch.randn(n, device=DEV, generator=g0)
+    g[5], g[1000], g[4100] = float("inf"), float("nan"), float("-inf")
+    p0, gref = p.clone(), g.clone()
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    hyper = torch.tensor([0.1, 1.0, 1.0, 0.0], dtype=torch.float64, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    if optimizer == "sgd":
+        rt.check(rt.lib.sitk_sgd_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), n, hyper.data_ptr(), 0.9, 0.0, 0, 1.0, 1, 0, -1,
+                                          None, None, cnt.data_ptr(), rt.stream_ptr()))
+        bad = torch.zeros(n, dtype=torch.bool, device=DEV)
+        for i in (5, 1000, 4100):
+            bad[i // 4 * 4:i // 4 * 4 + 4] = True                # SGD skips the 16-byte vector the element sits in
+        ref = p0 - 0.1 * gref
+        assert int(cnt) == 3
+    else:
+        rt.check(rt.lib.sitk_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, hyper.data_ptr(), 0.9, 0.999,
+                                           1e-8, 0.0, 0, 1.0, 1, 0, -1, None, None, cnt.data_ptr(), rt.stream_ptr()))
+        bad = ~torch.isfinite(gref)
+        ref = p0 - 0.1 * torch.sign(gref)                        # first Adam step: m / sqrt(v) = sign(g)
+        assert int(cnt) == 3
+    assert torch.equal(p[bad], p0[bad]) and float(m[bad].abs().max()) == 0.0
+    assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(m).all())
+    assert float((p[~bad] - ref[~bad]).abs().max()) < 1e-4
+    assert float(g.abs().max()) == 0.0                            # consumed gradients are zeroed, the skipped ones too
 
 
 @pytest.mark.parametrize("optimizer", ["sgd", "adam", "adamw"])
