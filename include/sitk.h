@@ -52,7 +52,7 @@ int sitk_dtype_size(int dtype);
 /* ---------------------------------------------------------------------------------------------
  * a1-a3  Patch gather.  tools/preprocessing.py:74-84 (out[s,c,j,v] = X[s,c,table[v,j]]) fused with
  * Rearrange('b c n v -> b n (v c)') of models/sit.py:49 / models/mpp.py:82-83.
- *   x_bvc     (B, n_vertices, C) fp32, channels last (C == 4)
+ *   x_bvc     (B, n_vertices, C) fp32, channels last, C in 1..4 (C == 4: one 16-byte record per vertex, the fast path)
  *   table_pv  (P, V) uint16, PATCH-major vertex ids (ids < n_vertices)
  *   tokens    (B*P, ld) `dtype`; columns [0, V*C) are written as f = v*C + c, columns
  *             [V*C, ld) are zero-filled (ld >= V*C, multiple of 4; of 8 when it feeds a bf16 GEMM).
@@ -445,7 +445,8 @@ int sitk_mpp_corrupt(const float* tokens, const uint8_t* masked, const uint8_t* 
  * swap_draw = U < p_swap, random_patches uniform in [0, P), replace_draw = U < p_replace (models/mpp.py:36-43,95-110).  Same
  * distribution as the reference's draws, not the same stream: parity tests replay the reference's captured tensors through
  * sitk_mpp_corrupt instead.  P <= 2048.
- * sitk_mpp_gather_corrupt = sitk_gather_tokens_idx (sample_idx / mean / stdv may be NULL) + sitk_mpp_corrupt in one pass:
+ * sitk_mpp_gather_corrupt (C == 4 only: every shipped configuration; other channel counts take sitk_gather_tokens* +
+ * sitk_mpp_corrupt) = sitk_gather_tokens_idx (sample_idx / mean / stdv may be NULL) + sitk_mpp_corrupt in one pass:
  * clean (B*P, V*C) fp32 and corrupted (B*P, ld) `dtype` are both written; when state != NULL it also advances state[1],
  * so the next sitk_mpp_draw (e.g. the next replay of a captured graph) draws fresh masks.                                  */
 int sitk_mpp_draw(const uint64_t* state, uint8_t* masked, uint8_t* swap_draw, int32_t* random_patches, uint8_t* replace_draw,

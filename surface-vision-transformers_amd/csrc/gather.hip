@@ -9,10 +9,14 @@
 
 namespace sitk {
 
-// One thread per (token row, vertex slot): loads the vertex id (2 B, coalesced along v), one 16-byte
-// channels-last vertex record (4 fp32 channels) and writes 4 consecutive token features.  A surface
-// is 655 KB, so the 1.2x re-reads of shared edge/corner vertices are served by L2.
-template <typename T>
+// One WAVE per token row (4 rows per workgroup in flight): a lane takes vertex slots v = lane, lane + 64, ...: it loads the vertex
+// id (2 B, coalesced along v), one channels-last vertex record (C fp32 channels: one 16-byte load for C = 4) and writes C
+// consecutive token features; the slots between V C and ld are the row's zero pad.  A surface is 164 C KB, so the 1.2x
+// re-reads of shared edge / corner vertices are served by L2 (profiles/r04_pmc_gather.txt: FETCH_SIZE against the batch's
+// bytes).  [Rounds 1 - 3 gave a 256-thread workgroup to every row: 160 of 256 threads busy, 20 480 workgroups; C = 4 only.]
+// LDS staging of a patch's records (north_star's wording) would add a hop without removing a byte: every record is read
+// once per patch it belongs to and written once; what the kernel needs is many independent 16-byte loads in flight.
+template <typename T, int C>
 __global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restrict__ x, const uint16_t* __restrict__ table,
                                                             T* __restrict__ tokens, int64_t rows, int n_vertices, int P, int V, int ld,
                                                             const float* __restrict__ mean, const float* __restrict__ stdv,
@@ -20,31 +24,55 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const float* __restr
                                                             const float* __restrict__ targets_all = nullptr,
                                                             float* __restrict__ target_out = nullptr, int n_targets = 0) {
   // resident data set (tools/train.py:97-113,282): batch row b is sample sample_idx[b] of x; its n_targets labels ride along
-  if (targets_all && blockIdx.x == 0 && blockIdx.y == 0) {
+  if (targets_all && blockIdx.x == 0) {
     const int64_t B = rows / P;
     for (int64_t i = threadIdx.x; i < B * n_targets; i += 256)
       target_out[i] = targets_all[(int64_t)sample_idx[i / n_targets] * n_targets + i % n_targets];
   }
-  const int slots = ld >> 2;  // 4-element slots per token row, the first V carry data, the rest zero pad
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // optional per-channel normalisation (x - mean[c]) / std[c]  (tools/preprocessing.py:72); a true division
   // so that the result is bit-identical to the reference's numpy expression evaluated in fp32
   const bool norm = mean != nullptr;
-  const f32x4 mu = norm ? load4(mean) : f32x4{0.f, 0.f, 0.f, 0.f};
-  const f32x4 sd = norm ? load4(stdv) : f32x4{1.f, 1.f, 1.f, 1.f};
-  for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {  // row = b * P + p
+  float mu[C], sd[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) { mu[c] = norm ? mean[c] : 0.f; sd[c] = norm ? stdv[c] : 1.f; }
+  const int K = V * C;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {  // row = b * P + p
     const int p = (int)(row % P);
     const int64_t b = sample_idx ? (int64_t)sample_idx[row / P] : row / P;
-    for (int v = blockIdx.x * 256 + threadIdx.x; v < slots; v += gridDim.x * 256) {
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (v < V) {
-        const int vid = table[(size_t)p * V + v];
-        val = *reinterpret_cast<const f32x4*>(x + ((size_t)b * n_vertices + vid) * 4);
-        if (norm) {
+    const uint16_t* trow = table + (size_t)p * V;
+    const float* xb = x + (size_t)b * n_vertices * C;
+    T* orow = tokens + (size_t)row * ld;
+    if constexpr (C == 4) {
+      const int slots = ld >> 2;                      // 4-element slots per token row, the first V carry data, the rest zero pad
+      for (int v0 = lane; v0 < slots; v0 += 256) {    // four slots per lane and pass: 4 ids, then 4 records in flight together
+        int vid[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) val[e] = (val[e] - mu[e]) / sd[e];
+        for (int j = 0; j < 4; ++j) vid[j] = v0 + 64 * j < V ? (int)trow[v0 + 64 * j] : -1;
+        f32x4 val[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          val[j] = vid[j] >= 0 ? *reinterpret_cast<const f32x4*>(xb + (size_t)vid[j] * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (norm && vid[j] >= 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[j][e] = (val[j][e] - mu[e]) / sd[e];
+          }
+          if (v0 + 64 * j < slots) store4(orow + 4 * (v0 + 64 * j), val[j]);
         }
       }
-      store4(tokens + (size_t)row * ld + 4 * v, val);
+    } else {
+      for (int v = lane; v < V; v += 64) {
+        const float* rec = xb + (size_t)trow[v] * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float val = rec[c];
+          if (norm) val = (val - mu[c]) / sd[c];
+          orow[v * C + c] = from_f32<T>(val);
+        }
+      }
+      for (int f = K + lane; f < ld; f += 64) orow[f] = from_f32<T>(0.f);
     }
   }
 }
@@ -110,13 +138,19 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 }
 
 template <typename T>
-static int run_gather(const float* x, const uint16_t* table, void* tokens, int B, int nv, int P, int V, int ld,
+static int run_gather(const float* x, const uint16_t* table, void* tokens, int B, int nv, int C, int P, int V, int ld,
                       const float* mean, const float* stdv, hipStream_t s, const int32_t* sample_idx = nullptr,
                       const float* targets_all = nullptr, float* target_out = nullptr, int n_targets = 0) {
   const int64_t rows = (int64_t)B * P;
-  dim3 grid(cdiv(ld / 4, 256), (unsigned)std::min<int64_t>(rows, 65535));
-  hipLaunchKernelGGL((gather_tokens_kernel<T>), grid, dim3(256), 0, s, x, table, reinterpret_cast<T*>(tokens), rows, nv, P, V, ld,
-                     mean, stdv, sample_idx, targets_all, target_out, n_targets);
+  const dim3 grid((unsigned)std::min<int64_t>(cdiv64(rows, 4), 16384));      // 4 rows (waves) per workgroup, grid-stride beyond 65 536 rows
+  T* t = reinterpret_cast<T*>(tokens);
+  switch (C) {
+    case 1: hipLaunchKernelGGL((gather_tokens_kernel<T, 1>), grid, dim3(256), 0, s, x, table, t, rows, nv, P, V, ld, mean, stdv, sample_idx, targets_all, target_out, n_targets); break;
+    case 2: hipLaunchKernelGGL((gather_tokens_kernel<T, 2>), grid, dim3(256), 0, s, x, table, t, rows, nv, P, V, ld, mean, stdv, sample_idx, targets_all, target_out, n_targets); break;
+    case 3: hipLaunchKernelGGL((gather_tokens_kernel<T, 3>), grid, dim3(256), 0, s, x, table, t, rows, nv, P, V, ld, mean, stdv, sample_idx, targets_all, target_out, n_targets); break;
+    case 4: hipLaunchKernelGGL((gather_tokens_kernel<T, 4>), grid, dim3(256), 0, s, x, table, t, rows, nv, P, V, ld, mean, stdv, sample_idx, targets_all, target_out, n_targets); break;
+    default: set_error("gather_tokens: num_channels=%d unsupported (1..4)", C); return SITK_ERR_INVALID;
+  }
   return check_launch("gather_tokens");
 }
 
@@ -171,12 +205,12 @@ extern "C" int sitk_gather_tokens_norm(const float* x_bvc, const uint16_t* table
   using namespace sitk;
   SITK_REQUIRE(x_bvc && table_pv && tokens, "gather_tokens: null pointer");
   SITK_REQUIRE((mean == nullptr) == (stdv == nullptr), "gather_tokens_norm: mean and std go together");
-  SITK_REQUIRE(C == 4, "gather_tokens: channels-last gather is specialised for num_channels == 4 (got %d); use patchify", C);
+  SITK_REQUIRE(C >= 1 && C <= 4, "gather_tokens: num_channels must be 1..4 (got %d)", C);
   SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "gather_tokens: bad shape");
   SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "gather_tokens: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (dtype == SITK_H16) return run_gather<h16>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
-  if (dtype == SITK_F32) return run_gather<float>(x_bvc, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s);
+  if (dtype == SITK_H16) return run_gather<h16>(x_bvc, table_pv, tokens, B, n_vertices, C, P, V, ld, mean, stdv, s);
+  if (dtype == SITK_F32) return run_gather<float>(x_bvc, table_pv, tokens, B, n_vertices, C, P, V, ld, mean, stdv, s);
   set_error("gather_tokens: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }
@@ -192,14 +226,14 @@ extern "C" int sitk_gather_tokens_idx(const float* x_all, const int32_t* sample_
   SITK_REQUIRE((mean == nullptr) == (stdv == nullptr), "gather_tokens_idx: mean and std go together");
   SITK_REQUIRE((targets_all == nullptr) == (target_out == nullptr) && (!targets_all || n_targets > 0),
                "gather_tokens_idx: targets_all, target_out and n_targets go together");
-  SITK_REQUIRE(C == 4, "gather_tokens_idx: channels-last gather is specialised for num_channels == 4 (got %d)", C);
+  SITK_REQUIRE(C >= 1 && C <= 4, "gather_tokens_idx: num_channels must be 1..4 (got %d)", C);
   SITK_REQUIRE(B > 0 && P > 0 && V > 0 && n_vertices > 0 && n_vertices <= 65536, "gather_tokens_idx: bad shape");
   SITK_REQUIRE(ld >= V * C && ld % 4 == 0, "gather_tokens_idx: ld=%d must be >= V*C=%d and a multiple of 4", ld, V * C);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SITK_H16)
-    return run_gather<h16>(x_all, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
+    return run_gather<h16>(x_all, table_pv, tokens, B, n_vertices, C, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
   if (dtype == SITK_F32)
-    return run_gather<float>(x_all, table_pv, tokens, B, n_vertices, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
+    return run_gather<float>(x_all, table_pv, tokens, B, n_vertices, C, P, V, ld, mean, stdv, s, sample_idx, targets_all, target_out, n_targets);
   set_error("gather_tokens_idx: bad dtype %d", dtype);
   return SITK_ERR_INVALID;
 }

@@ -66,6 +66,27 @@ def test_gather_tokens_bit_exact(ops, dtype, k):
     assert float(out[:, K:].float().abs().max()) == 0.0     # zero padding
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [1, 2, 3])
+def test_gather_tokens_fewer_channels_bit_exact(ops, dtype, C):
+    """num_channels < 4 (models/sit.py:34 takes any; the dHCP configs use 4): records of C floats, features f = v C + c, the pad
+    behind V C zero; with and without the fused per-channel normalisation."""
+    from sitk import tables
+    t = tables.load_table(320, 153)
+    B = 2
+    x = detgen.normal("gc/x", (B, 40962, C), mean=1.0, std=2.0, seed=C)
+    out = ops.gather_tokens(torch.from_numpy(x).to(DEV), tables.table_tensor(t, DEV), dtype)
+    K = 153 * C
+    assert out.shape == (B * 320, ops.pad64(K))
+    assert torch.equal(out[:, :K].reshape(B, 320, K), torch.from_numpy(sit_oracle.gather_tokens(x, t)).to(DEV).to(tdt(dtype)))
+    assert float(out[:, K:].float().abs().max()) == 0.0
+    mean, std = np.array([0.9, -0.1, 1.4][:C], np.float32), np.array([1.9, 0.7, 2.2][:C], np.float32)
+    ref = sit_oracle.gather_tokens(((x - mean) / std).astype(np.float32), t)
+    outn = ops.gather_tokens(torch.from_numpy(x).to(DEV), tables.table_tensor(t, DEV), dtype, mean=torch.from_numpy(mean).to(DEV),
+                             std=torch.from_numpy(std).to(DEV))
+    assert torch.equal(outn[:, :K].reshape(B, 320, K), torch.from_numpy(ref).to(DEV).to(tdt(dtype)))
+
+
 def test_gather_with_fused_normalisation_bit_exact(ops):
     """(x - means) / stds of tools/preprocessing.py:72 fused in front of the gather: bit-identical to the
     numpy expression evaluated in fp32 followed by the reference gather."""
