@@ -171,6 +171,8 @@ def main():
                          "all-reduced over a ONE-rank RCCL group) -- what each rank of an N > 1 run executes, minus the wire time")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` object (f16, data-parallel form, configs 3 and 5 as child processes behind the headline)")
+    ap.add_argument("--pg-priority", default="default", choices=["default", "high"],
+                    help="priority of the RCCL process group's stream (see the comment where the group is created)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N > 1 (gloo: rehearsal of the multi-rank path on a one-GPU box)")
     args = ap.parse_args()
@@ -201,10 +203,14 @@ def main():
         # kernel needs a second wave.  One RCCL channel = one workgroup; the 22 MB of gradients do not need more.
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "32")
         if args.backend == "nccl":
-            # RCCL's stream at HIGH priority: the runtime keeps streams of different priorities on different hardware queues, and
-            # the engine's data-parallel form makes this stream wait for its side stream -- on the main stream's queue that wait
-            # would stall the backward chain (measured with a one-rank group: 3.14 ms per step against 2.65)
-            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            # Priority of RCCL's stream.  Round 3 made it HIGH: the runtime keeps streams of different priorities on different
+            # hardware queues, and a collective that waited for the side stream from the main stream's queue stalled the backward
+            # chain (one-rank group: 3.14 ms per step against 2.65).  Round 4: the engine now issues every early bucket behind
+            # an event from a stream of its own, after the whole chain has been enqueued, and a stand-in for a collective with
+            # real wire time (tools/dp_cu_budget.py: 32 workgroups that hold their CUs for 161 + 88 us) cost +3.8 ms per step
+            # on a HIGH-priority stream against +0.9 ms on a default one (profiles/r04_dp_budget.txt): pending high-priority
+            # workgroups keep the chain's kernels from being dispatched.  Default priority is the default.
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=(args.pg_priority == "high"))
             dist.init_process_group("nccl", device_id=dev, pg_options=opts)
         else:
             dist.init_process_group("gloo")

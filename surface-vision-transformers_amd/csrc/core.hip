@@ -147,3 +147,27 @@ extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_cus_(const sit
 extern "C" int sitk_abi_version(void) { return SITK_ABI_VERSION; }
 extern "C" const char* sitk_last_error(void) { return sitk_rt::g_err; }
 extern "C" int sitk_dtype_size(int dtype) { return (dtype == SITK_BF16 || dtype == SITK_F16) ? 2 : (dtype == SITK_F32 ? 4 : 0); }
+
+#ifdef SITK_AB
+// Diagnostic build only (tools/dp_cu_budget.py): `workgroups` workgroups of 512 threads that hold their CUs' wave slots and 16 KB
+// of LDS each for `microseconds` (wall clock, s_memrealtime at 100 MHz) -- a stand-in for the channels of a gradient
+// all-reduce whose wire time a one-GPU box cannot produce.  Bounded: at most 5 ms whatever is asked.
+__global__ __launch_bounds__(512) void sitk_debug_occupy_kernel(unsigned long long ticks, int* sink) {
+  __shared__ int pad[4096];
+  pad[threadIdx.x] = (int)threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  int spins = 0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && spins < (1 << 22)) {
+    __builtin_amdgcn_s_sleep(32);
+    ++spins;
+  }
+  if (sink && spins < 0) sink[0] = pad[(threadIdx.x + 1) & 4095];
+}
+extern "C" int sitk_debug_occupy(int workgroups, int microseconds, sitk_stream_t stream) {
+  if (workgroups < 1 || workgroups > 256 || microseconds < 1) { sitk_rt::set_error("debug_occupy: bad arguments"); return SITK_ERR_INVALID; }
+  const unsigned long long ticks = 100ull * (unsigned long long)(microseconds > 5000 ? 5000 : microseconds);
+  hipLaunchKernelGGL(sitk_debug_occupy_kernel, dim3(workgroups), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), ticks,
+                     (int*)nullptr);
+  return sitk_rt::check_launch("debug_occupy");
+}
+#endif

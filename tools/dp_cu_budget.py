@@ -1,0 +1,107 @@
+"""Does the gradient all-reduce FIT beside the backward chain?  (round-3 review: with a one-rank process group the collective is
+a copy -- the 2.46 ms "per-rank" step says nothing about the CUs and the time a real all-reduce takes.)
+
+The data-parallel form of the step on a ONE-rank RCCL group (every collective on the real backend), plus, behind every
+bucket's all-reduce and ordered exactly like it (a high-priority stream that waits for the stream the collective was issued
+from; the step's main stream waits for it where it waits for the collective), a DUMMY kernel of `--channels` workgroups x 512
+threads that holds its CUs for the time the bucket needs on the wire: bytes / (--gbs GB/s) (22 MB in
+~0.25 ms per ring = 88 GB/s; the mesh algorithm is ~7x faster).  Needs the diagnostic build:
+
+    SITK_LIB=$PWD/surface-vision-transformers_amd/libsitk_ab.so python tools/dp_cu_budget.py [--channels 32 --gbs 88]
+"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sitk  # noqa: E402,F401
+from sitk import engine  # noqa: E402
+from sitk import runtime as rt  # noqa: E402
+from sitk.models.sit import SiT  # noqa: E402
+
+
+class _Both:
+    def __init__(self, work, ev):
+        self.work, self.ev = work, ev
+
+    def wait(self):
+        self.work.wait()
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--channels", type=int, default=32)
+    ap.add_argument("--gbs", type=float, default=88.0, help="wire rate of one bucket's all-reduce, GB/s of gradient bytes")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--prio", type=int, default=0, help="priority of the stream the dummy runs on (0 = default, like the process group of bench.py; -1 = high)")
+    a = ap.parse_args()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(a.channels))
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=False))
+    lib = ctypes.CDLL(rt.LIB_PATH)
+    lib.sitk_debug_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.sitk_debug_occupy.restype = ctypes.c_int
+    hp = torch.cuda.Stream(device=dev, priority=a.prio)
+    B = 64
+    res = {}
+    for mode in ("collective only", "collective + dummy channels"):
+        torch.manual_seed(1234)
+        model = SiT(dim=192, depth=12, heads=3, mlp_dim=768, dim_head=64, num_patches=320, num_vertices=153, num_channels=4,
+                    compute_dtype="bf16")
+        eng = engine.TrainEngine(model, B, input_layout="surface", lr=1e-5, momentum=0.9, process_group=dist.group.WORLD, device=dev)
+        assert eng.dp_side, "expected the two-slice side-stream form"
+        if mode != "collective only":
+            orig = eng._allreduce
+            log = []
+
+            def wrapped(lo, hi, orig=orig, eng=eng, log=log):
+                n0 = len(eng._pending)
+                orig(lo, hi)
+                us = max(1, int((hi - lo) * 4 / (a.gbs * 1e3)))
+                ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
+                ev0.record(torch.cuda.current_stream())
+                hp.wait_event(ev0)
+                assert lib.sitk_debug_occupy(a.channels, us, hp.cuda_stream) == 0
+                ev1.record(hp)
+                eng._pending[n0] = _Both(eng._pending[n0], ev1)
+                log.append(((hi - lo) * 4, us))
+            eng._allreduce = wrapped
+        g = torch.Generator(device=dev).manual_seed(100)
+        x = torch.randn((B, 40962, 4), device=dev, generator=g)
+        y = torch.randn((B,), device=dev, generator=g) * 2 + 40
+        eng.load_batch(x, y)
+        for _ in range(5):
+            eng.step()
+        torch.cuda.synchronize()
+        t0, host = time.perf_counter(), 0.0
+        for i in range(a.steps):
+            h0 = time.perf_counter()
+            eng.step()
+            host += time.perf_counter() - h0
+            if i % 10 == 9:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        res[mode] = (time.perf_counter() - t0) / a.steps * 1e3
+        extra = ""
+        if mode != "collective only":
+            per = log[-len(eng.bucket_plan[0]) - len(eng.bucket_plan[1]):]
+            extra = "  buckets (bytes, dummy us): " + ", ".join(f"({b}, {u})" for b, u in per)
+        print(f"{mode:30s}: {res[mode]:.3f} ms per step (host enqueue {host / a.steps * 1e3:.3f} ms){extra}", flush=True)
+    print(f"dummy all-reduce channels ({a.channels} workgroups x 512 threads at {a.gbs:.0f} GB/s) cost "
+          f"{(res['collective + dummy channels'] - res['collective only']) * 1e3:+.0f} us per step")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
