@@ -81,7 +81,7 @@ struct MlpParams {
 };
 
 __device__ u32x4 g_zero_page_mlp[4];
-__device__ unsigned long long g_mlp_stamps[2 * 16 * 8];   // diagnostic build (SITK_MLP_VAR=6): [wave][phase] cycle sums of workgroup 0
+__device__ unsigned long long g_mlp_stamps[2 * 16 * 8 + 64];   // + [224 .. 224 + 4 waves) of the to_qkv loop (see below: index 224 + 4 wave)   // diagnostic build (SITK_MLP_VAR=6): [wave][phase] cycle sums of workgroup 0
 
 // GELU without transcendentals in the loop.  v_exp_f32 / v_rcp_f32 run at a quarter of the VALU rate (16
 // cycles per wave instruction), and with one exp + one rcp per element the elementwise phase, not the
@@ -258,6 +258,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
         of[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_o, ((16 * TT * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 5] = __builtin_amdgcn_s_memtime() - t_kernel0; }
     f32x4 pacc[6][TT];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -273,7 +274,9 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 #pragma unroll
         for (int t = 0; t < TT; ++t) pacc[i][t] = Mma<h16>::mma(a, of[t][k], pacc[i][t]);
       }
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 1] = __builtin_amdgcn_s_memtime() - t_kernel0; }
     proj_residual_ln_rows<TG, TT>(smem + 73728, smem, pacc, tid, blk0, p.R, p.x, p.bo, p.gamma, p.beta, p.xmid, p.h, p.mean, p.rstd);
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 2] = __builtin_amdgcn_s_memtime() - t_kernel0; }
     issue(0, 1);                                               // the row buffer is dead: ring slot 1 takes chunk 0
 #pragma unroll
     for (int t = 0; t < TT; ++t)
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
     for (int k = 0; k < 3; ++k)
       if (tid + NT * k < MLP_MAX_M) reinterpret_cast<float*>(smem + MLP_OFF_B1)[tid + NT * k] = bvals[k];
     __syncthreads();                                           // tables visible; every wave holds its fragments of the strip
+    if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 3] = __builtin_amdgcn_s_memtime() - t_kernel0; }
   } else if constexpr (!BWD) {
     float bvals[3];
 #pragma unroll
@@ -610,8 +614,10 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       //      [72 KB ..) -> LayerNorm -> bf16 operand strip [0, 36 KB) -> 12 register fragments per wave; Wqkv
       //      streams in 24-KB chunks through a 2-slot ring at [48 KB, 96 KB) exactly as in ln_gemm_fused.hip. ----
       constexpr int NW = 2 * TG, QPW = 24 / NW;
+      if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 6] = __builtin_amdgcn_s_memtime() - t_loop_end; }
       proj_residual_ln_rows<TG, TT>(smem + 73728, smem, v, tid, blk0, p.R, p.xmid, p.b2, p.n_gamma, p.n_beta, p.out, p.n_h,
                                 p.n_mean, p.n_rstd);
+      if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 7] = __builtin_amdgcn_s_memtime() - t_loop_end; }
       // Lane-derived addresses of this phase are rebuilt from an opaque copy of the lane id: derived from `lane`
       // itself, hipcc computes them at kernel entry and carries them through the main loop, whose register budget
       // (254 of 256) has no room for them.
@@ -638,7 +644,13 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + qoff[i]),
                                            (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
       };
+      // FOUR ring slots [48 KB, 144 KB) (the fp32 row buffer is dead), three chunks in flight: with two slots and one chunk in
+      // flight this loop spent 17 k of its 26 k cycles waiting for the next 24 KB (profiles/r04_mlp_stamps_tail.txt): every CU
+      // asks L2 for the same chunk at the same time and one chunk per round trip is 8.6 B / clk / CU
+      constexpr int QNS = 4;
       qissue(0, 0);
+      if (nq > 1) qissue(1, 1);
+      if (nq > 2) qissue(2, 2);
       u32x4 qf[TT][6];
 #pragma unroll
       for (int t = 0; t < TT; ++t)
@@ -653,16 +665,39 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
       uint32_t qa[2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) qa[ks] = lbase + 49152 + (32 * hh + fr) * 128 + ((ks * 64 + fq * 16) ^ (keyl << 5));
+      unsigned long long qst[4] = {0, 0, 0, 0}, qtp = 0;     // diagnostic build: vmcnt wait / barrier / reads + MFMAs / pack + store
+#define SITK_QSTAMP(i)                                                                   \
+      if constexpr (VAR == 6) {                                                          \
+        const unsigned long long tn = __builtin_amdgcn_s_memtime();                      \
+        qst[i] += tn - qtp;                                                              \
+        qtp = tn;                                                                        \
+      }
+      if constexpr (VAR == 6) qtp = __builtin_amdgcn_s_memtime();
       for (int c = 0; c < nq; ++c) {
-        if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if constexpr (TT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // chunk c's DMA precedes the previous iteration's TT stores
-        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const uint32_t qbo = (c & 1) * 24576;
+        // chunk c must have landed; YOUNGER than its DMA and allowed to stay in flight: the DMAs of the chunks c + 1, c + 2 that
+        // exist (QPW pieces each) and the TT stores of each of the last two iterations
+        {
+          const int nd = nq - 1 - c < 2 ? nq - 1 - c : 2, keep = nd * QPW + (c < 2 ? c : 2) * TT;
+          switch (keep) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;      // (keep <= 2 QPW + 2 TT = 8 at TT = 2)
+          }
+        }
+        SITK_QSTAMP(0)
+        __builtin_amdgcn_s_barrier();                                 // everybody's pieces of chunk c; the slot of chunk c - 1 is free
+        SITK_QSTAMP(1)
+        const uint32_t qbo = (c & (QNS - 1)) * 24576;
         const uint32_t a0 = qa[0] + qbo, a1 = qa[1] + qbo;
         u32x4 x0, x1, x2, x3, y0, y1, y2, y3;
         SITK_MLP_ISSUE4(x0, x1, x2, x3, a0, a1, 0, 2048, 0, 2048);
-        if (c + 1 < nq) qissue(c + 1, (c + 1) & 1);
+        if (c + 3 < nq) qissue(c + 3, (c + 3) & (QNS - 1));
         f32x4 qacc[2][TT];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -682,6 +717,7 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
         SITK_MLP_WAIT4(x0, x1, x2, x3);
         SITK_MLP_Q_MMAS(2, x0, x1, x2, x3)
 #undef SITK_MLP_Q_MMAS
+        SITK_QSTAMP(2)
         u32x4 qsd[TT];
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -690,6 +726,12 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
           __builtin_amdgcn_raw_buffer_store_b128(qsd[t], r_y, qvo[t], c * 128, 0);
         }
         asm volatile("" : : "v"(qsd[0]), "v"(qsd[TT - 1]));         // store keep-alive (see the main loop)
+        SITK_QSTAMP(3)
+      }
+#undef SITK_QSTAMP
+      if constexpr (VAR == 6) {
+        if (blockIdx.x == 80 && lane == 0)
+          for (int i = 0; i < 4; ++i) g_mlp_stamps[224 + wave * 4 + i] = qst[i];
       }
     }
   } else {
@@ -786,6 +828,11 @@ static int attn_out_mlp_launch(const void* o_c, const void* wo_c, const float* b
                  "%s: bad next-block arguments (N3 %d)", what, N3);
     p.n_gamma = n_ln_w; p.n_beta = n_ln_b; p.n_w = reinterpret_cast<const h16*>(n_wqkv_c);
     p.n_h = reinterpret_cast<h16*>(n_h); p.n_mean = n_mean; p.n_rstd = n_rstd; p.n_y = reinterpret_cast<h16*>(n_qkv); p.N3 = N3;
+#ifdef SITK_AB
+    static const int var = sitk_ab_switch("SITK_MLP_VAR", 0);   // 6: stamped kernel (tools/mlp_stamps.py tail)
+    if (var == 6) hipLaunchKernelGGL((mlp_kernel<false, 6, 6, true, true, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
+    else
+#endif
     hipLaunchKernelGGL((mlp_kernel<false, 0, 6, true, true, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
   } else {
     hipLaunchKernelGGL((mlp_kernel<false, 0, 6, true, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
@@ -818,7 +865,7 @@ extern "C" int sitk_attn_out_mlp_next_fwd(const void* o_c, const void* wo_c, con
 
 // diagnostic: per-phase cycle sums of workgroup 0 written by the SITK_MLP_VAR=6 build (not part of the ABI header)
 extern "C" int sitk_mlp_debug_stamps(unsigned long long* out64) {
-  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_mlp_stamps), sizeof(unsigned long long) * (256 + 64)) == hipSuccess ? 0 : -1;
 }
 
 extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) {

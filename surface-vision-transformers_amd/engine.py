@@ -159,7 +159,7 @@ class TrainEngine:
     def __init__(self, model, batch_size, *, task="regression", input_layout="surface", loss="mse", optimizer="sgd",
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
-                 wgrad_overlap=None, prefetch_gather=True):
+                 wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -311,7 +311,9 @@ class TrainEngine:
         else:
             max_side = int(wgrad_overlap)
         self.wgrad_overlap = int(wgrad_overlap)
-        self._overlap = rt.lib.sitk_overlap_create(max_side, 42, 1) if wgrad_overlap > 0 else None
+        # workgroups of one side launch (two layers): 42 = the CUs the dim-192 chain's one-wave kernels leave idle
+        self.wgrad_overlap_cus = int(wgrad_overlap_cus) if wgrad_overlap_cus else 42
+        self._overlap = rt.lib.sitk_overlap_create(max_side, self.wgrad_overlap_cus, 1) if wgrad_overlap > 0 else None
         self._side = rt.lib.sitk_overlap_stream(self._overlap) if self._overlap else None
         self._side_torch = torch.cuda.ExternalStream(self._side, device=self.device) if self._overlap else None
         # With a side stream the patch gather of a regression step -- which reads the input batch and the patch table, no
