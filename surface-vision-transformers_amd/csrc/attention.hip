@@ -620,19 +620,15 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const h16* __r
 // lane's 16-byte fragment ks of its dO row (columns 32 ks + 8 fq .. + 8) -- no shuffle -- and go to `d_o_out` for the
 // key-side kernel in the same form.
 constexpr int FOLD_D = 192, FOLD_KS = FOLD_D / 32;
-template <int WAVES, bool FOLD = false>
-__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const h16* __restrict__ qkv, const h16* __restrict__ o,
-                                                              const h16* __restrict__ d_o, const float* __restrict__ lse,
-                                                              float* __restrict__ delta, h16* __restrict__ dqkv, int N,
-                                                              int H, float scale, const h16* __restrict__ dxmid = nullptr,
-                                                              const h16* __restrict__ wo_t = nullptr,
-                                                              h16* __restrict__ d_o_out = nullptr) {
+constexpr int RES_DQ_SMEM = 2 * (RES_MAX_N / 64) * 8192, RES_DQ_SMEM_FOLD = RES_DQ_SMEM + 64 * FOLD_D * 2;
+template <int WAVES, bool FOLD>
+SITK_DEV void attn_bwd_dq_res_body(char* smem, int bid, const h16* __restrict__ qkv, const h16* __restrict__ o,
+                                   const h16* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta,
+                                   h16* __restrict__ dqkv, int N, int H, float scale, const h16* __restrict__ dxmid,
+                                   const h16* __restrict__ wo_t, h16* __restrict__ d_o_out) {
   using T = h16;
-  __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192 + (FOLD ? 64 * FOLD_D * 2 : 0)];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  // FOLD: the H workgroups of one sample all read that sample's dxmid rows -- keep them on one XCD (one L2)
-  const int bid = FOLD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int h = bid % H, b = bid / H, I = H * 64, nkt = (N + 63) / 64;
   const size_t ld = (size_t)3 * I;
   const T* base = qkv + (size_t)b * N * ld;
@@ -744,15 +740,28 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const h16* 
   }
 }
 
+template <int WAVES, bool FOLD = false>
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const h16* __restrict__ qkv, const h16* __restrict__ o,
+                                                              const h16* __restrict__ d_o, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, h16* __restrict__ dqkv, int N,
+                                                              int H, float scale, const h16* __restrict__ dxmid = nullptr,
+                                                              const h16* __restrict__ wo_t = nullptr,
+                                                              h16* __restrict__ d_o_out = nullptr) {
+  __shared__ __attribute__((aligned(256))) char smem[FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM];
+  // FOLD: the H workgroups of one sample all read that sample's dxmid rows -- keep them on one XCD (one L2)
+  const int bid = FOLD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  attn_bwd_dq_res_body<WAVES, FOLD>(smem, bid, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out);
+}
+
+constexpr int RES_DKV_SMEM = 2 * (RES_MAX_N / 64) * 8192 + 2 * RES_MAX_N * 4;
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const h16* __restrict__ qkv, const h16* __restrict__ d_o,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                               h16* __restrict__ dqkv, int N, int H, float scale) {
+SITK_DEV void attn_bwd_dkv_res_body(char* smem, int bid, const h16* __restrict__ qkv, const h16* __restrict__ d_o,
+                                    const float* __restrict__ lse, const float* __restrict__ delta, h16* __restrict__ dqkv,
+                                    int N, int H, float scale) {
   using T = h16;
-  __shared__ __attribute__((aligned(256))) char smem[2 * (RES_MAX_N / 64) * 8192 + 2 * RES_MAX_N * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int h = blockIdx.x % H, b = blockIdx.x / H, I = H * 64, nqt = (N + 63) / 64;
+  const int h = bid % H, b = bid / H, I = H * 64, nqt = (N + 63) / 64;
   const size_t ld = (size_t)3 * I;
   const T* base = qkv + (size_t)b * N * ld;
   // row statistics FIRST: every LDS read of the sweep then is `address register + 16-bit immediate`
@@ -817,6 +826,34 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const h16*
       }
     }
   }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const h16* __restrict__ qkv, const h16* __restrict__ d_o,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               h16* __restrict__ dqkv, int N, int H, float scale) {
+  __shared__ __attribute__((aligned(256))) char smem[RES_DKV_SMEM];
+  attn_bwd_dkv_res_body<WAVES>(smem, (int)blockIdx.x, qkv, d_o, lse, delta, dqkv, N, H, scale);
+}
+
+// The two sides in ONE launch (round 4): a workgroup owns its (sample, head) through both -- the query side first (dQ, delta,
+// and with FOLD the dO rows), then, behind a workgroup barrier, the key side on the dO / delta rows the same workgroup has
+// just written (L2) and on q, k, v that the first half has just pulled through this XCD's L2.  One launch boundary per layer
+// less, and q, k, v cross HBM once instead of twice (section 8, round 4).  The single-side kernels above stay for profiling
+// (sitk_attention_bwd_phases with phases 1 or 2).
+template <bool FOLD>
+__global__ __launch_bounds__(1024) void attn_bwd_res_kernel(const h16* __restrict__ qkv, const h16* __restrict__ o,
+                                                            const h16* __restrict__ d_o, const float* __restrict__ lse,
+                                                            float* __restrict__ delta, h16* __restrict__ dqkv, int N, int H,
+                                                            float scale, const h16* __restrict__ dxmid, const h16* __restrict__ wo_t,
+                                                            h16* __restrict__ d_o_out) {
+  constexpr int SMEM = (FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM) > RES_DKV_SMEM ? (FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM) : RES_DKV_SMEM;
+  __shared__ __attribute__((aligned(256))) char smem[SMEM];
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);      // the H workgroups of a sample on one XCD (they share its dxmid rows)
+  attn_bwd_dq_res_body<16, FOLD>(smem, bid, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's dO / delta stores have left the CU ...
+  __syncthreads();                                       // ... and nobody reads the K / V image any more
+  attn_bwd_dkv_res_body<16>(smem, bid, qkv, FOLD ? d_o_out : d_o, lse, delta, dqkv, N, H, scale);
 }
 
 #ifdef SITK_AB
@@ -2049,6 +2086,13 @@ static int run_bwd_proj(const void* qkv, const void* o, const void* dxmid, const
     return check_launch("attention_bwd_dkv_pk");
   }
 #endif
+  if (phases == 3 && sitk_ab_switch("SITK_ATTN_MERGED", 1)) {    // both sides in one launch
+    hipLaunchKernelGGL((attn_bwd_res_kernel<true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
+                       reinterpret_cast<const h16*>(o), (const h16*)nullptr, lse, delta, reinterpret_cast<h16*>(dqkv), N, H,
+                       scale, reinterpret_cast<const h16*>(dxmid), reinterpret_cast<const h16*>(wo_t),
+                       reinterpret_cast<h16*>(d_o));
+    return check_launch("attention_bwd_proj_res");
+  }
   if (phases & 1)
   hipLaunchKernelGGL((attn_bwd_dq_res_kernel<16, true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
                      reinterpret_cast<const h16*>(o), (const h16*)nullptr, lse, delta, reinterpret_cast<h16*>(dqkv), N, H,
@@ -2079,6 +2123,12 @@ static int run_bwd(const void* qkv, const void* o, const void* d_o, const float*
       return check_launch("attention_bwd_dkv_pk");
     }
 #endif
+    if (N <= RES_MAX_N && phases == 3 && sitk_ab_switch("SITK_ATTN_MERGED", 1)) {    // both sides in one launch
+      hipLaunchKernelGGL((attn_bwd_res_kernel<false>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
+                         reinterpret_cast<const h16*>(o), reinterpret_cast<const h16*>(d_o), lse, delta,
+                         reinterpret_cast<h16*>(dqkv), N, H, scale, (const h16*)nullptr, (const h16*)nullptr, (h16*)nullptr);
+      return check_launch("attention_bwd_res");
+    }
     if (N <= RES_MAX_N) {
       if (phases & 1)
       hipLaunchKernelGGL(attn_bwd_dq_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),

@@ -522,23 +522,17 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
     }
     // ---- attention branch: xmid = x + Wo attn(Wqkv LN1(x)) + bo ----
     if (sitk_attention_bwd_proj_supported(c.N, D, dt)) {     // d_o = dx_mid Wo inside the query-side kernel
-      // (two single-phase calls = the two launches of sitk_attention_bwd_proj, with room for a timeline mark in between)
+      // (query side + key side: ONE launch where the sequence is LDS-resident, two otherwise)
       SITK_TRY(sitk_attention_bwd_phases(a.qkv, a.o, nullptr, dxBc, a.wo_t, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale,
-                                         dt, 1, stream));
-      SITK_MARK("attn_bwd_dq");
-      SITK_TRY(sitk_attention_bwd_phases(a.qkv, a.o, nullptr, dxBc, a.wo_t, S.d_o, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale,
-                                         dt, 2, stream));
-      SITK_MARK("attn_bwd_dkv");
+                                         dt, 3, stream));
+      SITK_MARK("attn_bwd");
     } else {
       sitk_gemm_desc d3 = gemm_desc(R, I, D, dxBc, D, 0, a.wo_t, SITK_EPI_STORE, S.d_o, I, 0);
       SITK_TRY(sitk_gemm_nt(&d3, dt, stream));
       SITK_MARK("gemm:dto_out");
       SITK_TRY(sitk_attention_bwd_phases(a.qkv, a.o, S.d_o, nullptr, nullptr, nullptr, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale,
-                                         dt, 1, stream));
-      SITK_MARK("attn_bwd_dq");
-      SITK_TRY(sitk_attention_bwd_phases(a.qkv, a.o, S.d_o, nullptr, nullptr, nullptr, a.lse, S.delta, dqkv, c.B, c.N, c.heads, D, scale,
-                                         dt, 2, stream));
-      SITK_MARK("attn_bwd_dkv");
+                                         dt, 3, stream));
+      SITK_MARK("attn_bwd");
     }
     // ---- the four weight (+ bias) gradients of the layer, one launch ----
     sitk_wgrad_desc wg[4] = {

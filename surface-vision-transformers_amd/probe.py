@@ -159,11 +159,12 @@ def layer_kernels(eng, nset):
             s.wo_t.data_ptr() if fold else None, s.d_o.data_ptr() if fold else None, s.lse.data_ptr(), s.delta.data_ptr(),
             dqkv.data_ptr(), B, N, H, D, 0.125, dt, phases, rt.stream_ptr()))
         return dqkv
-    # algorithmic work (backward = 2 x forward = four products): dP and dQ count for the query side, dV and dK
-    # for the key side; both kernels also recompute S (query side executes 3 products + the folded projection, key side 4)
-    add("attention backward, query side (dQ" + (", d to_out folded in)" if fold else ")"), "attn_bwd_dq",
-        lambda i: att_bwd(i, 1), att + (2.0 * R * D * I if fold else 0.0), R * (5 * I + (D if fold else I)) * es, L, "attn_bwd_dq")
-    add("attention backward, key side (dK, dV)", "attn_bwd_dkv", lambda i: att_bwd(i, 2), att, R * 6 * I * es, L, "attn_bwd_dkv")
+    # algorithmic work (backward = 2 x forward = four products: dP, dQ, dV, dK; both sides also recompute S, the
+    # query side executes the folded projection).  ONE launch where the sequence is LDS-resident (round 4: query side + key
+    # side merged, q / k / v cross HBM once), two launches timed as one row otherwise (one timeline mark behind the pair).
+    add("attention backward (dQ" + (", d to_out folded in" if fold else "") + ", dK, dV)", "attn_bwd",
+        lambda i: att_bwd(i, 3), 2 * att + (2.0 * R * D * I if fold else 0.0), R * (3 * I + I + (D + I if fold else I) + 3 * I) * es, L,
+        "attn_bwd")
     # the weight gradients of a whole backward slice run as one launch (csrc/encoder.hip): all L layers on one GPU
     probs = []
     nl = L if 4 * L <= 48 else 1
