@@ -224,6 +224,16 @@ int sitk_attn_out_mlp_next_fwd(const void* o_c, const void* wo_c, const float* b
                                float* n_rstd, void* n_qkv, int N3, int64_t rows, int D, int I, int M, int dtype,
                                sitk_stream_t stream);
 size_t sitk_mlp_bwd_partial_floats(int64_t rows);
+/* d to_qkv + LayerNorm backward of layer l (sitk_ln_gemm_bwd: dqkv .. partials1, N = 3 heads 64) and the fused MLP backward of
+ * layer l - 1 (sitk_mlp_bwd on the dx / dx_c the first half has just written: xmid .. partials2) in ONE launch (ABI 9).  Both
+ * kernels give a workgroup the same 96 rows, so the second half reads its own workgroup's rows back from L2.  Same results,
+ * bit for bit, as the two calls.  Needs sitk_ln_gemm_mlp_bwd_supported (h16, dim 192, at most 24 576 rows).              */
+int sitk_ln_gemm_mlp_bwd_supported(int64_t rows, int D, int N, int M, int dtype);
+int sitk_ln_gemm_mlp_bwd(const void* dqkv, const void* wqkv_t_c, const float* x, const float* mean1, const float* rstd1,
+                         const float* ln1_w, const float* dres, float* dx, void* dx_c, float* partials1, int N,
+                         const float* xmid, const float* mean2, const float* rstd2, const float* ln2_w, const void* w2t_c,
+                         const void* w1t_c, const void* gd, void* du, float* dx_mid, void* dx_mid_c, float* partials2,
+                         int64_t rows, int D, int M, int dtype, sitk_stream_t stream);
 int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
                  const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du, float* dx,
                  void* dx_c, float* partials, int64_t rows, int D, int M, int dtype, sitk_stream_t stream);

@@ -488,6 +488,7 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
   SITK_MARK("begin");
   SITK_TRY(sitk_cast_rows(dx, D, S.dxAc[slot(layer_end - 1)], D, R, D, dt, stream));
   SITK_MARK("cast_rows");
+  bool mlp_bwd_done = false;
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const LayerActs& a = L.layers[l];
     const float* xl = l == 0 ? x_in : a.x_in;
@@ -503,9 +504,12 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
     float* part2 = S.ln_partials + (size_t)(2 * l + 1) * S.ln_partial_floats;
     const void* gact = a.g;
     if (mlp_fused(c)) {
-      SITK_TRY(sitk_mlp_bwd(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, S.dxB, dxBc, part2, R, D, M, dt,
-                            stream));
-      SITK_MARK("mlp_bwd");
+      if (!mlp_bwd_done) {      // (done already when the previous layer's d to_qkv launch carried it: the pair kernel below)
+        SITK_TRY(sitk_mlp_bwd(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, S.dxB, dxBc, part2, R, D, M, dt,
+                              stream));
+        SITK_MARK("mlp_bwd");
+      }
+      mlp_bwd_done = false;
       ln_entries.push_back(LnFinalizeEntry{part2, G[l].ln2_w, G[l].ln2_b, (int)(sitk_mlp_bwd_partial_floats(R) / (2 * D))});
       gact = a.g ? a.g : S.g[sl];
     } else {
@@ -561,7 +565,19 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
     else if (S.wg_batch) wg_all.insert(wg_all.end(), wg, wg + 4);       // launched once, after the slice's last layer
     else { SITK_TRY(sitk_gemm_wgrad_group_ws(wg, 4, dt, S.wgrad_ws, S.wgrad_ws_bytes, stream)); SITK_MARK("wgrad"); }
     float* part1 = S.ln_partials + (size_t)(2 * l) * S.ln_partial_floats;
-    if (qkv_fused(c)) {
+    if (qkv_fused(c) && l > layer_begin && mlp_fused(c) && sitk_ln_gemm_mlp_bwd_supported(R, D, 3 * I, M, dt)) {
+      // d to_qkv + LayerNorm backward of THIS layer and the MLP backward of the NEXT one (l - 1) in one launch: same 96-row
+      // workgroups, the second half reads back the rows its own workgroup has just written (dx, dxc_next)
+      const LayerActs& an = L.layers[l - 1];
+      const int sn = slot(l - 1);
+      float* part2n = S.ln_partials + (size_t)(2 * (l - 1) + 1) * S.ln_partial_floats;
+      SITK_TRY(sitk_ln_gemm_mlp_bwd(dqkv, a.wqkv_t, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, dxc_next, part1, 3 * I, an.xmid,
+                                    an.mean2, an.rstd2, P[l - 1].ln2_w, an.w2_t, an.w1_t, an.u, S.du[sn], S.dxB, S.dxBc[sn], part2n, R,
+                                    D, M, dt, stream));
+      SITK_MARK("ln_gemm_mlp_bwd");
+      mlp_bwd_done = true;
+      ln_entries.push_back(LnFinalizeEntry{part1, G[l].ln1_w, G[l].ln1_b, (int)(sitk_ln_gemm_bwd_partial_floats(R) / (2 * D))});
+    } else if (qkv_fused(c)) {
       SITK_TRY(sitk_ln_gemm_bwd(dqkv, a.wqkv_t, xl, a.mean1, a.rstd1, P[l].ln1_w, S.dxB, dx, dxc_next, part1, R, D, 3 * I, dt,
                                 stream));
       SITK_MARK("ln_gemm_bwd");

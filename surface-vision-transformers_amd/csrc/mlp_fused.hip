@@ -39,6 +39,7 @@
 // halves of a wave pair exchange partial sums through LDS and each finishes 96 of the 192 features.
 #include "common.h"
 #include "fused_epilogue.h"
+#include "ln_gemm_bwd_body.h"
 
 namespace sitk {
 
@@ -143,14 +144,15 @@ static_assert(MLP_SMEM <= 163840, "LDS plan");
 
 // TG = token groups (of 16 TT rows = 2 waves) per workgroup; (TG, TT) = (4, 2): 128 rows, 8 waves; (6, 1): 96 rows,
 // 12 waves; (3, 2): 96 rows, 6 waves (A/B only).  See fused_block_rows() in fused_epilogue.h.
-template <bool BWD, int VAR = 0, int TG = 4, bool PROJ = false, bool NEXT = false, int TT = 2>
-__global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
+// The kernel's body as a device function (smem: MLP_SMEM bytes, 256-byte aligned): mlp_kernel below is this and nothing else;
+// ln_gemm_mlp_bwd_kernel chains it behind the body of ln_gemm_bwd_kernel.
+template <bool BWD, int VAR, int TG, bool PROJ, bool NEXT, int TT>
+SITK_DEV void mlp_body(const MlpParams& p, char* smem) {
   static_assert(!NEXT || PROJ, "the appended LayerNorm + to_qkv shares the 96-row LDS plan of the projection prologue");
   constexpr int D = MLP_D, BLK = 16 * TT * TG, NT = 128 * TG, PPW = 24 / TG;   // rows, threads, DMA pieces per wave and chunk
   static_assert(!PROJ || (!BWD && BLK == 96), "the projection prologue needs Wo (72 KB) + a 96-row fp32 row buffer in LDS");
   constexpr int PAR = PROJ ? 1 : 0;                                      // ring slot of chunk 0
   constexpr int W1B = MLP_W1B, W2B = MLP_W2B;
-  __shared__ __attribute__((aligned(256))) char smem[MLP_SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int tg = wave >> 1, hh = wave & 1;
@@ -747,6 +749,25 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
   }
 }
 
+template <bool BWD, int VAR = 0, int TG = 4, bool PROJ = false, bool NEXT = false, int TT = 2>
+__global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
+  __shared__ __attribute__((aligned(256))) char smem[MLP_SMEM];
+  mlp_body<BWD, VAR, TG, PROJ, NEXT, TT>(p, smem);
+}
+
+// d to_qkv + LayerNorm backward of layer l, then the MLP backward of layer l - 1, in ONE launch (round 4).  Both kernels give a
+// workgroup the same 96 rows, and everything the second reads of the first's output (dx fp32 and its compute-dtype copy) are
+// that workgroup's OWN rows: behind a workgroup barrier they come back from this XCD's L2 instead of crossing HBM, and the
+// chain has one launch boundary per layer less.  12 waves x 16 tokens only (the geometry of the one-round shapes).
+__global__ __launch_bounds__(768) void ln_gemm_mlp_bwd_kernel(LnGemmParams p1, MlpParams p2) {
+  static_assert(lg_bwd_smem<6, 1>() <= MLP_SMEM, "LDS plan");
+  __shared__ __attribute__((aligned(256))) char smem[MLP_SMEM];
+  ln_gemm_bwd_body<6, 1>(p1, smem, reinterpret_cast<const h16*>(g_zero_page_mlp));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's dx / dxc rows have left the CU ...
+  __syncthreads();                                       // ... and nobody reads the first kernel's LDS image any more
+  mlp_body<true, 0, 6, false, false, 1>(p2, smem);
+}
+
 // 96-row workgroups run as 12 waves of 16 tokens (3 per SIMD); SITK_MLP_TT1=0 selects the 6 x 32-token
 // variant they replaced (2,2,1,1 waves per SIMD), kept for A/B measurements
 static bool mlp_tt1() {
@@ -899,4 +920,40 @@ extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, c
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<true, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL((mlp_kernel<true, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_bwd");
+}
+
+SITK_F16_TWIN(sitk_ln_gemm_mlp_bwd_supported)
+extern "C" int sitk_ln_gemm_mlp_bwd_supported(int64_t rows, int D, int N, int M, int dtype) {
+  SITK_FORWARD_F16(dtype, sitk_ln_gemm_mlp_bwd_supported, rows, D, N, M, dtype);
+  return sitk_mlp_fused_supported(D, M, dtype) && N % 64 == 0 && N >= 64 && rows > 0 && rows * (int64_t)N < (1ll << 30) &&
+         fused_block_rows(rows) == 96 && mlp_tt1() && sitk_ab_switch("SITK_LG_TT1", 1) && sitk_ab_switch("SITK_BWD_PAIR", 1);
+}
+
+SITK_F16_TWIN(sitk_ln_gemm_mlp_bwd)
+extern "C" int sitk_ln_gemm_mlp_bwd(const void* dqkv, const void* wqkv_t_c, const float* x, const float* mean1, const float* rstd1,
+                                    const float* ln1_w, const float* dres, float* dx, void* dx_c, float* partials1, int N,
+                                    const float* xmid, const float* mean2, const float* rstd2, const float* ln2_w,
+                                    const void* w2t_c, const void* w1t_c, const void* gd, void* du, float* dx_mid, void* dx_mid_c,
+                                    float* partials2, int64_t rows, int D, int M, int dtype, sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_ln_gemm_mlp_bwd, dqkv, wqkv_t_c, x, mean1, rstd1, ln1_w, dres, dx, dx_c, partials1, N, xmid, mean2, rstd2, ln2_w, w2t_c, w1t_c, gd, du, dx_mid, dx_mid_c, partials2, rows, D, M, dtype, stream);
+  SITK_REQUIRE(dqkv && wqkv_t_c && x && mean1 && rstd1 && ln1_w && dx && dx_c && partials1 && xmid && mean2 && rstd2 && ln2_w &&
+               w2t_c && w1t_c && gd && du && dx_mid && dx_mid_c && partials2, "ln_gemm_mlp_bwd: null pointer");
+  SITK_REQUIRE(sitk_ln_gemm_mlp_bwd_supported(rows, D, N, M, dtype),
+               "ln_gemm_mlp_bwd: needs h16, dim 192, 96-row workgroups (at most 24576 rows) (got rows %lld dim %d N %d mlp_dim %d)",
+               (long long)rows, D, N, M);
+  LnGemmParams p1 = {};
+  p1.x = x; p1.gamma = ln1_w; p1.w = reinterpret_cast<const h16*>(wqkv_t_c);
+  p1.mean = const_cast<float*>(mean1); p1.rstd = const_cast<float*>(rstd1);
+  p1.y = const_cast<h16*>(reinterpret_cast<const h16*>(dqkv));
+  p1.dres = dres; p1.dx = dx; p1.dxc = reinterpret_cast<h16*>(dx_c); p1.partials = partials1;
+  p1.R = (int)rows; p1.N = N;
+  MlpParams p2 = {};
+  p2.x = xmid; p2.gamma = ln2_w; p2.mean = const_cast<float*>(mean2); p2.rstd = const_cast<float*>(rstd2);
+  p2.wa = reinterpret_cast<const h16*>(w2t_c); p2.wb = reinterpret_cast<const h16*>(w1t_c);
+  p2.u = const_cast<h16*>(reinterpret_cast<const h16*>(gd));
+  p2.du = reinterpret_cast<h16*>(du); p2.dy = dx; p2.dyc = reinterpret_cast<const h16*>(dx_c);
+  p2.out = dx_mid; p2.outc = reinterpret_cast<h16*>(dx_mid_c); p2.partials = partials2;
+  p2.R = (int)rows; p2.M = M;
+  hipLaunchKernelGGL(ln_gemm_mlp_bwd_kernel, dim3(cdiv((int)rows, 96)), dim3(768), 0, reinterpret_cast<hipStream_t>(stream), p1, p2);
+  return check_launch("ln_gemm_mlp_bwd");
 }

@@ -298,6 +298,30 @@ def ln_gemm_bwd(dy, wt_c, x, mean, rstd, ln_w, dres, dtype):
     return dx, dx_c, partials.view(-1, 2, D)
 
 
+def ln_gemm_mlp_bwd_supported(rows, D, N, M, dtype):
+    return bool(rt.lib.sitk_ln_gemm_mlp_bwd_supported(rows, D, N, M, rt.dtype_code(dtype)))
+
+
+def ln_gemm_mlp_bwd(dqkv, wqkv_t_c, x, mean1, rstd1, ln1_w, dres, xmid, mean2, rstd2, ln2_w, w2t_c, w1t_c, gd, dtype):
+    """ln_gemm_bwd (layer l) + mlp_bwd (layer l - 1, on the dx / dx_c the first half writes) in ONE launch.
+    Returns (dx, dx_c, partials1, dx_mid, dx_mid_c, du, partials2) -- the outputs of the two calls, bit for bit."""
+    rows, D = x.shape
+    N, M = dqkv.shape[1], gd.shape[1]
+    code = rt.dtype_code(dtype)
+    dx, dx_mid = torch.empty_like(x), torch.empty_like(x)
+    dx_c = torch.empty((rows, D), dtype=dqkv.dtype, device=x.device)
+    dx_mid_c = torch.empty_like(dx_c)
+    du = torch.empty_like(gd)
+    p1 = torch.empty(rt.lib.sitk_ln_gemm_bwd_partial_floats(rows), dtype=torch.float32, device=x.device)
+    p2 = torch.empty(rt.lib.sitk_mlp_bwd_partial_floats(rows), dtype=torch.float32, device=x.device)
+    rt.check(rt.lib.sitk_ln_gemm_mlp_bwd(dqkv.data_ptr(), wqkv_t_c.data_ptr(), x.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(),
+                                         ln1_w.data_ptr(), rt.ptr(dres), dx.data_ptr(), dx_c.data_ptr(), p1.data_ptr(), N,
+                                         xmid.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), ln2_w.data_ptr(), w2t_c.data_ptr(),
+                                         w1t_c.data_ptr(), gd.data_ptr(), du.data_ptr(), dx_mid.data_ptr(), dx_mid_c.data_ptr(),
+                                         p2.data_ptr(), rows, D, M, code, rt.stream_ptr()))
+    return dx, dx_c, p1.view(-1, 2, D), dx_mid, dx_mid_c, du, p2.view(-1, 2, D)
+
+
 # ---- attention -------------------------------------------------------------------------------------
 def attention_fwd(qkv, B, N, H, scale, dtype):
     code = rt.dtype_code(dtype)

@@ -7,7 +7,8 @@ inside a hipGraph, and the replay is timed between two HIP events on the replay 
 Each repetition works on its OWN set of operand and output buffers (one set per layer, as in the real step, where
 every layer's activations are distinct tensors): replaying one launch over the same buffers lets its stores hit lines
 the previous repetition left in the Infinity Cache and reads 20-25 % fast (round 1's table did that).  Rows are single
-kernels (the two kernels of the attention backward are timed one by one through sitk_attention_bwd_phases), so each
+kernels (round 4: the attention backward is ONE launch where the sequence is LDS-resident, and d to_qkv + norm backward of
+layer l runs in one launch with the MLP backward of layer l - 1), so each
 `us` must agree with the same kernel's average in profiles/*step_kernel_stats*.md of the same bench command.
 
 The dominant kernel is the single kernel with the largest (average duration x launches per step).  Its bound is the
@@ -181,10 +182,22 @@ def layer_kernels(eng, nset):
     add(f"weight gradients of {nl} layer(s), one launch", "wgrad_x2_kernel" if nb_all else "wgrad_kernel",
         lambda i: ops.gemm_wgrad_group(probs, dt, workspace=ws_all if nb_all else None), wg_flops * nl,
         nl * R * (2 * D + 2 * M + 4 * I + 2 * D) * es, L // nl, "wgrad")
+    pair = fused_qkv and fused_mlp and L > 1 and ops.ln_gemm_mlp_bwd_supported(R, D, 3 * I, M, dt)
+    if pair:
+        # layers L-1 .. 1: d to_qkv + norm backward of layer l and the MLP backward of layer l - 1 in ONE launch (round 4); the
+        # first MLP backward and the last d to_qkv of a slice stay single launches (the two rows around this one)
+        rows[:] = [(n, k, f, fl, nb, (1 if lab == "mlp_bwd" else ln), lab) for (n, k, f, fl, nb, ln, lab) in rows]
+        add("d to_qkv + norm backward + next layer's d net.3 x GELU' + d net.0 + norm backward (one launch)", "ln_gemm_mlp_bwd_kernel",
+            lambda i: ops.ln_gemm_mlp_bwd(S[i].qkv, S[i].wqkv_t, S[i].x32, S[i].mean, S[i].rstd, S[i].gam, S[i].dx32, S[i].x32,
+                                          S[i].mean, S[i].rstd, S[i].gam, S[i].w2_t, S[i].w1_t, S[i].u, dt),
+            # bytes that have to cross HBM: the two kernels' sums minus dx (fp32) and its compute-dtype copy, which the second
+            # half reads back from L2 (its own workgroup wrote them)
+            2.0 * R * 3 * I * D + mlp_flops, R * (3 * I * es + 12 * D + D * es) + R * (2 * M * es + 8 * D + D * es), L - 1,
+            "ln_gemm_mlp_bwd")
     if fused_qkv:
         add("d to_qkv + norm backward (fused)", "ln_gemm_bwd_kernel",
             lambda i: ops.ln_gemm_bwd(S[i].qkv, S[i].wqkv_t, S[i].x32, S[i].mean, S[i].rstd, S[i].gam, S[i].dx32, dt),
-            2.0 * R * 3 * I * D, R * (3 * I * es + 12 * D + D * es), L)
+            2.0 * R * 3 * I * D, R * (3 * I * es + 12 * D + D * es), 1 if pair else L)
     else:
         add("d to_qkv", "gemm_nt", lambda i: ops.gemm_nt(S[i].qkv, S[i].wqkv_t, torch.empty_like(S[i].h), dt), 2.0 * R * 3 * I * D,
             R * (3 * I + D) * es, L)

@@ -86,6 +86,8 @@ _SIGS = {
     "sitk_attn_out_mlp_next_fwd": (C.c_int, [_P] * 24 + [_I, _L, _I, _I, _I, _I, _P]),
     "sitk_mlp_bwd_partial_floats": (_Z, [_L]),
     "sitk_mlp_bwd": (C.c_int, [_P] * 13 + [_L, _I, _I, _I, _P]),
+    "sitk_ln_gemm_mlp_bwd_supported": (C.c_int, [_L, _I, _I, _I, _I]),
+    "sitk_ln_gemm_mlp_bwd": (C.c_int, [_P] * 10 + [_I] + [_P] * 11 + [_L, _I, _I, _I, _P]),
     "sitk_ln_gemm_fused_supported": (C.c_int, [_I, _I, _I]),
     "sitk_ln_gemm_fwd": (C.c_int, [_P] * 8 + [_L, _I, _I, _I, _P]),
     "sitk_ln_gemm_bwd_partial_floats": (_Z, [_L]),

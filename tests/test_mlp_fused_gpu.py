@@ -267,3 +267,32 @@ def test_attn_out_mlp_next_fwd(ops, rows):
     again = ops.attn_out_mlp_next_fwd(o, woc, bo, x, ln_w, ln_b, w1c, b1, w2c, b2, n_lw, n_lb, wq, _H.name, want_g=True)
     for a, b in zip(got, again):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("rows", [96, 321 * 3, 1000, 20544])
+def test_ln_gemm_mlp_bwd_pair_launch_is_bitwise_the_two_launches(ops, rows):
+    """sitk_ln_gemm_mlp_bwd = sitk_ln_gemm_bwd (d to_qkv + LayerNorm backward of layer l) followed by sitk_mlp_bwd of layer
+    l - 1 on the dx / dx_c it wrote, in ONE launch (same 96-row workgroups; the second half reads its own rows back): every
+    output must carry the bits of the two separate launches, repeatedly (a missing wait between the halves shows as noise)."""
+    M, N3 = 768, 576
+    assert ops.ln_gemm_mlp_bwd_supported(rows, D, N3, M, _H.name)
+    assert not ops.ln_gemm_mlp_bwd_supported(30000, D, N3, M, _H.name)           # 128-row workgroups: separate launches
+    x, xmid = rnd("pair/x", (rows, D), 1.5), rnd("pair/xm", (rows, D), 1.5)
+    dres = rnd("pair/dres", (rows, D), 1.0)
+    dqkv = rnd("pair/dqkv", (rows, N3), 1.0).to(_H.td)
+    wq_t = rnd("pair/wq", (D, N3), D ** -0.5).to(_H.td)
+    ln1_w = rnd("pair/l1", (D,), 0.3) + 1.0
+    ln_w, ln_b, w1, b1, w2, b2 = params("pair", M)
+    w1c, w2c = w1.to(_H.td), w2.to(_H.td)
+    w1t, w2t = w1c.T.contiguous(), w2c.T.contiguous()
+    _, _, mean2, rstd2, gd, _ = ops.mlp_fwd(xmid, ln_w, ln_b, w1c, b1, w2c, b2, _H.name)
+    xd = x.double()
+    mean1, rstd1 = xd.mean(1).float(), (xd.var(1, unbiased=False) + 1e-5).rsqrt().float()
+    dx, dx_c, p1 = ops.ln_gemm_bwd(dqkv, wq_t, x, mean1, rstd1, ln1_w, dres, _H.name)
+    dxm, dxm_c, du, p2 = ops.mlp_bwd(dx, dx_c, xmid, mean2, rstd2, ln_w, w2t, w1t, gd, _H.name)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got = ops.ln_gemm_mlp_bwd(dqkv, wq_t, x, mean1, rstd1, ln1_w, dres, xmid, mean2, rstd2, ln_w, w2t, w1t, gd, _H.name)
+        torch.cuda.synchronize()
+        for a, b in zip(got, (dx, dx_c, p1, dxm, dxm_c, du, p2)):
+            assert torch.equal(a, b)

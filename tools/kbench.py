@@ -1,7 +1,7 @@
 """Micro-benchmark of single hot-path kernels at the headline shapes (for rocprofv3 --pmc runs).
 
     python tools/kbench.py <kernel> [--reps 20] [--batch 64]
-kernels: wgrad_w1 wgrad_w2 wgrad_qkv wgrad_layer gemm_qkv gemm_fc1 gemm_fc2 gemm_dfc2 gemm_dfc1 attn_fwd attn_bwd attn_bwd_do attn_bwd_proj ln_fwd ln_bwd mlp_fwd mlp_fwd_nosave mlp_bwd lnqkv_fwd lnqkv_bwd
+kernels: wgrad_w1 wgrad_w2 wgrad_qkv wgrad_layer gemm_qkv gemm_fc1 gemm_fc2 gemm_dfc2 gemm_dfc1 attn_fwd attn_bwd attn_bwd_do attn_bwd_proj ln_fwd ln_bwd mlp_fwd mlp_fwd_nosave mlp_bwd lnqkv_fwd lnqkv_bwd lnqkv_mlp_bwd
 """
 import argparse
 import os
@@ -66,6 +66,7 @@ def main():
         "mlp_bwd": lambda: ops.mlp_bwd(x32, dxT, x32, mean, rstd, bD, w["w2_t"], w["w1_t"], u, dt),
         "lnqkv_fwd": lambda: ops.ln_gemm_fwd(x32, bD, bD, w["qkv"], dt),
         "lnqkv_bwd": lambda: ops.ln_gemm_bwd(qkv, w["qkv_t"], x32, mean, rstd, bD, x32, dt),
+        "lnqkv_mlp_bwd": lambda: ops.ln_gemm_mlp_bwd(qkv, w["qkv_t"], x32, mean, rstd, bD, x32, x32, mean, rstd, bD, w["w2_t"], w["w1_t"], u, dt),
         "proj_mlp_fwd": lambda: ops.attn_out_mlp_fwd(o, w["qkv"][:D].contiguous(), bD, x32, bD, bD, w["w1"], bM, w["w2"], bD, dt, want_g=True),
         "proj_mlp_next_fwd": lambda: ops.attn_out_mlp_next_fwd(o, w["qkv"][:D].contiguous(), bD, x32, bD, bD, w["w1"], bM, w["w2"], bD, bD, bD, w["qkv"], dt, want_g=True),
         "mlp_fwd_g": lambda: ops.mlp_fwd(x32, bD, bD, w["w1"], bM, w["w2"], bD, dt, want_g=True),
