@@ -166,6 +166,7 @@ def main():
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: the patch gather on the main stream, in front of the patch embedding")
     ap.add_argument("--wgrad-overlap", type=int, default=None,
                     help="layers whose weight gradients run on a side stream beside the backward chain (default: engine's choice)")
+    ap.add_argument("--no-head-deferred", action="store_true", help="A/B: the head's gradient sums behind the head kernel on the main stream")
     ap.add_argument("--overlap-cus", type=int, default=None, help="workgroups of one side-stream weight-gradient launch (default 42)")
     ap.add_argument("--dp-form", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL form of the step (3 backward slices, one hipGraph per segment, every bucket "
@@ -234,7 +235,7 @@ def main():
     eng = engine.TrainEngine(model, B, task=args.task, input_layout="surface", lr=1e-5, momentum=0.9,
                              process_group=pg, use_graph=(True if args.graph else (False if args.no_graph else None)), device=dev,
                              wgrad_overlap=args.wgrad_overlap, prefetch_gather=not args.no_prefetch,
-                             wgrad_overlap_cus=args.overlap_cus)
+                             wgrad_overlap_cus=args.overlap_cus, head_deferred=not args.no_head_deferred)
     g = torch.Generator(device=dev).manual_seed(100 + rank)   # every rank its own synthetic shard
     x = torch.randn((B, 40962, 4), device=dev, generator=g)
     y = torch.randn((B,), device=dev, generator=g) * 2 + 40 if args.task == "regression" else None

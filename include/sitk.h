@@ -237,6 +237,12 @@ int sitk_ln_gemm_mlp_bwd(const void* dqkv, const void* wqkv_t_c, const float* x,
 int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
                  const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du, float* dx,
                  void* dx_c, float* partials, int64_t rows, int D, int M, int dtype, sitk_stream_t stream);
+/* sitk_mlp_bwd for the first backward kernel of a chain, where dy exists in fp32 only: dy_c is an OUTPUT here -- the kernel
+ * rounds its operand from dy and writes the compute-dtype copy (the weight gradient of net.3 reads it).  sitk_cast_rows +
+ * sitk_mlp_bwd in one launch, same bits (ABI 9). */
+int sitk_mlp_bwd_cast(const float* dy, void* dy_c, const float* x, const float* mean, const float* rstd,
+                 const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du, float* dx,
+                 void* dx_c, float* partials, int64_t rows, int D, int M, int dtype, sitk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused LayerNorm + bias-free projection of the attention half of a block, PreNorm(LayerNorm, Attention)
@@ -428,6 +434,15 @@ int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b,
                            const float* target, float* logits, float* loss, float* dx, float* d_ln_w, float* d_ln_b,
                            float* d_w, float* d_b, int B, int N, int D, int n_classes, int pool_mean, int l1, float* ws,
                            float* grad_scale, sitk_stream_t stream);
+/* sitk_head_loss_fwd_bwd without the reduction of the workspace rows (ws is required): dx -- all that the backward chain
+ * waits for -- is complete when it returns; the head's parameter gradients and the loss are complete only after
+ * sitk_head_finalize(ws, ...) has run, on any stream ordered behind this call (the engine: the side stream, beside the chain).
+ * Same bits as the one-call form (ABI 9). */
+int sitk_head_loss_fwd_bwd_deferred(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
+                                    const float* target, float* logits, float* dx, int B, int N, int D, int n_classes,
+                                    int pool_mean, int l1, float* ws, float* grad_scale, sitk_stream_t stream);
+int sitk_head_finalize(const float* ws, int B, int D, int n_classes, float* d_ln_w, float* d_ln_b, float* d_w, float* d_b,
+                       float* loss, sitk_stream_t stream);
 
 /* column sums: out[c] += sum_r in[r][c]  (d_pos_embedding / d_cls_token over the batch).  Up to 512 rows (4 096 when
  * cols >= 4 096) one workgroup per column group sums all rows in a fixed order (bitwise reproducible; out must not be

@@ -486,8 +486,13 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
   std::vector<sitk_wgrad_desc> wg_all;
   wg_all.reserve(4 * (layer_end - layer_begin));
   SITK_MARK("begin");
-  SITK_TRY(sitk_cast_rows(dx, D, S.dxAc[slot(layer_end - 1)], D, R, D, dt, stream));
-  SITK_MARK("cast_rows");
+  // the compute-dtype copy of the incoming dx: written by the first MLP backward launch itself where that is the fused kernel
+  static const int cast_in_mlp = sitk_ab_switch("SITK_BWD_CAST_FOLD", 1);
+  bool dx_cast_pending = mlp_fused(c) && cast_in_mlp;
+  if (!dx_cast_pending) {
+    SITK_TRY(sitk_cast_rows(dx, D, S.dxAc[slot(layer_end - 1)], D, R, D, dt, stream));
+    SITK_MARK("cast_rows");
+  }
   bool mlp_bwd_done = false;
   for (int l = layer_end - 1; l >= layer_begin; --l) {
     const LayerActs& a = L.layers[l];
@@ -505,8 +510,14 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
     const void* gact = a.g;
     if (mlp_fused(c)) {
       if (!mlp_bwd_done) {      // (done already when the previous layer's d to_qkv launch carried it: the pair kernel below)
-        SITK_TRY(sitk_mlp_bwd(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, S.dxB, dxBc, part2, R, D, M, dt,
-                              stream));
+        if (dx_cast_pending) {
+          SITK_TRY(sitk_mlp_bwd_cast(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, S.dxB, dxBc, part2, R, D,
+                                     M, dt, stream));
+        } else {
+          SITK_TRY(sitk_mlp_bwd(dx, dxAc, a.xmid, a.mean2, a.rstd2, P[l].ln2_w, a.w2_t, a.w1_t, a.u, du, S.dxB, dxBc, part2, R, D, M, dt,
+                                stream));
+        }
+        dx_cast_pending = false;
         SITK_MARK("mlp_bwd");
       }
       mlp_bwd_done = false;

@@ -808,10 +808,10 @@ extern "C" int sitk_embed_cls_rows(float* x, const float* cls_token, const float
   return check_launch("embed_cls_rows");
 }
 
-extern "C" int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
-                                      const float* target, float* logits, float* loss, float* dx, float* d_ln_w,
-                                      float* d_ln_b, float* d_w, float* d_b, int B, int N, int D, int n_classes,
-                                      int pool_mean, int l1, float* ws, float* grad_scale, sitk_stream_t stream) {
+static int head_loss_launch(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
+                            const float* target, float* logits, float* loss, float* dx, float* d_ln_w, float* d_ln_b,
+                            float* d_w, float* d_b, int B, int N, int D, int n_classes, int pool_mean, int l1, float* ws,
+                            float* grad_scale, bool finalize, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(x && ln_w && ln_b && w && b && target && logits && loss && dx && d_ln_w && d_ln_b && d_w && d_b,
                "head_loss_fwd_bwd: null pointer");
@@ -830,12 +830,40 @@ extern "C" int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const f
                        d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1, ws, grad_scale);
   }
   SITK_LAUNCH_CHECK("head_loss_fwd_bwd");
-  if (ws) {
+  if (ws && finalize) {
     hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 64)), dim3(64), 0, s, ws, B, D,
                        n_classes, d_b, d_w, d_ln_w, d_ln_b, loss);
     SITK_LAUNCH_CHECK("head_finalize");
   }
   return SITK_OK;
+}
+
+extern "C" int sitk_head_loss_fwd_bwd(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
+                                      const float* target, float* logits, float* loss, float* dx, float* d_ln_w,
+                                      float* d_ln_b, float* d_w, float* d_b, int B, int N, int D, int n_classes,
+                                      int pool_mean, int l1, float* ws, float* grad_scale, sitk_stream_t stream) {
+  return head_loss_launch(x, ln_w, ln_b, w, b, target, logits, loss, dx, d_ln_w, d_ln_b, d_w, d_b, B, N, D, n_classes, pool_mean, l1,
+                          ws, grad_scale, true, stream);
+}
+
+// The same without the reduction of the workspace rows: dx (all the backward chain waits for) is complete, the head's parameter
+// gradients and the loss are not until sitk_head_finalize has run -- on any stream ordered behind this call, e.g. beside the chain.
+extern "C" int sitk_head_loss_fwd_bwd_deferred(const float* x, const float* ln_w, const float* ln_b, const float* w, const float* b,
+                                               const float* target, float* logits, float* dx, int B, int N, int D, int n_classes,
+                                               int pool_mean, int l1, float* ws, float* grad_scale, sitk_stream_t stream) {
+  SITK_REQUIRE(ws, "head_loss_fwd_bwd_deferred: needs the workspace");
+  float* unused = ws;        // (never written: every gradient term goes to the workspace rows)
+  return head_loss_launch(x, ln_w, ln_b, w, b, target, logits, unused, dx, unused, unused, unused, unused, B, N, D, n_classes,
+                          pool_mean, l1, ws, grad_scale, false, stream);
+}
+
+extern "C" int sitk_head_finalize(const float* ws, int B, int D, int n_classes, float* d_ln_w, float* d_ln_b, float* d_w,
+                                  float* d_b, float* loss, sitk_stream_t stream) {
+  using namespace sitk;
+  SITK_REQUIRE(ws && d_ln_w && d_ln_b && d_w && d_b && B > 0 && D > 0 && n_classes > 0, "head_finalize: bad arguments");
+  hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv((int)sitk_head_ws_floats(1, D, n_classes), 64)), dim3(64), 0,
+                     reinterpret_cast<hipStream_t>(stream), ws, B, D, n_classes, d_b, d_w, d_ln_w, d_ln_b, loss);
+  return check_launch("head_finalize");
 }
 
 extern "C" int sitk_loss_fwd_bwd(const float* pred, const float* target, float* loss, float* dpred, int n, int l1,

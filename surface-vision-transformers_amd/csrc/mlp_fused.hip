@@ -60,6 +60,7 @@ struct MlpParams {
   float* out;          // (R,192) fp32                     | dx (R,192) fp32
   // backward only
   const h16* dyc;     // (R,192) compute-dtype copy of dy
+  h16* dyc_make;      // not null: that copy does not exist yet -- round dy here and WRITE it (the weight gradients read it)
   const float* dy;     // (R,192) fp32 dy (residual gradient)
   h16* du;            // (R,M)
   h16* outc;          // (R,192) compute-dtype copy of dx
@@ -356,12 +357,30 @@ SITK_DEV void mlp_body(const MlpParams& p, char* smem) {
         hf[t][k] = *reinterpret_cast<const u32x4*>(sH + (k >> 1) * (BLK * 128) +
                                                    lds_off(16 * TT * tg + 16 * t + fr, (k & 1) * 64 + fq * 16));
   } else {
-    const __amdgpu_buffer_rsrc_t r_dyc = make_rsrc(p.dyc + oD, RD * 2);
+    if (p.dyc_make) {
+      // first backward kernel of a chain: dy exists in fp32 only.  The fragments are rounded from it (as sitk_cast_rows would)
+      // and the wave of each pair that carries hh == 0 writes the copy; the other's descriptor has no records, so that both
+      // issue the same memory operations.
+      const __amdgpu_buffer_rsrc_t r_dyf = make_rsrc(p.dy + oD, RD * 4);
+      const __amdgpu_buffer_rsrc_t r_mk = make_rsrc(p.dyc_make + oD, hh == 0 ? RD * 2 : 0);
 #pragma unroll
-    for (int t = 0; t < TT; ++t)
+      for (int t = 0; t < TT; ++t)
 #pragma unroll
-      for (int k = 0; k < 6; ++k)
-        hf[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_dyc, ((16 * TT * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
+        for (int k = 0; k < 6; ++k) {
+          const int e = (16 * TT * tg + 16 * t + fr) * D + k * 32 + fq * 8;
+          const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dyf, e * 4, 0, 0));
+          const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_dyf, e * 4 + 16, 0, 0));
+          hf[t][k] = u32x4{pack_h16(lo[0], lo[1]), pack_h16(lo[2], lo[3]), pack_h16(hi[0], hi[1]), pack_h16(hi[2], hi[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(hf[t][k], r_mk, e * 2, 0, 0);
+        }
+    } else {
+      const __amdgpu_buffer_rsrc_t r_dyc = make_rsrc(p.dyc + oD, RD * 2);
+#pragma unroll
+      for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          hf[t][k] = __builtin_amdgcn_raw_buffer_load_b128(r_dyc, ((16 * TT * tg + 16 * t + fr) * D + k * 32 + fq * 8) * 2, 0, 0);
+    }
   }
 
   if constexpr (VAR == 6) { if (blockIdx.x == 80 && lane == 0) g_mlp_stamps[128 + wave * 8 + 4] = __builtin_amdgcn_s_memtime() - t_kernel0; }
@@ -893,13 +912,10 @@ extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) {
   return rows > 0 ? (size_t)cdiv64(rows, fused_block_rows(rows)) * 2 * MLP_D : 0;
 }
 
-SITK_F16_TWIN(sitk_mlp_bwd)
-extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
-                            const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du,
-                            float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
-                            sitk_stream_t stream) {
-  SITK_FORWARD_F16(dtype, sitk_mlp_bwd, dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, du, dx, dx_c, partials, rows, D, M, dtype, stream);
-  SITK_REQUIRE(dy && dy_c && x && mean && rstd && ln_w && w2t_c && w1t_c && gd && du && dx && dx_c && partials,
+static int mlp_bwd_launch(const float* dy, const void* dy_c, void* dy_c_make, const float* x, const float* mean, const float* rstd,
+                          const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du, float* dx,
+                          void* dx_c, float* partials, int64_t rows, int D, int M, int dtype, sitk_stream_t stream) {
+  SITK_REQUIRE(dy && (dy_c || dy_c_make) && x && mean && rstd && ln_w && w2t_c && w1t_c && gd && du && dx && dx_c && partials,
                "mlp_bwd: null pointer");
   SITK_TRY(mlp_check("mlp_bwd", rows, D, M, dtype));
   MlpParams p = {};
@@ -907,6 +923,7 @@ extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, c
   p.wa = reinterpret_cast<const h16*>(w2t_c); p.wb = reinterpret_cast<const h16*>(w1t_c);
   p.u = const_cast<h16*>(reinterpret_cast<const h16*>(gd));
   p.du = reinterpret_cast<h16*>(du); p.dy = dy; p.dyc = reinterpret_cast<const h16*>(dy_c);
+  p.dyc_make = reinterpret_cast<h16*>(dy_c_make);
   p.out = dx; p.outc = reinterpret_cast<h16*>(dx_c); p.partials = partials;
   p.R = (int)rows; p.M = M;
   static const int var = sitk_ab_switch("SITK_MLP_VAR", 0);
@@ -920,6 +937,29 @@ extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, c
   else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<true, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL((mlp_kernel<true, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_bwd");
+}
+
+SITK_F16_TWIN(sitk_mlp_bwd)
+extern "C" int sitk_mlp_bwd(const float* dy, const void* dy_c, const float* x, const float* mean, const float* rstd,
+                            const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du,
+                            float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
+                            sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_mlp_bwd, dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, du, dx, dx_c, partials, rows, D, M, dtype, stream);
+  SITK_REQUIRE(dy_c, "mlp_bwd: null pointer");
+  return mlp_bwd_launch(dy, dy_c, nullptr, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, du, dx, dx_c, partials, rows, D, M, dtype, stream);
+}
+
+// sitk_mlp_bwd for the FIRST backward kernel of a chain, where dy exists in fp32 only: the kernel rounds its operand fragments
+// from dy and writes the compute-dtype copy to dy_c (an OUTPUT here; the weight gradient of net.3 reads it) -- sitk_cast_rows +
+// sitk_mlp_bwd in one launch, same bits.
+SITK_F16_TWIN(sitk_mlp_bwd_cast)
+extern "C" int sitk_mlp_bwd_cast(const float* dy, void* dy_c, const float* x, const float* mean, const float* rstd,
+                                 const float* ln_w, const void* w2t_c, const void* w1t_c, const void* gd, void* du,
+                                 float* dx, void* dx_c, float* partials, int64_t rows, int D, int M, int dtype,
+                                 sitk_stream_t stream) {
+  SITK_FORWARD_F16(dtype, sitk_mlp_bwd_cast, dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, du, dx, dx_c, partials, rows, D, M, dtype, stream);
+  SITK_REQUIRE(dy_c, "mlp_bwd_cast: null pointer");
+  return mlp_bwd_launch(dy, nullptr, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, du, dx, dx_c, partials, rows, D, M, dtype, stream);
 }
 
 SITK_F16_TWIN(sitk_ln_gemm_mlp_bwd_supported)

@@ -78,7 +78,7 @@ class FlatParams:
         return all(p.data.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[id(p)][0] for p in self.params)
 
 
-def grad_write_stages(model, task, slices):
+def grad_write_stages(model, task, slices, head_deferred=False):
     """Backward stage after which each parameter's gradient is FINAL, keyed by id(parameter).
 
     Stage i < len(slices): backward slice i (slices run last layer first; segment 0 also holds forward, loss and the
@@ -86,7 +86,8 @@ def grad_write_stages(model, task, slices):
     from flat-buffer offsets:
       * layers lb..le-1 of slice i: weight / bias / LayerNorm gradients of those layers (the slice's one weight-gradient
         launch and its LayerNorm reduction close the slice);
-      * mlp_head.*: the fused head + loss kernel of segment 0 (regression); untouched (zero) under MPP;
+      * mlp_head.*: the fused head + loss kernel of segment 0 (regression) -- or, with a side stream (head_deferred), the
+        reduction of its per-sample terms in `_finish_backward`; untouched (zero) under MPP;
       * to_original.* (models/mpp.py:66-67,129): its weight gradient joins the weight-gradient launch of the slice that
         ends at layer 0 or runs in `_finish_backward` -> final only after finish, like the embedding, cls_token,
         pos_embedding and mask_token gradients."""
@@ -98,7 +99,7 @@ def grad_write_stages(model, task, slices):
             for p in layer.parameters():
                 stage[id(p)] = i
     for p in sit.mlp_head.parameters():
-        stage[id(p)] = 0
+        stage[id(p)] = finish if head_deferred else 0
     assert n >= 1
     return stage
 
@@ -136,6 +137,8 @@ class TrainEngine:
 
     wgrad_overlap: number of layers whose weight gradients run on a side stream BESIDE the rest of the backward chain, on
                   the CUs its one-wave kernels leave idle (sitk_encoder_bwd_overlap); 0 = off.  Needs eager launches.
+    head_deferred: with a side stream, the sum of the head's per-sample gradient terms and of the loss runs THERE beside the
+                  chain's tail (sitk_head_loss_fwd_bwd_deferred + sitk_head_finalize); False = behind the head kernel on the main stream.
     prefetch_gather: with a side stream, enqueue the patch gather of a regression step there (it then runs beside the previous
                   step's tail); False = in front of the patch embedding on the main stream.  Inputs must then reach the
                   engine through load_batch() / step(x, ...) / step(indices=...), which order that gather behind their copy
@@ -159,7 +162,7 @@ class TrainEngine:
     def __init__(self, model, batch_size, *, task="regression", input_layout="surface", loss="mse", optimizer="sgd",
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
-                 wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None):
+                 wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -314,6 +317,7 @@ class TrainEngine:
         # workgroups of one side launch (two layers): 42 = the CUs the dim-192 chain's one-wave kernels leave idle
         self.wgrad_overlap_cus = int(wgrad_overlap_cus) if wgrad_overlap_cus else 42
         self._overlap = rt.lib.sitk_overlap_create(max_side, self.wgrad_overlap_cus, 1) if wgrad_overlap > 0 else None
+        self._head_deferred = bool(self._overlap) and bool(head_deferred) and task == "regression"
         self._side = rt.lib.sitk_overlap_stream(self._overlap) if self._overlap else None
         self._side_torch = torch.cuda.ExternalStream(self._side, device=self.device) if self._overlap else None
         # With a side stream the patch gather of a regression step -- which reads the input batch and the patch table, no
@@ -335,7 +339,8 @@ class TrainEngine:
             self._ar_stream = torch.cuda.Stream(device=self.device)
         if use_graph is None:
             use_graph = not self._overlap
-        self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices), len(self.slices))
+        self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices, head_deferred=self._head_deferred),
+                                           len(self.slices))
         self.use_graph = use_graph
         self._graphs = None
         self._pending = []
@@ -388,6 +393,15 @@ class TrainEngine:
         self._encoder_forward(save)
         ln, fc = sit.mlp_head[0], sit.mlp_head[1]
         g = self.fp.g
+        if self._head_deferred:
+            # With a side stream the sum of the head's per-sample gradient terms (and of the loss) leaves the chain: backward
+            # waits for dx only; _embed_backward runs sitk_head_finalize on the side stream beside the chain's tail.
+            rt.check(L.sitk_head_loss_fwd_bwd_deferred(self.xL.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(),
+                                                       fc.weight.data_ptr(), fc.bias.data_ptr(), self.target.data_ptr(),
+                                                       self.logits.data_ptr(), self.dx.data_ptr(), B, N, D, self.ncls,
+                                                       self.pool_mean, int(self.loss_kind == "l1"), self.head_ws.data_ptr(),
+                                                       self.gscale.data_ptr() if self.loss_scaled else None, s))
+            return
         # pool + head + loss + their backward: one launch (dx = d(loss)/d(x_L) for every row comes out of it)
         rt.check(L.sitk_head_loss_fwd_bwd(self.xL.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), fc.weight.data_ptr(),
                                           fc.bias.data_ptr(), self.target.data_ptr(), self.logits.data_ptr(),
@@ -438,6 +452,11 @@ class TrainEngine:
         # sitk_encoder_bwd_overlap left behind the chain's last kernel) they run beside the tail weight-gradient launch.
         rt.check(rt.lib.sitk_colsum_f32_dup(self.dx.data_ptr(), B, N * D, N * D, gpos.data_ptr(),
                                             g(sit.cls_token).data_ptr(), D, self._side if self._overlap else self._s()))
+        if self._head_deferred and self.task == "regression":      # (see _forward_regression: the head's gradients and the loss)
+            ln, fc = sit.mlp_head[0], sit.mlp_head[1]
+            rt.check(rt.lib.sitk_head_finalize(self.head_ws.data_ptr(), B, D, self.ncls, g(ln.weight).data_ptr(),
+                                               g(ln.bias).data_ptr(), g(fc.weight).data_ptr(), g(fc.bias).data_ptr(),
+                                               self.loss_acc.data_ptr(), self._side))
         if self.task == "mpp":
             # d mask_token = (sum of dx over the replaced rows) W_embed: reads the chain's final dx like the sums above, so with a
             # side stream it runs there too, beside the tail weight-gradient launch (27 us at the end of the step otherwise)

@@ -248,8 +248,12 @@ def attn_out_mlp_next_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, n_ln
 
 
 def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, dtype):
-    """gd = the gelu'(u) saved by the fused forward.  Returns (dx, dx_c, du, partials (workgroups, 2, D))."""
+    """gd = the gelu'(u) saved by the fused forward.  Returns (dx, dx_c, du, partials (workgroups, 2, D)).
+    dy_c = None: the kernel rounds dy itself and also returns the compute-dtype copy it wrote (sitk_mlp_bwd_cast):
+    (dx, dx_c, du, partials, dy_c)."""
     rows, D = x.shape
+    if dy_c is None:
+        return _mlp_bwd_cast(dy, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, dtype)
     M = gd.shape[1]
     code = rt.dtype_code(dtype)
     du = torch.empty_like(gd)
@@ -261,6 +265,21 @@ def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, dtype):
                                  ln_w.data_ptr(), w2t_c.data_ptr(), w1t_c.data_ptr(), gd.data_ptr(), du.data_ptr(),
                                  dx.data_ptr(), dx_c.data_ptr(), partials.data_ptr(), rows, D, M, code, rt.stream_ptr()))
     return dx, dx_c, du, partials.view(-1, 2, D)
+
+
+def _mlp_bwd_cast(dy, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, dtype):
+    rows, D = x.shape
+    M = gd.shape[1]
+    du = torch.empty_like(gd)
+    dx = torch.empty_like(x)
+    dx_c = torch.empty((rows, D), dtype=gd.dtype, device=x.device)
+    dy_c = torch.empty((rows, D), dtype=gd.dtype, device=x.device)
+    partials = torch.empty(rt.lib.sitk_mlp_bwd_partial_floats(rows), dtype=torch.float32, device=x.device)
+    rt.check(rt.lib.sitk_mlp_bwd_cast(dy.data_ptr(), dy_c.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      ln_w.data_ptr(), w2t_c.data_ptr(), w1t_c.data_ptr(), gd.data_ptr(), du.data_ptr(),
+                                      dx.data_ptr(), dx_c.data_ptr(), partials.data_ptr(), rows, D, M, rt.dtype_code(dtype),
+                                      rt.stream_ptr()))
+    return dx, dx_c, du, partials.view(-1, 2, D), dy_c
 
 
 # ---- fused LayerNorm + to_qkv ----------------------------------------------------------------------
@@ -464,6 +483,23 @@ def head_loss_fwd_bwd(x, ln_w, ln_b, w, b, target, loss, dx, d_ln_w, d_ln_b, d_w
                                            d_ln_w.data_ptr(), d_ln_b.data_ptr(), d_w.data_ptr(), d_b.data_ptr(), B, N, D, ncls,
                                            int(pool_mean), int(l1), rt.ptr(ws), rt.ptr(grad_scale), rt.stream_ptr()))
     return logits
+
+
+def head_loss_fwd_bwd_deferred(x, ln_w, ln_b, w, b, target, dx, B, N, D, pool_mean, l1=False, grad_scale=None):
+    """head_loss_fwd_bwd without the sum of the per-sample gradient terms: returns (logits, ws); head_finalize(ws, ...) adds
+    them (and the loss) later, on any stream ordered behind this call."""
+    ncls = w.shape[0]
+    logits = torch.empty((B, ncls), dtype=torch.float32, device=x.device)
+    ws = torch.empty(rt.lib.sitk_head_ws_floats(B, D, ncls), dtype=torch.float32, device=x.device)
+    rt.check(rt.lib.sitk_head_loss_fwd_bwd_deferred(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w.data_ptr(), b.data_ptr(),
+                                                    target.data_ptr(), logits.data_ptr(), dx.data_ptr(), B, N, D, ncls,
+                                                    int(pool_mean), int(l1), ws.data_ptr(), rt.ptr(grad_scale), rt.stream_ptr()))
+    return logits, ws
+
+
+def head_finalize(ws, B, D, ncls, d_ln_w, d_ln_b, d_w, d_b, loss):
+    rt.check(rt.lib.sitk_head_finalize(ws.data_ptr(), B, D, ncls, d_ln_w.data_ptr(), d_ln_b.data_ptr(), d_w.data_ptr(),
+                                       d_b.data_ptr(), loss.data_ptr(), rt.stream_ptr()))
 
 
 def loss_fwd_bwd(pred, target, loss, dpred, l1=False):

@@ -86,6 +86,7 @@ _SIGS = {
     "sitk_attn_out_mlp_next_fwd": (C.c_int, [_P] * 24 + [_I, _L, _I, _I, _I, _I, _P]),
     "sitk_mlp_bwd_partial_floats": (_Z, [_L]),
     "sitk_mlp_bwd": (C.c_int, [_P] * 13 + [_L, _I, _I, _I, _P]),
+    "sitk_mlp_bwd_cast": (C.c_int, [_P] * 13 + [_L, _I, _I, _I, _P]),
     "sitk_ln_gemm_mlp_bwd_supported": (C.c_int, [_L, _I, _I, _I, _I]),
     "sitk_ln_gemm_mlp_bwd": (C.c_int, [_P] * 10 + [_I] + [_P] * 11 + [_L, _I, _I, _I, _P]),
     "sitk_ln_gemm_fused_supported": (C.c_int, [_I, _I, _I]),
@@ -122,6 +123,8 @@ _SIGS = {
     "sitk_head_ws_floats": (_Z, [_I, _I, _I]),
     "sitk_head_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "sitk_head_loss_fwd_bwd": (C.c_int, [_P] * 13 + [_I] * 6 + [_P, _P, _P]),
+    "sitk_head_loss_fwd_bwd_deferred": (C.c_int, [_P] * 8 + [_I] * 6 + [_P, _P, _P]),
+    "sitk_head_finalize": (C.c_int, [_P, _I, _I, _I] + [_P] * 6),
     "sitk_loss_fwd_bwd": (C.c_int, [_P, _P, _P, _P, _I, _I, _P]),
     "sitk_colsum_f32": (C.c_int, [_P, _L, _I, _I, _P, _P]),
     "sitk_colsum_f32_dup": (C.c_int, [_P, _L, _I, _I, _P, _P, _I, _P]),

@@ -38,7 +38,7 @@ def _mpp_module(depth):
                                         channels=4, num_vertices=561)
 
 
-def _writer_stage(name, slices, task):
+def _writer_stage(name, slices, task, head_deferred=False):
     """The spec, restated from the step's launch order (not from sitk.engine's code): index of the segment whose
     kernels write this parameter's gradient LAST; len(slices) = the finish stage."""
     finish = len(slices)
@@ -47,15 +47,18 @@ def _writer_stage(name, slices, task):
         layer = int(name.split(".")[2])
         return next(i for i, (lb, le) in enumerate(slices) if lb <= layer < le)
     if name.startswith("mlp_head."):
-        return 0                       # fused head + loss kernel, segment 0 (never written under MPP: zero)
+        # fused head + loss kernel, segment 0 (never written under MPP: zero); with a side stream the sum of its per-sample
+        # terms runs in the finish stage (sitk_head_loss_fwd_bwd_deferred + sitk_head_finalize)
+        return finish if head_deferred else 0
     # to_original.* (weight-gradient launch of the slice ending at layer 0, or finish), mask_token, cls_token,
     # pos_embedding, to_patch_embedding.1.*: all behind the last backward slice
     return finish
 
 
+@pytest.mark.parametrize("head_deferred", [False, True])
 @pytest.mark.parametrize("task", ["regression", "mpp"])
 @pytest.mark.parametrize("nsl", [1, 2, 3, 4, 12])
-def test_bucket_plan_reduces_every_gradient_once_and_only_after_it_is_written(task, nsl):
+def test_bucket_plan_reduces_every_gradient_once_and_only_after_it_is_written(task, nsl, head_deferred):
     """`to_original.*` sits BEHIND mlp_head in the flat buffer, so an offset-derived "everything from
     the first finished layer to the end of the buffer" range all-reduced it right after slice 0 -- two slices before
     the kernel that writes it.  The plan is derived from where each gradient is written instead; this walks
@@ -69,7 +72,7 @@ def test_bucket_plan_reduces_every_gradient_once_and_only_after_it_is_written(ta
     fp = _cpu_flat_params(module)
     bounds = [round(i * depth / nsl) for i in range(nsl + 1)]
     slices = [(bounds[i], bounds[i + 1]) for i in range(nsl)][::-1]
-    plan = engine.grad_bucket_plan(fp, engine.grad_write_stages(module, task, slices), nsl)
+    plan = engine.grad_bucket_plan(fp, engine.grad_write_stages(module, task, slices, head_deferred=head_deferred), nsl)
     assert len(plan) == nsl
     flat_ranges = sorted(r for point in plan for r in point)
     assert flat_ranges[0][0] == 0 and flat_ranges[-1][1] == fp.total
@@ -79,7 +82,7 @@ def test_bucket_plan_reduces_every_gradient_once_and_only_after_it_is_written(ta
         point = next(i for i, rs in enumerate(plan) if any(a <= lo and lo + n <= b for a, b in rs))
         # point i < nsl - 1 is issued right after segment i; point nsl - 1 after the finish stage
         issued_after = point if point < nsl - 1 else nsl
-        assert issued_after >= _writer_stage(name, slices, task), (name, point, slices)           # (b)
+        assert issued_after >= _writer_stage(name, slices, task, head_deferred), (name, point, slices)           # (b)
     if task == "mpp" and nsl > 1:
         lo, _ = fp.offsets[id(ssl.to_original.weight)]
         assert not any(a <= lo < b for a, b in plan[0]), "to_original reduced with slice 0 again"

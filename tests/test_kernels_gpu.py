@@ -537,6 +537,32 @@ def test_head_loss_fused_matches_autograd(ops, pool_mean, ncls, l1):
         assert rel(g, r.grad) < 1e-5
 
 
+@pytest.mark.parametrize("pool_mean,ncls,scaled", [(False, 1, False), (True, 3, False), (False, 1, True)])
+def test_head_loss_deferred_plus_finalize_is_bitwise_the_one_call_form(ops, pool_mean, ncls, scaled):
+    """sitk_head_loss_fwd_bwd_deferred + sitk_head_finalize (the engine runs the second on its side stream) = the one-call
+    form, bit for bit: dx, logits, the head's gradients (added to what the buffers hold) and the loss."""
+    B, N, D = 64, 321, 192
+    x = rnd("hd/x", (B * N, D))
+    lw, lb = 1 + 0.1 * rnd("hd/lw", (D,)), 0.1 * rnd("hd/lb", (D,))
+    w, b = rnd("hd/w", (ncls, D), 0.1), rnd("hd/b", (ncls,), 0.1)
+    tgt = rnd("hd/t", (B, ncls))
+    outs = []
+    for deferred in (False, True):
+        loss = torch.full((1,), 0.25, device=DEV)
+        dx = torch.full((B * N, D), 7.0, device=DEV)
+        grads = [torch.full_like(t, 0.5) for t in (lw, lb, w, b)]
+        gs = torch.zeros(2, device=DEV) if scaled else None
+        if deferred:
+            logits, ws = ops.head_loss_fwd_bwd_deferred(x, lw, lb, w, b, tgt, dx, B, N, D, pool_mean, grad_scale=gs)
+            assert all(bool((g == 0.5).all()) for g in grads) and float(loss) == 0.25      # nothing summed yet
+            ops.head_finalize(ws, B, D, ncls, *grads, loss)
+        else:
+            logits = ops.head_loss_fwd_bwd(x, lw, lb, w, b, tgt, loss, dx, *grads, B, N, D, pool_mean, grad_scale=gs)
+        outs.append([logits, loss, dx, *grads] + ([gs] if scaled else []))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+
+
 @pytest.mark.parametrize("l1", [0, 1])
 def test_loss(ops, l1):
     p, t = rnd("ls/p", (64,)), rnd("ls/t", (64,))

@@ -296,3 +296,23 @@ def test_ln_gemm_mlp_bwd_pair_launch_is_bitwise_the_two_launches(ops, rows):
         torch.cuda.synchronize()
         for a, b in zip(got, (dx, dx_c, p1, dxm, dxm_c, du, p2)):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("rows", [96, 1000, 20544, 30000])
+def test_mlp_bwd_that_rounds_dy_itself_is_bitwise_cast_plus_mlp_bwd(ops, rows):
+    """sitk_mlp_bwd_cast (the first backward launch of a chain: dy exists in fp32 only) = sitk_cast_rows + sitk_mlp_bwd, bit for
+    bit, and the compute-dtype copy it writes for the weight gradients is the cast's."""
+    M = 768
+    xmid = rnd("bc/xm", (rows, D), 1.5)
+    dy = rnd("bc/dy", (rows, D), 1.0)
+    ln_w, ln_b, w1, b1, w2, b2 = params("bc", M)
+    w1c, w2c = w1.to(_H.td), w2.to(_H.td)
+    w1t, w2t = w1c.T.contiguous(), w2c.T.contiguous()
+    _, _, mean2, rstd2, gd, _ = ops.mlp_fwd(xmid, ln_w, ln_b, w1c, b1, w2c, b2, _H.name)
+    dy_c = ops.cast_rows(dy, _H.name)
+    want = ops.mlp_bwd(dy, dy_c, xmid, mean2, rstd2, ln_w, w2t, w1t, gd, _H.name)
+    got = ops.mlp_bwd(dy, None, xmid, mean2, rstd2, ln_w, w2t, w1t, gd, _H.name)
+    torch.cuda.synchronize()
+    for a, b in zip(got[:4], want):
+        assert torch.equal(a, b)
+    assert torch.equal(got[4], dy_c)
