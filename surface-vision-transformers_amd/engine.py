@@ -437,7 +437,10 @@ class TrainEngine:
         pos = sit.pos_embedding.data.view(-1, D)
         ops.gemm_nt(tokens, self.w_embed, self.x0, dt, M=B * P, N=D, K=ld, epilogue=ops.EPI_BIAS_RES, bias=lin.bias.data,
                     aux=pos, omap=(P, N, 1), auxmap=(P, 0, 1))
-        rt.check(L.sitk_embed_cls_rows(self.x0.data_ptr(), sit.cls_token.data_ptr(), pos.data_ptr(), B, N, D, s))
+        # the cls rows of x0 depend on no product: with a side stream (forked in _stage_beside, joined in _encoder_forward) they
+        # are written there, beside the patch embedding
+        rt.check(L.sitk_embed_cls_rows(self.x0.data_ptr(), sit.cls_token.data_ptr(), pos.data_ptr(), B, N, D,
+                                       self._side if self._overlap else s))
 
     def _embed_backward(self, tokens):
         sit = self.sit
