@@ -1,5 +1,5 @@
 """Robustness check of the two-stream step: many steps on a NEW batch each (resident data set, host indices), prefetched gather
-against the in-line one -- losses and parameters must stay bit-equal; then a long run of the bench configuration.
+against the in-line one, the head's gradient sums on the side stream against the main one -- losses and parameters must stay bit-equal; then a long run of the bench configuration.
 
     python tools/stress_two_stream.py [--steps 300]
 """
@@ -30,17 +30,19 @@ def main():
     ys = torch.randn((S, 1), device=dev, generator=g) + 40
     picks = [torch.randperm(S, generator=torch.Generator().manual_seed(i))[:B].numpy() for i in range(a.steps)]
     out = []
-    for prefetch in (True, False):
-        eng = engine.TrainEngine(copy.deepcopy(base), B, input_layout="surface", lr=1e-4, momentum=0.9, prefetch_gather=prefetch)
+    for prefetch, deferred in ((True, True), (False, True), (True, False)):
+        eng = engine.TrainEngine(copy.deepcopy(base), B, input_layout="surface", lr=1e-4, momentum=0.9, prefetch_gather=prefetch,
+                                 head_deferred=deferred)
         eng.load_dataset(xs, ys)
         losses = []
         t0 = time.time()
         for idx in picks:
             losses.append(eng.step(indices=idx).clone())
         torch.cuda.synchronize()
-        print(f"prefetch {prefetch}: {a.steps} steps in {time.time() - t0:.2f} s, last loss {float(losses[-1]):.6f}", flush=True)
+        print(f"prefetch {prefetch}, head sums on the side stream {deferred}: {a.steps} steps in {time.time() - t0:.2f} s, last loss {float(losses[-1]):.6f}", flush=True)
         out.append((torch.cat(losses), eng.fp.flat.clone()))
-    same_l, same_p = torch.equal(out[0][0], out[1][0]), torch.equal(out[0][1], out[1][1])
+    same_l = all(torch.equal(out[0][0], o[0]) for o in out[1:])
+    same_p = all(torch.equal(out[0][1], o[1]) for o in out[1:])
     print("losses bit-equal:", same_l, " parameters bit-equal:", same_p)
     assert same_l and same_p
     eng = engine.TrainEngine(copy.deepcopy(base), B, input_layout="surface", lr=1e-5, momentum=0.9)
