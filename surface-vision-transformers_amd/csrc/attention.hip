@@ -619,13 +619,25 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const h16* __r
 // c = 32 (ct >> 1) + 8 (m >> 2) + 4 (ct & 1) + (m & 3): the accumulators of blocks 2 ks and 2 ks + 1 then ARE the
 // lane's 16-byte fragment ks of its dO row (columns 32 ks + 8 fq .. + 8) -- no shuffle -- and go to `d_o_out` for the
 // key-side kernel in the same form.
+#ifdef SITK_AB
+// diagnostic build: s_memtime stamps of the merged backward kernel's first workgroups (tools/res_stamps.py)
+constexpr int RES_STAMP_WGS = 4, RES_STAMP_N = 12;
+__device__ unsigned long long g_res_stamps[RES_STAMP_WGS][16][RES_STAMP_N];
+#define RES_ST_PARAM , unsigned long long* st
+#define RES_ST_ARG , st
+#define RES_STAMP(i) do { if (st) st[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RES_ST_PARAM
+#define RES_ST_ARG
+#define RES_STAMP(i) do {} while (0)
+#endif
 constexpr int FOLD_D = 192, FOLD_KS = FOLD_D / 32;
 constexpr int RES_DQ_SMEM = 2 * (RES_MAX_N / 64) * 8192, RES_DQ_SMEM_FOLD = RES_DQ_SMEM + 64 * FOLD_D * 2;
 template <int WAVES, bool FOLD>
 SITK_DEV void attn_bwd_dq_res_body(char* smem, int bid, const h16* __restrict__ qkv, const h16* __restrict__ o,
                                    const h16* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta,
                                    h16* __restrict__ dqkv, int N, int H, float scale, const h16* __restrict__ dxmid,
-                                   const h16* __restrict__ wo_t, h16* __restrict__ d_o_out) {
+                                   const h16* __restrict__ wo_t, h16* __restrict__ d_o_out RES_ST_PARAM) {
   using T = h16;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -645,8 +657,10 @@ SITK_DEV void attn_bwd_dq_res_body(char* smem, int bid, const h16* __restrict__ 
                                        (__attribute__((address_space(3))) void*)(sW + pc * 1024), 16, 0, 0);
     }
   }
+  RES_STAMP(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  RES_STAMP(2);
   const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_h16(lane);
   // FOLD: A-fragment offsets of blocks ct = 0 / 1 (+ 2048 for ct = 2 / 3, + 4096 per k-step): row c(ct, m), chunk fq
@@ -737,6 +751,7 @@ SITK_DEV void attn_bwd_dq_res_body(char* smem, int bid, const h16* __restrict__ 
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt + 4 * fq, dq[dt] * scale);
     }
+    RES_STAMP(qt < WAVES ? 3 : 4);
   }
 }
 
@@ -750,14 +765,17 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const h16* 
   __shared__ __attribute__((aligned(256))) char smem[FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM];
   // FOLD: the H workgroups of one sample all read that sample's dxmid rows -- keep them on one XCD (one L2)
   const int bid = FOLD ? xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  attn_bwd_dq_res_body<WAVES, FOLD>(smem, bid, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out);
+#ifdef SITK_AB
+  unsigned long long* st = nullptr;
+#endif
+  attn_bwd_dq_res_body<WAVES, FOLD>(smem, bid, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out RES_ST_ARG);
 }
 
 constexpr int RES_DKV_SMEM = 2 * (RES_MAX_N / 64) * 8192 + 2 * RES_MAX_N * 4;
 template <int WAVES>
 SITK_DEV void attn_bwd_dkv_res_body(char* smem, int bid, const h16* __restrict__ qkv, const h16* __restrict__ d_o,
                                     const float* __restrict__ lse, const float* __restrict__ delta, h16* __restrict__ dqkv,
-                                    int N, int H, float scale) {
+                                    int N, int H, float scale RES_ST_PARAM) {
   using T = h16;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -776,8 +794,10 @@ SITK_DEV void attn_bwd_dkv_res_body(char* smem, int bid, const h16* __restrict__
     sL[r] = r < N ? -lse[ridx] * kLog2e : -INFINITY;   // negated (added below); exp2(x - inf) = 0 for padded query rows
     sD[r] = r < N ? -delta[ridx] : 0.f;
   }
+  RES_STAMP(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  RES_STAMP(7);
   const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_h16(lane);
   for (int kt = wave; kt * 16 < N; kt += WAVES) {
@@ -825,6 +845,7 @@ SITK_DEV void attn_bwd_dkv_res_body(char* smem, int bid, const h16* __restrict__
         store4(row + 2 * I + 16 * dt + 4 * fq, dv[dt]);
       }
     }
+    RES_STAMP(kt < WAVES ? 8 : 9);
   }
 }
 
@@ -833,7 +854,10 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const h16*
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                h16* __restrict__ dqkv, int N, int H, float scale) {
   __shared__ __attribute__((aligned(256))) char smem[RES_DKV_SMEM];
-  attn_bwd_dkv_res_body<WAVES>(smem, (int)blockIdx.x, qkv, d_o, lse, delta, dqkv, N, H, scale);
+#ifdef SITK_AB
+  unsigned long long* st = nullptr;
+#endif
+  attn_bwd_dkv_res_body<WAVES>(smem, (int)blockIdx.x, qkv, d_o, lse, delta, dqkv, N, H, scale RES_ST_ARG);
 }
 
 // The two sides in ONE launch (round 4): a workgroup owns its (sample, head) through both -- the query side first (dQ, delta,
@@ -850,11 +874,23 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(const h16* __restric
   constexpr int SMEM = (FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM) > RES_DKV_SMEM ? (FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM) : RES_DKV_SMEM;
   __shared__ __attribute__((aligned(256))) char smem[SMEM];
   const int bid = xcd_remap(blockIdx.x, gridDim.x);      // the H workgroups of a sample on one XCD (they share its dxmid rows)
-  attn_bwd_dq_res_body<16, FOLD>(smem, bid, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out);
+#ifdef SITK_AB
+  unsigned long long stamps[RES_STAMP_N] = {}, *st = stamps;
+  st[0] = __builtin_amdgcn_s_memtime();
+#endif
+  attn_bwd_dq_res_body<16, FOLD>(smem, bid, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out RES_ST_ARG);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's dO / delta stores have left the CU ...
   __syncthreads();                                       // ... and nobody reads the K / V image any more
-  attn_bwd_dkv_res_body<16>(smem, bid, qkv, FOLD ? d_o_out : d_o, lse, delta, dqkv, N, H, scale);
+  RES_STAMP(5);
+  attn_bwd_dkv_res_body<16>(smem, bid, qkv, FOLD ? d_o_out : d_o, lse, delta, dqkv, N, H, scale RES_ST_ARG);
+#ifdef SITK_AB
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st[10] = __builtin_amdgcn_s_memtime();
+  if (blockIdx.x >= gridDim.x / 2 && blockIdx.x < gridDim.x / 2 + RES_STAMP_WGS && (threadIdx.x & 63) == 0)
+    for (int i = 0; i < RES_STAMP_N; ++i) g_res_stamps[blockIdx.x - gridDim.x / 2][threadIdx.x >> 6][i] = stamps[i];
+#endif
 }
+
 
 #ifdef SITK_AB
 // ------------------------------------------------------------------------------------------
@@ -2234,6 +2270,11 @@ extern "C" int sitk_attention_bwd_phases(const void* qkv, const void* o, const v
 }
 
 #if defined(SITK_AB) && !defined(SITK_TU_F16)
+// diagnostic build: the s_memtime stamps of the merged sequence-resident backward kernel ([workgroup][wave][12])
+extern "C" int sitk_debug_res_stamps(void* out, size_t bytes) {
+  if (bytes != sizeof(sitk::g_res_stamps)) return (int)sizeof(sitk::g_res_stamps);
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sitk::g_res_stamps), bytes) == hipSuccess ? 0 : -1;
+}
 // diagnostic build: copies the s_memtime stamps of the unit-packed kernels' first workgroups to the host
 extern "C" int sitk_debug_pk_stamps(void* out, size_t bytes) {
   if (bytes != sizeof(sitk::g_pk_stamps)) return (int)sizeof(sitk::g_pk_stamps);
