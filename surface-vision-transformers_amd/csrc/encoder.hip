@@ -557,9 +557,10 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
         wgrad_desc(R, 3 * I, D, dqkv, 0, a.h1, G[l].wqkv, nullptr),
     };
     if (S.wg_batch && n_side < side_max) {
-      // This layer's weight gradients run beside the rest of the chain, on the side stream.  Two layers per launch: their 42
-      // tiles, each over ALL tokens, are one workgroup per idle CU -- no token split, so no slab traffic and no reduction
-      // launch (one layer at a time would be 21 tiles split in two: measured 190 us per layer against ~150 this way).
+      // This layer's weight gradients run beside the rest of the chain, on the side stream.  Two layers per launch: their 20
+      // double tiles (256 x 192) in two token halves are 40 workgroups for the CUs the chain leaves idle, followed by a slab
+      // reduction of 12 - 30 us on the same stream (three or four layers per launch need no split but start later: measured
+      // 2.59 / 2.50 ms per step against 2.43, profiles/README.md round 3).
       wg_side.insert(wg_side.end(), wg, wg + 4);
       ++n_side;
       if ((int)wg_side.size() == 8 || n_side == side_max) {
