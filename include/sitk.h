@@ -40,7 +40,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 9
+#define SITK_ABI_VERSION 10
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -395,6 +395,18 @@ sitk_stream_t sitk_overlap_stream(sitk_overlap* o);
 int sitk_overlap_set_layers(sitk_overlap* o, int layers);
 int sitk_overlap_fork(sitk_overlap* o, sitk_stream_t stream);
 int sitk_overlap_join(sitk_overlap* o, sitk_stream_t stream);
+/* Data parallelism (ABI 10; the reference has none: tools/train.py:72 picks one device).  A call of sitk_encoder_bwd_overlap
+ * over layers [layer_begin, layer_end) with s = min(`layers`, layer_end - layer_begin) side layers makes ceil(s / 2) side
+ * launches: launch i carries the weight + bias gradients (to_qkv, to_out, net.0, net.3 -- NOT the LayerNorm parameters, which
+ * one reduction at the end of the call finishes) of layers layer_end - 1 - 2 i and layer_end - 2 - 2 i (the last launch holds
+ * one layer when s is odd).  Behind each launch and its slab reduction the call records an event on the side stream:
+ * sitk_overlap_side_launches = how many the last call made; sitk_overlap_wait_side_launch makes `stream` wait for launch i,
+ * behind which those layers' gradients are FINAL -- the caller all-reduces that bucket from `stream` while the chain goes on.
+ * sitk_overlap_set_tail_cus: the one weight-gradient launch behind the chain (the layers that did not go to the side stream)
+ * is sized for `cus` CUs instead of the chip's 256, so that the all-reduce channels still running beside it keep theirs. */
+int sitk_overlap_side_launches(const sitk_overlap* o);
+int sitk_overlap_wait_side_launch(sitk_overlap* o, int i, sitk_stream_t stream);
+int sitk_overlap_set_tail_cus(sitk_overlap* o, int cus);
 int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* params,
                              const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
                              size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,
@@ -525,9 +537,11 @@ int sitk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * grad + n and are cleared in 16-byte pieces: n % 4 == 0 is required (the engine pads every parameter to 64 floats).
  * inv_loss_scale (device pointer or NULL): the gradients are additionally multiplied by *inv_loss_scale, the 1 / S that
  * sitk_head_loss_fwd_bwd left behind (f16 mode), read on the device so that a captured graph follows it.
- * nonfinite (device int or NULL; ABI 9): a gradient that is not finite -- an f16 intermediate that overflowed behind the loss
- * scale -- never reaches the parameters or the optimizer state: its element (SGD: the 16-byte vector it sits in) is skipped,
- * zeroed like every consumed gradient, and counted in *nonfinite (atomic add; the caller polls it when it likes).       */
+ * nonfinite (device int or NULL; ABI 9, per element since ABI 10): NULL = the reference's behaviour (tools/train.py:291 has no
+ * guard: a non-finite gradient reaches the parameters).  Not NULL (the engine: loss-scaled f16 mode only): a gradient ELEMENT that
+ * is not finite -- an f16 intermediate that overflowed behind the loss scale -- never reaches the parameters or the optimizer
+ * state: it is skipped, zeroed like every consumed gradient, and counted in *nonfinite (atomic add; the caller polls it when it
+ * likes).  Adam's step count advances whether or not elements were skipped.                                              */
 int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state, float momentum,
                       float weight_decay, int nesterov, float grad_scale, int zero_grad, int64_t n_extra,
                       int64_t keep_idx, float* keep_dst, const float* inv_loss_scale, int* nonfinite,

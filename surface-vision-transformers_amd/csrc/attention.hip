@@ -893,664 +893,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(const h16* __restric
 
 
 #ifdef SITK_AB
-// ------------------------------------------------------------------------------------------
-// Unit-packed variants (h16, 320 < N <= 336: the 321-token configurations, every width) -- round 4.
-// DIAGNOSTIC BUILD ONLY (make AB=1, SITK_ATTN_PK=1): measured, correct (the whole attention test set passes on them) and
-// NOT faster than the sequence-resident kernels -- forward 15.6 against 15.5 us, query side 22.3 against 20.7, key side 24.4
-// against 26.2 (tools/attn_bench.py, B = 64), and inside the training step slower (38.7 / 27.9 us): their 256 workgroups
-// of 160 KB take every CU, so the weight-gradient workgroups of the side stream push a part of them into a second round.
-// Why (tools/pk_stamps.py, profiles/r04_attn_pk_stamps.txt): a two-head workgroup takes in 160 KB instead of 82 (the rows
-// of a head are fetched by two workgroups: 31 MB per launch instead of 16), every wave is held in its DMA issue until
-// most of that has landed (7.5 k cycles warm, 16 k from HBM), and the barriers the LDS plan needs between the phases keep
-// the vector-bound score phase (7.4 k cycles for four waves per SIMD) from overlapping the matrix-bound product phase
-// (5.5 k): 23 k cycles per workgroup for 4 units per SIMD.  Kept as the record of the experiment.
-// The sequence-resident kernels above give a workgroup to one (sample, head): its 21 query (key) tiles run on 16 waves
-// in two rounds, the second with 5 waves busy, the B x H = 192 workgroups of the benchmark shape leave 64 of the 256
-// CUs idle, and a workgroup computes nothing until all of its 82 KB have landed.  Here the unit of work is ONE
-// (head, 16-row tile) and a workgroup is 16 CONSECUTIVE units of one sample, one per wave: 3 heads x 21 tiles = 63
-// units = 4 workgroups per sample, 256 workgroups at B = 64, a single round with 63 of 64 wave slots busy.  A window
-// of 16 units spans at most two heads, so a workgroup keeps two head "slots" per operand.  Two operands of two heads
-// (4 x 42 KB) do not fit the CU's 160 KB, and a kernel that waits for both before it computes has its whole load
-// exposed; so every kernel works in PHASES over one operand at a time and keeps the whole score row of its tile in
-// registers between them (21 blocks of 16: 84 fp32 in the forward kernel, 44 registers of packed h16 pairs backward):
-//   forward : S (K) | exact softmax: one maximum per row, no running rescale | O = P V (V)
-//   dQ      : [dO = dxmid Wo (FOLD), delta] | P = exp2(c q k - lse) (K) | dS = P (dO v - delta), in place (V) | dQ = dS K (K)
-//   dK, dV  : P^T (Q) | dV += P^T dO, dS^T = P^T (v dO - delta), in place (dO) | dK = dS^T Q (Q)
-// LDS plan (all of the CU's 163 840 B, one workgroup per CU):
-//   R0 = 2 slots x 43 008 B : the FIRST operand (K / K / Q), 320 rows + one 16-row block per head
-//   R1 = 77 824 B           : the SECOND operand (V / V / dO): slot 0 whole | slot 1 tiles 0..2 | slot 1 tile 5 | 8 KB
-//                             (the 8 KB: per-query lse / delta rows of the key-side kernel; FOLD: R1 first holds Wo^T)
-//   slot 1's tiles 3 and 4 (16 KB, one DMA piece per wave) arrive LATE: forward -- into R0 once the scores are
-//   taken; backward -- over slot 0's tiles 0 and 1 once every wave is through the early tiles (two more barriers).
-// Both transfers are issued up front; the first phase starts when the FIRST operand has landed (counted vmcnt: every
-// wave issues the same number of pieces, the index clamped) and the second lands under it.  For that the first
-// phase's LDS reads are inline asm (hipcc drains the DMA queue in front of LDS reads it can see), barriers are bare
-// s_barrier (no fence: __syncthreads() waits for vmcnt(0)), and no vector-memory LOAD is issued behind the second
-// transfer before it is waited for anyway (vmcnt is one in-order counter).
-// dS is formed from the h16-ROUNDED probabilities (the sequence-resident kernels multiply the fp32 ones): one more
-// rounding of one factor, the price of a 336-key row in 44 registers.
-// The workgroups of a sample are consecutive logical ids (one XCD: its L2 serves the rows two of them share).
-// ------------------------------------------------------------------------------------------
-constexpr int PK_NQ = 21, PK_W = 16;                                   // 16-row blocks per head; waves = units per workgroup
-constexpr int PK_T64 = (PK_NQ + 3) / 4;                                // 64-row tiles per head, the last one partly filled
-constexpr int PK_LAST = PK_NQ - 4 * (PK_T64 - 1);                      // 16-row blocks of the last tile
-constexpr int PK_SLOT = (PK_T64 - 1) * 8192 + PK_LAST * 2048;          // one head's rows in LDS: 43 008 B
-constexpr int PK_NPC = 2 * PK_NQ;                                      // DMA pieces (8 rows x 128 B) per slot
-constexpr int PK_LDS = 163840;
-constexpr int PK_R1 = 2 * PK_SLOT, PK_R1_BYTES = PK_LDS - PK_R1;
-constexpr int PK_LATE0 = 3, PK_NLATE = 2;                              // slot 1's 64-row tiles 3 and 4 arrive late
-constexpr int PK_R1_S1 = PK_SLOT;                                      // slot 1, tiles 0 .. PK_LATE0 - 1
-constexpr int PK_R1_S1_LAST = PK_R1_S1 + PK_LATE0 * 8192;              // slot 1, last tile
-constexpr int PK_R1_STATS = PK_R1_S1_LAST + PK_LAST * 2048;            // [slot][lse, delta][PK_STAT_LD] floats
-constexpr int PK_STAT_LD = 384;
-static_assert(PK_LAST == 1 && PK_LATE0 + PK_NLATE == PK_T64 - 1 && PK_NLATE * 8 == PK_W, "late tiles: one piece per wave");
-static_assert(PK_R1_STATS + 4 * PK_STAT_LD * 4 <= PK_R1_BYTES, "R1 plan");
-static_assert(2 * 64 * 192 * 2 <= PK_R1_BYTES, "FOLD: two Wo^T slices in R1");
-static bool pk_supported(int N) { return N > 16 * (PK_NQ - 1) && N <= 16 * PK_NQ; }
-static int pk_wgs_per_sample(int H) { return (H * PK_NQ + PK_W - 1) / PK_W; }
-
-template <int NS>
-struct PkCount {                                                       // pieces per wave of the two transfers (NS = slots)
-  static constexpr int E1 = NS * PK_NPC, PPW1 = (E1 + PK_W - 1) / PK_W;                                   // 42 -> 3, 84 -> 6
-  static constexpr int E2 = PK_NPC + (NS - 1) * (PK_NPC - 8 * PK_NLATE), PPW2 = (E2 + PK_W - 1) / PK_W;   // 42 -> 3, 68 -> 5
-};
-
-template <int... Is, typename F>
-SITK_DEV void static_for_impl(std::integer_sequence<int, Is...>, F&& f) { (f(std::integral_constant<int, Is>{}), ...); }
-template <int N_, typename F>
-SITK_DEV void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N_>{}, f); }
-constexpr int PK_NP = (PK_NQ + 1) / 2;                                 // 32-row PAIRS of blocks per head; the last one holds one block
-static_assert(PK_NQ % 2 == 1, "the last pair is half filled");
-
-SITK_DEV void pk_barrier() { asm volatile("s_barrier" ::: "memory"); }
-template <int N_>
-SITK_DEV void pk_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
-// diagnostic build only (make AB=1): s_memtime stamps of the first workgroups' waves, read back by tools/pk_stamps.py
-#ifdef SITK_AB
-constexpr int PK_STAMP_WGS = 8, PK_STAMP_N = 12;
-__device__ unsigned long long g_pk_stamps[3][PK_STAMP_WGS][PK_W][PK_STAMP_N];
-#define PK_STAMP_DECL unsigned long long pk_st[PK_STAMP_N] = {}; const unsigned long long pk_rt0 = __builtin_amdgcn_s_memrealtime()
-#define PK_STAMP(idx) pk_st[idx] = __builtin_amdgcn_s_memtime()
-#define PK_STAMP_FLUSH(kern)                                                                                      \
-  do {                                                                                                            \
-    pk_st[PK_STAMP_N - 1] = __builtin_amdgcn_s_memrealtime() - pk_rt0;      /* 100 MHz ticks of the wave's lifetime */ \
-    if (blockIdx.x < PK_STAMP_WGS && (threadIdx.x & 63) == 0)                                                     \
-      for (int i_ = 0; i_ < PK_STAMP_N; ++i_) g_pk_stamps[kern][blockIdx.x][threadIdx.x >> 6][i_] = pk_st[i_];    \
-  } while (0)
-#else
-#define PK_STAMP_DECL do {} while (0)
-#define PK_STAMP(idx) do {} while (0)
-#define PK_STAMP_FLUSH(kern) do {} while (0)
+// (diagnostic build only: the unit-packed kernels of round 4 -- an experiment that measured no gain -- and their launch branches)
+#include "experimental/attn_pk.inc"
 #endif
-
-// Which units a workgroup owns: `c` = its index inside the sample; heads h0 (slot 0) and, when the window crosses a head
-// boundary, h0 + 1 (slot 1).  Waves beyond the sample's last unit repeat it (they move their DMA pieces, join every
-// barrier and store nothing).
-struct PkUnit {
-  int b, h0, nslots, h, slot, tile;
-  bool active;
-};
-SITK_DEV PkUnit pk_unit(int H, int wps, int wave) {
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int b = L / wps, c = L - b * wps, U = H * PK_NQ;
-  const int u0 = c * PK_W, ulast = min(u0 + PK_W - 1, U - 1), u = min(u0 + wave, U - 1);
-  PkUnit p;
-  p.b = b;
-  p.h0 = u0 / PK_NQ;
-  p.nslots = ulast / PK_NQ - p.h0 + 1;
-  p.h = u / PK_NQ;
-  p.slot = p.h - p.h0;
-  p.tile = u - p.h * PK_NQ;
-  p.active = u0 + wave < U;
-  return p;
-}
-// one DMA piece: rows 8 q .. 8 q + 7 (64 columns from `src`) -> dst in the swizzled tile image.  Rows >= nrows repeat the
-// last row (branch-free; finite values): every kernel below gives such rows the probability 0 exactly, by masking.
-SITK_DEV void pk_dma_piece(char* dst, const h16* __restrict__ src, size_t ld, int nrows, int q, int lane) {
-  const int row = q * 8 + (lane >> 3), r64 = row & 63;
-  const int chunk = (lane & 7) ^ (attn_res_key(r64) << 1);
-  const char* g = reinterpret_cast<const char*>(src + (size_t)min(row, nrows - 1) * ld + chunk * 8);
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-}
-// first operand: all rows of NS consecutive heads (first column src0) -> the slots of R0
-template <int NS>
-SITK_DEV void pk_dma_first(char* r0, const h16* __restrict__ src0, size_t ld, int nrows, int wave, int lane) {
-  using C = PkCount<NS>;
-#pragma unroll
-  for (int i = 0; i < C::PPW1; ++i) {
-    const int e = min(wave * C::PPW1 + i, C::E1 - 1), sl = e >= PK_NPC ? 1 : 0, q = e - sl * PK_NPC;
-    pk_dma_piece(r0 + sl * PK_SLOT + q * 1024, src0 + sl * 64, ld, nrows, q, lane);
-  }
-}
-// second operand, everything but slot 1's late tiles -> R1
-template <int NS>
-SITK_DEV void pk_dma_second(char* r1, const h16* __restrict__ src0, size_t ld, int nrows, int wave, int lane) {
-  using C = PkCount<NS>;
-#pragma unroll
-  for (int i = 0; i < C::PPW2; ++i) {
-    const int e = min(wave * C::PPW2 + i, C::E2 - 1), sl = e >= PK_NPC ? 1 : 0;
-    int q = e - sl * PK_NPC;
-    if (sl && q >= PK_LATE0 * 8) q += 8 * PK_NLATE;
-    const int off = sl == 0 ? q * 1024 : (q < PK_LATE0 * 8 ? PK_R1_S1 + q * 1024 : PK_R1_S1_LAST + (q - 8 * (PK_T64 - 1)) * 1024);
-    pk_dma_piece(r1 + off, src0 + sl * 64, ld, nrows, q, lane);
-  }
-}
-// slot 1's late tiles: one piece per wave -> late_base
-SITK_DEV void pk_dma_late(char* late_base, const h16* __restrict__ src0, size_t ld, int nrows, int wave, int lane) {
-  pk_dma_piece(late_base + wave * 1024, src0 + 64, ld, nrows, PK_LATE0 * 8 + wave, lane);
-}
-// second operand: address of pair p2 (rows 32 p2 ..) of slot sl (p2 is a compile-time constant where this is used)
-SITK_DEV const char* pk_pair2(const char* r1, const char* late_base, int sl, int p2) {
-  const int t = p2 >> 1, hb = (p2 & 1) * 4096;
-  if (sl == 0) return r1 + t * 8192 + hb;
-  if (t < PK_LATE0) return r1 + PK_R1_S1 + t * 8192 + hb;
-  if (t < PK_T64 - 1) return late_base + (t - PK_LATE0) * 8192 + hb;
-  return r1 + PK_R1_S1_LAST;
-}
-constexpr bool pk_pair_is_late(int p2) { return (p2 >> 1) >= PK_LATE0 && (p2 >> 1) < PK_T64 - 1; }
-
-// asm row-fragment reads (invisible to hipcc's DMA drain): the two (or one) 16-row blocks x 2 k-steps of a pair at byte OFF
-template <int OFF>
-SITK_DEV void pk_rows2(u32x4 (&f)[2][2], uint32_t a0, uint32_t a1) {
-  asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %5 offset:%6\n\t"
-               "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %5 offset:%7\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : "=&v"(f[0][0]), "=&v"(f[0][1]), "=&v"(f[1][0]), "=&v"(f[1][1])
-               : "v"(a0), "v"(a1), "n"(OFF), "n"(OFF + 2048)
-               : "memory");
-}
-template <int OFF>
-SITK_DEV void pk_rows1(u32x4 (&f)[2][2], uint32_t a0, uint32_t a1) {
-  asm volatile("ds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %3 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(f[0][0]), "=&v"(f[0][1])
-               : "v"(a0), "v"(a1), "n"(OFF)
-               : "memory");
-}
-// s[i] += rows of pair p2 of the slot at (a0, a1) (asm reads) . frag; the last pair holds one block
-template <int p2>
-SITK_DEV void pk_row_mma_asm(f32x4 (&s)[2], uint32_t a0, uint32_t a1, const u32x4 (&frag)[2]) {
-  constexpr int NB = p2 == PK_NP - 1 ? 1 : 2;
-  u32x4 f[2][2];
-  if constexpr (NB == 2) pk_rows2<p2 * 4096>(f, a0, a1);
-  else pk_rows1<p2 * 4096>(f, a0, a1);
-#pragma unroll
-  for (int i = 0; i < NB; ++i)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) s[i] = Mma<h16>::mma(f[i][ks], frag[ks], s[i]);
-}
-// the same with compiler-visible reads (phases in which no transfer is in flight)
-template <bool HALF>
-SITK_DEV void pk_row_mma(f32x4 (&s)[2], const char* pair, const u32x4 (&frag)[2], const LaneOffs& o) {
-#pragma unroll
-  for (int i = 0; i < (HALF ? 1 : 2); ++i)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      s[i] = Mma<h16>::mma(*reinterpret_cast<const u32x4*>(pair + o.row[ks] + i * 2048), frag[ks], s[i]);
-}
-// acc[dt] += pair^T x pf (pf = the packed probabilities of the pair's 32 rows).  HALF: the pair holds ONE block and NO rows
-// behind it are read (the last pair of a slot is stored as one block): the upper half of the A operand is zero.
-template <bool HALF, bool SUM>
-SITK_DEV void pk_tr_mma_pf(f32x4 (&acc)[4], f32x4& lsum, const u32x4& pf, const char* pair, const LaneOffs& o) {
-  if constexpr (SUM) {
-    const u32x4 ones = {kOnesH16x2, kOnesH16x2, kOnesH16x2, kOnesH16x2};
-    lsum = Mma<h16>::mma(ones, pf, lsum);
-  }
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) {
-    const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(pair + o.tr[dt]));
-    u32x4 vf;
-    vf[0] = __builtin_bit_cast(u32x2, lo)[0];
-    vf[1] = __builtin_bit_cast(u32x2, lo)[1];
-    if constexpr (HALF) {
-      vf[2] = 0u;
-      vf[3] = 0u;
-    } else {
-      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4*)(pair + o.tr[dt] + 2048));
-      vf[2] = __builtin_bit_cast(u32x2, hi)[0];
-      vf[3] = __builtin_bit_cast(u32x2, hi)[1];
-    }
-    acc[dt] = Mma<h16>::mma(vf, pf, acc[dt]);
-  }
-}
-// pf <- pack(unpack(pf) * d): dS from the packed probabilities and the fp32 (dP - delta) of the same pair
-template <bool HALF>
-SITK_DEV void pk_scale_packed(u32x4& pf, const f32x4 (&d)[2]) {
-  const h16x8 v = __builtin_bit_cast(h16x8, pf);
-  h16x8 r;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    r[e] = (h16)((float)v[e] * d[0][e]);
-    r[e + 4] = HALF ? (h16)0.f : (h16)((float)v[e + 4] * d[1][e]);
-  }
-  pf = __builtin_bit_cast(u32x4, r);
-}
-
-// ---- forward ---------------------------------------------------------------------------------------------------
-template <int NS>
-SITK_DEV void pk_fwd_body(char* smem, uint32_t lds0, const PkUnit& un, const h16* __restrict__ qkv, h16* __restrict__ o,
-                          float* __restrict__ lse, int N, int H, float scale, int wave, int lane) {
-  using T = h16;
-  using C = PkCount<NS>;
-  PK_STAMP_DECL;
-  PK_STAMP(0);
-  const int fr = lane & 15, fq = lane >> 4;
-  const int b = un.b, h = un.h, I = H * 64, slot = NS == 1 ? 0 : un.slot;
-  const size_t ld = (size_t)3 * I;
-  const T* base = qkv + (size_t)b * N * ld;
-  char* r1 = smem + PK_R1;
-  const int q = un.tile * 16 + fr, qc = min(q, N - 1);
-  u32x4 qf[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + ks * 32 + fq * 8);
-  pk_dma_first<NS>(smem, base + I + un.h0 * 64, ld, N, wave, lane);           // K
-  pk_dma_second<NS>(r1, base + 2 * I + un.h0 * 64, ld, N, wave, lane);        // V, lands under the score phase
-  __builtin_amdgcn_sched_barrier(0);
-  PK_STAMP(1);
-  const float c = scale * kLog2e;
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) qf[ks] = scale_frag(qf[ks], c);
-  const LaneOffs lo = lane_offs_h16(lane);
-  const uint32_t kb = lds0 + slot * PK_SLOT, a0 = kb + lo.row[0], a1 = kb + lo.row[1];
-  pk_wait_vm<C::PPW2>();                                                       // K (and q) have landed
-  PK_STAMP(2);
-  pk_barrier();
-  PK_STAMP(3);
-  // phase 1: the row's probabilities, packed.  First with the maximum taken as 0 (scores of LayerNorm'ed activations are a
-  // few log2 units); only if some row's maximum leaves [-8, 8] (kRescaleThr: its probability then leaves [2^-8, 2^8], and
-  // an f16 pack could overflow from 2^16) the sweep is repeated with the true maximum as the MFMAs' initial accumulator.
-  u32x4 pf[PK_NP];
-  float m = 0.f, mxl = -INFINITY;
-  auto sweep = [&](auto first_c) {
-    constexpr bool FIRST = decltype(first_c)::value;
-    static_for<PK_NP>([&](auto pc) {
-      constexpr int p2 = decltype(pc)::value;
-      constexpr bool HALF = p2 == PK_NP - 1;
-      f32x4 s[2];
-      s[0] = splat4(-m);
-      s[1] = HALF ? splat4(0.f) : splat4(-m);
-      pk_row_mma_asm<p2>(s, a0, a1, qf);
-#pragma unroll
-      for (int i = 0; i < (HALF ? 1 : 2); ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          if constexpr (HALF) {
-            if (p2 * 32 + 16 * i + 4 * fq + jj >= N) s[i][jj] = -INFINITY;
-          }
-          if constexpr (FIRST) mxl = fmaxf(mxl, s[i][jj]);
-          s[i][jj] = fast_exp2(s[i][jj]);
-        }
-      pf[p2] = pack_pair_h16(s[0], s[1]);
-      __builtin_amdgcn_sched_barrier(0);        // one pair at a time: its fp32 scores die here
-    });
-  };
-  sweep(std::true_type{});
-  PK_STAMP(4);
-  const float mx = xor_max4(mxl);
-  if (__any(fabsf(mx) > kRescaleThr)) {
-    m = mx;
-    sweep(std::false_type{});
-  }
-  PK_STAMP(5);
-  pk_barrier();                                                                // every wave has read its K rows
-  PK_STAMP(6);
-  if constexpr (NS == 2) pk_dma_late(smem, base + 2 * I + un.h0 * 64, ld, N, wave, lane);   // V's late tiles take their place
-  f32x4 lacc = splat4(0.f), oacc[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) oacc[dt] = splat4(0.f);
-  pk_wait_vm<0>();
-  PK_STAMP(7);
-  pk_barrier();
-  PK_STAMP(8);
-  // phase 2: O = P V, row sums on the matrix pipe
-  static_for<PK_NP>([&](auto pc) {
-    constexpr int p2 = decltype(pc)::value;
-    pk_tr_mma_pf<p2 == PK_NP - 1, true>(oacc, lacc, pf[p2], pk_pair2(r1, smem, slot, p2), lo);
-  });
-  PK_STAMP(9);
-  const float lt = lacc[0], inv = 1.0f / lt;
-  if (un.active && q < N) {
-    T* orow = o + ((size_t)b * N + q) * I + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store4(orow + 16 * dt + 4 * fq, oacc[dt] * inv);
-    if (fq == 0) lse[((size_t)b * H + h) * N + q] = (m + __log2f(lt)) * kLn2;
-  }
-  PK_STAMP(10);
-  PK_STAMP_FLUSH(0);
-}
-
-__global__ __launch_bounds__(PK_W * 64) void attn_fwd_pk_kernel(const h16* __restrict__ qkv, h16* __restrict__ o,
-                                                                float* __restrict__ lse, int N, int H, float scale, int wps) {
-  __shared__ __attribute__((aligned(256))) char smem[PK_LDS];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const PkUnit un = pk_unit(H, wps, wave);
-  if (un.nslots == 1) pk_fwd_body<1>(smem, lds0, un, qkv, o, lse, N, H, scale, wave, lane);
-  else pk_fwd_body<2>(smem, lds0, un, qkv, o, lse, N, H, scale, wave, lane);
-}
-
-// ---- backward, query side ------------------------------------------------------------------------------------------
-// FOLD: six k-step panels of one 16-row block of the head's Wo^T slice (asm reads: the K transfer is still in flight)
-template <int OFF>
-SITK_DEV void pk_w6(u32x4 (&f)[6], uint32_t a) {
-  asm volatile("ds_read_b128 %0, %6 offset:%7\n\tds_read_b128 %1, %6 offset:%8\n\tds_read_b128 %2, %6 offset:%9\n\t"
-               "ds_read_b128 %3, %6 offset:%10\n\tds_read_b128 %4, %6 offset:%11\n\tds_read_b128 %5, %6 offset:%12\n\t"
-               "s_waitcnt lgkmcnt(0)"
-               : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3]), "=&v"(f[4]), "=&v"(f[5])
-               : "v"(a), "n"(OFF), "n"(OFF + 4096), "n"(OFF + 8192), "n"(OFF + 12288), "n"(OFF + 16384), "n"(OFF + 20480)
-               : "memory");
-}
-
-template <int NS, bool FOLD>
-SITK_DEV void pk_dq_body(char* smem, uint32_t lds0, const PkUnit& un, const h16* __restrict__ qkv, const h16* __restrict__ o,
-                         const h16* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta,
-                         h16* __restrict__ dqkv, int N, int H, float scale, const h16* __restrict__ dxmid,
-                         const h16* __restrict__ wo_t, h16* __restrict__ d_o_out, int wave, int lane) {
-  using T = h16;
-  using C = PkCount<NS>;
-  static_assert(FOLD_KS == 6, "pk_w6");
-  constexpr int WSL = 64 * FOLD_D * 2;                                        // one head's Wo^T slice: [panel 0..5][64 rows][64 B]
-  constexpr int EW = NS * 4 * FOLD_KS, PPWW = (EW + PK_W - 1) / PK_W;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int b = un.b, h = un.h, I = H * 64, slot = NS == 1 ? 0 : un.slot;
-  const size_t ld = (size_t)3 * I;
-  const T* base = qkv + (size_t)b * N * ld;
-  char* r1 = smem + PK_R1;
-  const int q = un.tile * 16 + fr, qc = min(q, N - 1);
-  const bool live = un.active && q < N;
-  const size_t ridx = ((size_t)b * H + h) * N + qc;
-  // every register load of the kernel first: nothing but DMA pieces and stores enters the vmcnt queue behind them
-  u32x4 qf[2], dof[2], ovf[2], dxf[FOLD ? FOLD_KS : 1];
-  const float lseq = lse[ridx];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int eo = ks * 32 + fq * 8;
-    qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
-    ovf[ks] = *reinterpret_cast<const u32x4*>(o + ((size_t)b * N + qc) * I + h * 64 + eo);
-    if constexpr (!FOLD) dof[ks] = *reinterpret_cast<const u32x4*>(d_o + ((size_t)b * N + qc) * I + h * 64 + eo);
-  }
-  if constexpr (FOLD) {
-#pragma unroll
-    for (int ks = 0; ks < FOLD_KS; ++ks)
-      dxf[ks] = *reinterpret_cast<const u32x4*>(dxmid + ((size_t)b * N + qc) * FOLD_D + ks * 32 + fq * 8);
-#pragma unroll
-    for (int i = 0; i < PPWW; ++i) {                                           // Wo^T slices of the head(s) -> R1
-      const int pc = min(wave * PPWW + i, EW - 1), sl = pc >= 4 * FOLD_KS ? 1 : 0, pq = pc - sl * 4 * FOLD_KS;
-      const int panel = pq >> 2, row = (pq & 3) * 16 + (lane >> 2), kq = (lane & 3) ^ ((row >> 2) & 3);
-      const h16* g = wo_t + (size_t)((un.h0 + sl) * 64 + row) * FOLD_D + panel * 32 + kq * 8;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(r1 + sl * WSL + pq * 1024), 16, 0, 0);
-    }
-  }
-  pk_dma_first<NS>(smem, base + I + un.h0 * 64, ld, N, wave, lane);            // K
-  __builtin_amdgcn_sched_barrier(0);
-  const LaneOffs lo = lane_offs_h16(lane);
-  float dpart = 0.f;
-  if constexpr (FOLD) {
-    const uint32_t wb = lds0 + PK_R1 + slot * WSL;
-    uint32_t wa[2];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int crow = 8 * (fr >> 2) + 4 * ct + (fr & 3);
-      wa[ct] = wb + crow * 64 + ((fq ^ ((crow >> 2) & 3)) << 4);
-    }
-    pk_wait_vm<C::PPW1>();                                                     // Wo^T and the rows above have landed; K is in flight
-    pk_barrier();
-    f32x4 acc[4];
-    static_for<4>([&](auto cc) {
-      constexpr int ct = decltype(cc)::value;
-      u32x4 wf[6];
-      pk_w6<(ct >> 1) * 2048>(wf, wa[ct & 1]);
-      acc[ct] = splat4(0.f);
-#pragma unroll
-      for (int ks = 0; ks < FOLD_KS; ++ks) acc[ct] = Mma<h16>::mma(wf[ks], dxf[ks], acc[ct]);
-    });
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      dof[ks] = pack_pair_h16(acc[2 * ks], acc[2 * ks + 1]);
-      if (live) *reinterpret_cast<u32x4*>(d_o_out + ((size_t)b * N + q) * I + h * 64 + ks * 32 + fq * 8) = dof[ks];
-    }
-    pk_barrier();                                                              // every wave is through with Wo^T: R1 is V's now
-  }
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const h16x8 dv8 = __builtin_bit_cast(h16x8, dof[ks]), ov8 = __builtin_bit_cast(h16x8, ovf[ks]);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dpart += (float)dv8[e] * (float)ov8[e];
-  }
-  pk_dma_second<NS>(r1, base + 2 * I + un.h0 * 64, ld, N, wave, lane);        // V, lands under the score phase
-  __builtin_amdgcn_sched_barrier(0);
-  const float dl = xor_sum4(dpart);
-  if (live && fq == 0) delta[ridx] = dl;
-  const float c = scale * kLog2e, nLq = -lseq * kLog2e, ndl = -dl;
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) qf[ks] = scale_frag(qf[ks], c);              // scores in log2 units straight from the MFMA
-  const uint32_t kb = lds0 + slot * PK_SLOT, a0 = kb + lo.row[0], a1 = kb + lo.row[1];
-  pk_wait_vm<C::PPW2>();                                                       // K has landed
-  pk_barrier();
-  // phase 1 (K, asm reads): the row's probabilities, packed
-  u32x4 pf[PK_NP];
-  static_for<PK_NP>([&](auto pc) {
-    constexpr int p2 = decltype(pc)::value;
-    constexpr bool HALF = p2 == PK_NP - 1;
-    f32x4 s[2];
-    s[0] = splat4(nLq);
-    s[1] = HALF ? splat4(0.f) : splat4(nLq);
-    pk_row_mma_asm<p2>(s, a0, a1, qf);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        float x = (HALF && i == 1) ? 0.f : fast_exp2(s[i][jj]);
-        if constexpr (HALF) {
-          if (p2 * 32 + 16 * i + 4 * fq + jj >= N) x = 0.f;
-        }
-        s[i][jj] = x;
-      }
-    pf[p2] = pack_pair_h16(s[0], s[1]);
-    asm volatile("" : "+v"(pf[p2]));            // opaque: hipcc otherwise keeps every ROUNDED probability in a register of its own for phase 2
-    __builtin_amdgcn_sched_barrier(0);          // one pair at a time: its fp32 scores die here (hipcc would keep several alive)
-  });
-  pk_wait_vm<0>();
-  pk_barrier();
-  // phase 2 (V): dS = P (dO v - delta), in place
-  auto v_pair = [&](auto pc) {
-    constexpr int p2 = decltype(pc)::value;
-    constexpr bool HALF = p2 == PK_NP - 1;
-    f32x4 dp[2];
-    dp[0] = splat4(ndl);
-    dp[1] = splat4(ndl);
-    pk_row_mma<HALF>(dp, pk_pair2(r1, r1, slot, p2), dof, lo);
-    pk_scale_packed<HALF>(pf[p2], dp);
-  };
-  static_for<PK_NP>([&](auto pc) {
-    if constexpr (NS == 1 || !pk_pair_is_late(decltype(pc)::value)) v_pair(pc);
-  });
-  if constexpr (NS == 2) {
-    pk_barrier();                                                              // every wave is through slot 0's tiles 0 and 1
-    pk_dma_late(r1, base + 2 * I + un.h0 * 64, ld, N, wave, lane);
-    pk_wait_vm<0>();
-    pk_barrier();
-    static_for<PK_NP>([&](auto pc) {
-      if constexpr (pk_pair_is_late(decltype(pc)::value)) v_pair(pc);
-    });
-  }
-  // phase 3 (K again, transposed reads): dQ = dS K
-  f32x4 dq[4], nosum;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) dq[dt] = splat4(0.f);
-  const char* sK = smem + slot * PK_SLOT;
-  static_for<PK_NP>([&](auto pc) {
-    constexpr int p2 = decltype(pc)::value;
-    pk_tr_mma_pf<p2 == PK_NP - 1, false>(dq, nosum, pf[p2], sK + p2 * 4096, lo);
-  });
-  if (live) {
-    T* row = dqkv + ((size_t)b * N + q) * ld + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) store4(row + 16 * dt + 4 * fq, dq[dt] * scale);
-  }
-}
-
-template <bool FOLD>
-__global__ __launch_bounds__(PK_W * 64) void attn_bwd_dq_pk_kernel(const h16* __restrict__ qkv, const h16* __restrict__ o,
-                                                                   const h16* __restrict__ d_o, const float* __restrict__ lse,
-                                                                   float* __restrict__ delta, h16* __restrict__ dqkv, int N,
-                                                                   int H, float scale, int wps, const h16* __restrict__ dxmid,
-                                                                   const h16* __restrict__ wo_t, h16* __restrict__ d_o_out) {
-  __shared__ __attribute__((aligned(256))) char smem[PK_LDS];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const PkUnit un = pk_unit(H, wps, wave);
-  if (un.nslots == 1) pk_dq_body<1, FOLD>(smem, lds0, un, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out, wave, lane);
-  else pk_dq_body<2, FOLD>(smem, lds0, un, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out, wave, lane);
-}
-
-// ---- backward, key side --------------------------------------------------------------------------------------------
-// two (or one) f32x4 of a per-query statistics row (asm reads, phase 1): blocks 16 i of pair p2 at a + OFF + 64 i
-template <int OFF>
-SITK_DEV void pk_stat2(f32x4 (&v)[2], uint32_t a) {
-  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4\n\ts_waitcnt lgkmcnt(0)"
-               : "=&v"(v[0]), "=&v"(v[1])
-               : "v"(a), "n"(OFF), "n"(OFF + 64)
-               : "memory");
-}
-template <int OFF>
-SITK_DEV void pk_stat1(f32x4 (&v)[2], uint32_t a) {
-  asm volatile("ds_read_b128 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(a), "n"(OFF) : "memory");
-}
-
-template <int NS>
-SITK_DEV void pk_dkv_body(char* smem, uint32_t lds0, const PkUnit& un, const h16* __restrict__ qkv, const h16* __restrict__ d_o,
-                          const float* __restrict__ lse, const float* __restrict__ delta, h16* __restrict__ dqkv, int N,
-                          int H, float scale, int wave, int lane) {
-  using T = h16;
-  using C = PkCount<NS>;
-  constexpr int ES = NS * 12, PPWS = (ES + PK_W - 1) / PK_W;                  // statistics: 6 pieces of 64 floats per (slot, table)
-  const int fr = lane & 15, fq = lane >> 4;
-  const int b = un.b, h = un.h, I = H * 64, slot = NS == 1 ? 0 : un.slot;
-  const size_t ld = (size_t)3 * I;
-  const T* base = qkv + (size_t)b * N * ld;
-  const T* dob = d_o + (size_t)b * N * I;
-  char* r1 = smem + PK_R1;
-  const int key = un.tile * 16 + fr, kc = min(key, N - 1);
-  u32x4 kf[2], vf[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) kf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + ks * 32 + fq * 8);
-  pk_dma_first<NS>(smem, base + un.h0 * 64, ld, N, wave, lane);                // Q
-#pragma unroll
-  for (int i = 0; i < PPWS; ++i) {                                             // lse and delta rows of the head(s), 4 bytes per lane
-    const int e = min(wave * PPWS + i, ES - 1), sl = e >= 12 ? 1 : 0, tb = (e - sl * 12) / 6, j = e - sl * 12 - tb * 6;
-    const float* g = (tb ? delta : lse) + ((size_t)b * H + un.h0 + sl) * N + min(j * 64 + lane, N - 1);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)(r1 + PK_R1_STATS + ((sl * 2 + tb) * PK_STAT_LD + j * 64) * 4),
-                                     4, 0, 0);
-  }
-  pk_dma_second<NS>(r1, dob + un.h0 * 64, (size_t)I, N, wave, lane);          // dO, lands under the score phase
-  __builtin_amdgcn_sched_barrier(0);
-  const float c = scale * kLog2e;
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) kf[ks] = scale_frag(kf[ks], c);              // log2-domain scores
-  const LaneOffs lo = lane_offs_h16(lane);
-  const uint32_t qb = lds0 + slot * PK_SLOT, a0 = qb + lo.row[0], a1 = qb + lo.row[1];
-  const int st_off = PK_R1 + PK_R1_STATS + slot * 2 * PK_STAT_LD * 4 + fq * 16;
-  const uint32_t sa = lds0 + st_off;                                           // lse row; delta row: + PK_STAT_LD * 4
-  pk_wait_vm<C::PPW2>();                                                       // Q, the statistics (and k) have landed
-  pk_barrier();
-  // phase 1 (Q, asm reads): P^T of the unit's 16 keys against every query, packed
-  u32x4 pf[PK_NP];
-  static_for<PK_NP>([&](auto pc) {
-    constexpr int p2 = decltype(pc)::value;
-    constexpr bool HALF = p2 == PK_NP - 1;
-    f32x4 s[2];
-    if constexpr (HALF) pk_stat1<p2 * 128>(s, sa);
-    else pk_stat2<p2 * 128>(s, sa);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        float x = (HALF && i == 1) ? 0.f : s[i][jj] * -kLog2e;
-        if constexpr (HALF) {
-          if (p2 * 32 + 16 * i + 4 * fq + jj >= N) x = -INFINITY;             // padded queries: p = exp2(-inf) = 0
-        }
-        s[i][jj] = x;
-      }
-    pk_row_mma_asm<p2>(s, a0, a1, kf);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) s[i][jj] = (HALF && i == 1) ? 0.f : fast_exp2(s[i][jj]);
-    pf[p2] = pack_pair_h16(s[0], s[1]);
-    asm volatile("" : "+v"(pf[p2]));            // opaque (see the query-side kernel)
-    __builtin_amdgcn_sched_barrier(0);          // one pair at a time: its fp32 scores die here
-  });
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) vf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + ks * 32 + fq * 8);
-  f32x4 dk[4], dv[4], nosum;
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt) { dk[dt] = splat4(0.f); dv[dt] = splat4(0.f); }
-  pk_wait_vm<0>();
-  pk_barrier();
-  // phase 2 (dO): dV += P^T dO; dS^T = P^T (v dO^T - delta), in place
-  const char* srow = smem + st_off + PK_STAT_LD * 4;                           // this lane's window of the delta row
-  auto do_pair = [&](auto pc) {
-    constexpr int p2 = decltype(pc)::value;
-    constexpr bool HALF = p2 == PK_NP - 1;
-    const char* pair = pk_pair2(r1, r1, slot, p2);
-    f32x4 dp[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      dp[i] = splat4(0.f);
-      if (!(HALF && i == 1)) {
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(srow + (p2 * 32 + 16 * i) * 4);
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) dp[i][jj] = (!HALF || p2 * 32 + 16 * i + 4 * fq + jj < N) ? -d4[jj] : 0.f;
-      }
-    }
-    pk_row_mma<HALF>(dp, pair, vf, lo);
-    pk_tr_mma_pf<HALF, false>(dv, nosum, pf[p2], pair, lo);
-    pk_scale_packed<HALF>(pf[p2], dp);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  static_for<PK_NP>([&](auto pc) {
-    if constexpr (NS == 1 || !pk_pair_is_late(decltype(pc)::value)) do_pair(pc);
-  });
-  if constexpr (NS == 2) {
-    pk_barrier();                                                              // every wave is through slot 0's tiles 0 and 1
-    pk_dma_late(r1, dob + un.h0 * 64, (size_t)I, N, wave, lane);
-    pk_wait_vm<0>();
-    pk_barrier();
-    static_for<PK_NP>([&](auto pc) {
-      if constexpr (pk_pair_is_late(decltype(pc)::value)) do_pair(pc);
-    });
-  }
-  // phase 3 (Q again, transposed reads): dK = dS^T Q
-  const char* sQ = smem + slot * PK_SLOT;
-  static_for<PK_NP>([&](auto pc) {
-    constexpr int p2 = decltype(pc)::value;
-    pk_tr_mma_pf<p2 == PK_NP - 1, false>(dk, nosum, pf[p2], sQ + p2 * 4096, lo);
-  });
-  if (un.active && key < N) {
-    T* row = dqkv + ((size_t)b * N + key) * ld + h * 64;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      store4(row + I + 16 * dt + 4 * fq, dk[dt] * scale);
-      store4(row + 2 * I + 16 * dt + 4 * fq, dv[dt]);
-    }
-  }
-}
-
-__global__ __launch_bounds__(PK_W * 64) void attn_bwd_dkv_pk_kernel(const h16* __restrict__ qkv, const h16* __restrict__ d_o,
-                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
-                                                                    h16* __restrict__ dqkv, int N, int H, float scale, int wps) {
-  __shared__ __attribute__((aligned(256))) char smem[PK_LDS];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const PkUnit un = pk_unit(H, wps, wave);
-  if (un.nslots == 1) pk_dkv_body<1>(smem, lds0, un, qkv, d_o, lse, delta, dqkv, N, H, scale, wave, lane);
-  else pk_dkv_body<2>(smem, lds0, un, qkv, d_o, lse, delta, dqkv, N, H, scale, wave, lane);
-}
-
-#endif  // SITK_AB (unit-packed variants)
 
 // ------------------------------------------------------------------------------------------
 // Ring variants (bf16, 384 < N <= 2048: the 1281-token configurations of BASELINE configs 3 and 5).
@@ -2076,12 +1421,7 @@ template <typename T>
 static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, float scale, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
 #ifdef SITK_AB
-    if (pk_supported(N) && sitk_ab_switch("SITK_ATTN_PK", 0)) {
-      const int wps = pk_wgs_per_sample(H);
-      hipLaunchKernelGGL(attn_fwd_pk_kernel, dim3(B * wps), dim3(PK_W * 64), 0, s, reinterpret_cast<const h16*>(qkv),
-                         reinterpret_cast<h16*>(o), lse, N, H, scale, wps);
-      return check_launch("attention_fwd_pk");
-    }
+    { int rc; if (pk_try_fwd(qkv, o, lse, B, N, H, scale, s, &rc)) return rc; }
 #endif
     if (N <= RES_MAX_N) {
       hipLaunchKernelGGL(attn_fwd_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
@@ -2108,19 +1448,7 @@ static bool bwd_proj_supported(int N, int D, int dtype) { return dtype == SITK_H
 static int run_bwd_proj(const void* qkv, const void* o, const void* dxmid, const void* wo_t, void* d_o, const float* lse,
                         float* delta, void* dqkv, int B, int N, int H, float scale, hipStream_t s, int phases = 3) {
 #ifdef SITK_AB
-  if (pk_supported(N) && sitk_ab_switch("SITK_ATTN_PK", 0)) {
-    const int wps = pk_wgs_per_sample(H);
-    if (phases & 1)
-      hipLaunchKernelGGL((attn_bwd_dq_pk_kernel<true>), dim3(B * wps), dim3(PK_W * 64), 0, s, reinterpret_cast<const h16*>(qkv),
-                         reinterpret_cast<const h16*>(o), (const h16*)nullptr, lse, delta, reinterpret_cast<h16*>(dqkv), N, H,
-                         scale, wps, reinterpret_cast<const h16*>(dxmid), reinterpret_cast<const h16*>(wo_t),
-                         reinterpret_cast<h16*>(d_o));
-    SITK_LAUNCH_CHECK("attention_bwd_proj_dq_pk");
-    if (phases & 2)
-      hipLaunchKernelGGL(attn_bwd_dkv_pk_kernel, dim3(B * wps), dim3(PK_W * 64), 0, s, reinterpret_cast<const h16*>(qkv),
-                         reinterpret_cast<const h16*>(d_o), lse, delta, reinterpret_cast<h16*>(dqkv), N, H, scale, wps);
-    return check_launch("attention_bwd_dkv_pk");
-  }
+  { int rc; if (pk_try_bwd_proj(qkv, o, dxmid, wo_t, d_o, lse, delta, dqkv, B, N, H, scale, s, phases, &rc)) return rc; }
 #endif
   if (phases == 3 && sitk_ab_switch("SITK_ATTN_MERGED", 1)) {    // both sides in one launch
     hipLaunchKernelGGL((attn_bwd_res_kernel<true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
@@ -2146,18 +1474,7 @@ static int run_bwd(const void* qkv, const void* o, const void* d_o, const float*
                    int B, int N, int H, float scale, hipStream_t s, int phases = 3) {
   if constexpr (sizeof(T) == 2) {
 #ifdef SITK_AB
-    if (pk_supported(N) && sitk_ab_switch("SITK_ATTN_PK", 0)) {
-      const int wps = pk_wgs_per_sample(H);
-      if (phases & 1)
-        hipLaunchKernelGGL((attn_bwd_dq_pk_kernel<false>), dim3(B * wps), dim3(PK_W * 64), 0, s, reinterpret_cast<const h16*>(qkv),
-                           reinterpret_cast<const h16*>(o), reinterpret_cast<const h16*>(d_o), lse, delta,
-                           reinterpret_cast<h16*>(dqkv), N, H, scale, wps, (const h16*)nullptr, (const h16*)nullptr, (h16*)nullptr);
-      SITK_LAUNCH_CHECK("attention_bwd_dq_pk");
-      if (phases & 2)
-        hipLaunchKernelGGL(attn_bwd_dkv_pk_kernel, dim3(B * wps), dim3(PK_W * 64), 0, s, reinterpret_cast<const h16*>(qkv),
-                           reinterpret_cast<const h16*>(d_o), lse, delta, reinterpret_cast<h16*>(dqkv), N, H, scale, wps);
-      return check_launch("attention_bwd_dkv_pk");
-    }
+    { int rc; if (pk_try_bwd(qkv, o, d_o, lse, delta, dqkv, B, N, H, scale, s, phases, &rc)) return rc; }
 #endif
     if (N <= RES_MAX_N && phases == 3 && sitk_ab_switch("SITK_ATTN_MERGED", 1)) {    // both sides in one launch
       hipLaunchKernelGGL((attn_bwd_res_kernel<false>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
@@ -2274,10 +1591,5 @@ extern "C" int sitk_attention_bwd_phases(const void* qkv, const void* o, const v
 extern "C" int sitk_debug_res_stamps(void* out, size_t bytes) {
   if (bytes != sizeof(sitk::g_res_stamps)) return (int)sizeof(sitk::g_res_stamps);
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(sitk::g_res_stamps), bytes) == hipSuccess ? 0 : -1;
-}
-// diagnostic build: copies the s_memtime stamps of the unit-packed kernels' first workgroups to the host
-extern "C" int sitk_debug_pk_stamps(void* out, size_t bytes) {
-  if (bytes != sizeof(sitk::g_pk_stamps)) return (int)sizeof(sitk::g_pk_stamps);
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sitk::g_pk_stamps), bytes) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -79,7 +79,9 @@ struct sitk_overlap {
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ev;     // [0, max_layers): forks of sitk_encoder_bwd_overlap; max_layers: its chain / join event;
                                   // max_layers + 1: sitk_overlap_fork / _join
-  int max_layers = 0, layers = 0, cus = 0, caller_joins = 0;
+  std::vector<hipEvent_t> done;   // [i]: recorded on the side stream behind side launch i (+ its slab reduction) of the last
+                                  // sitk_encoder_bwd_overlap call: the gradients that launch wrote are final there
+  int max_layers = 0, layers = 0, cus = 0, caller_joins = 0, n_done = 0, tail_cus = 256;
 };
 extern "C" sitk_overlap* sitk_overlap_create(int max_layers, int cus, int caller_joins) {
   if (max_layers < 1 || max_layers > 64 || cus < 1 || cus > 128) { sitk_rt::set_error("overlap: bad arguments"); return nullptr; }
@@ -104,11 +106,20 @@ extern "C" sitk_overlap* sitk_overlap_create(int max_layers, int cus, int caller
       sitk_overlap_destroy(o);
       return nullptr;
     }
+  o->done.resize(max_layers);
+  for (size_t i = 0; i < o->done.size(); ++i)
+    if (hipEventCreateWithFlags(&o->done[i], hipEventDisableTiming) != hipSuccess) {
+      sitk_rt::set_error("overlap: hipEventCreate failed");
+      o->done.resize(i);
+      sitk_overlap_destroy(o);
+      return nullptr;
+    }
   return o;
 }
 extern "C" void sitk_overlap_destroy(sitk_overlap* o) {
   if (!o) return;
   for (hipEvent_t e : o->ev) (void)hipEventDestroy(e);
+  for (hipEvent_t e : o->done) (void)hipEventDestroy(e);
   if (o->side) (void)hipStreamDestroy(o->side);
   delete o;
 }
@@ -116,6 +127,20 @@ extern "C" sitk_stream_t sitk_overlap_stream(sitk_overlap* o) { return o ? (sitk
 extern "C" int sitk_overlap_set_layers(sitk_overlap* o, int layers) {
   if (!o || layers < 0 || layers > o->max_layers) { sitk_rt::set_error("overlap_set_layers: 0..max_layers"); return SITK_ERR_INVALID; }
   o->layers = layers;
+  return SITK_OK;
+}
+extern "C" int sitk_overlap_set_tail_cus(sitk_overlap* o, int cus) {
+  if (!o || cus < 1 || cus > 256) { sitk_rt::set_error("overlap_set_tail_cus: 1..256"); return SITK_ERR_INVALID; }
+  o->tail_cus = cus;
+  return SITK_OK;
+}
+extern "C" int sitk_overlap_side_launches(const sitk_overlap* o) { return o ? o->n_done : 0; }
+extern "C" int sitk_overlap_wait_side_launch(sitk_overlap* o, int i, sitk_stream_t stream) {
+  if (!o || i < 0 || i >= o->n_done) { sitk_rt::set_error("overlap_wait_side_launch: launch %d of %d", i, o ? o->n_done : 0); return SITK_ERR_INVALID; }
+  if (hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), o->done[i], 0) != hipSuccess) {
+    sitk_rt::set_error("overlap: wait for side launch %d failed", i);
+    return SITK_ERR_LAUNCH;
+  }
   return SITK_OK;
 }
 extern "C" int sitk_overlap_fork(sitk_overlap* o, sitk_stream_t stream) {
@@ -143,18 +168,28 @@ extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_stream_(sitk
 extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_event_(sitk_overlap* o, int i) { return (o && i >= 0 && i < (int)o->ev.size()) ? (void*)o->ev[i] : nullptr; }
 extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_layers_(const sitk_overlap* o) { return o ? o->layers : 0; }
 extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_cus_(const sitk_overlap* o) { return o ? o->cus : 0; }
+extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_tail_cus_(const sitk_overlap* o) { return o ? o->tail_cus : 256; }
+extern "C" __attribute__((visibility("hidden"))) void sitk_overlap_reset_done_(sitk_overlap* o) { if (o) o->n_done = 0; }
+// the event behind the next side launch (null when the object has no room left: cannot happen, one launch holds >= 1 layer)
+extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_next_done_(sitk_overlap* o) {
+  return (o && o->n_done < (int)o->done.size()) ? (void*)o->done[o->n_done++] : nullptr;
+}
 
 extern "C" int sitk_abi_version(void) { return SITK_ABI_VERSION; }
 extern "C" const char* sitk_last_error(void) { return sitk_rt::g_err; }
 extern "C" int sitk_dtype_size(int dtype) { return (dtype == SITK_BF16 || dtype == SITK_F16) ? 2 : (dtype == SITK_F32 ? 4 : 0); }
 
 #ifdef SITK_AB
-// Diagnostic build only (tools/dp_cu_budget.py): `workgroups` workgroups of 512 threads that hold their CUs' wave slots and 16 KB
-// of LDS each for `microseconds` (wall clock, s_memrealtime at 100 MHz) -- a stand-in for the channels of a gradient
-// all-reduce whose wire time a one-GPU box cannot produce.  Bounded: at most 5 ms whatever is asked.
-__global__ __launch_bounds__(512) void sitk_debug_occupy_kernel(unsigned long long ticks, int* sink) {
-  __shared__ int pad[4096];
+// Diagnostic build only (tools/dp_cu_budget.py): `workgroups` workgroups that hold their CUs for `microseconds` (wall clock,
+// s_memrealtime at 100 MHz) -- a stand-in for the channels of a gradient all-reduce whose wire time a one-GPU box cannot
+// produce.  The footprint is the one of RCCL's own kernel on this chip (the gfx950 code object inside torch's librccl.so,
+// `rcclGenericKernel<*>`: 256 threads, 19 744 B of LDS, 261 - 280 registers per lane, 352 B of scratch), so what can and
+// cannot share a CU with it is what can and cannot share a CU with a real channel: nothing of this library's chain (its
+// workgroups take 146 KB of LDS or the whole register file).  Bounded: at most 5 ms whatever is asked.
+__global__ __launch_bounds__(256) void sitk_debug_occupy_kernel(unsigned long long ticks, int* sink) {
+  extern __shared__ int pad[];              // 19 744 B, given at launch (a static array the kernel never reads is dropped)
   pad[threadIdx.x] = (int)threadIdx.x;
+  asm volatile("v_mov_b32 v247, 0\n\tv_accvgpr_write_b32 a31, 0" ::: "v247", "a31");     // 248 + 32 registers per lane
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   int spins = 0;
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && spins < (1 << 22)) {
@@ -166,7 +201,7 @@ __global__ __launch_bounds__(512) void sitk_debug_occupy_kernel(unsigned long lo
 extern "C" int sitk_debug_occupy(int workgroups, int microseconds, sitk_stream_t stream) {
   if (workgroups < 1 || workgroups > 256 || microseconds < 1) { sitk_rt::set_error("debug_occupy: bad arguments"); return SITK_ERR_INVALID; }
   const unsigned long long ticks = 100ull * (unsigned long long)(microseconds > 5000 ? 5000 : microseconds);
-  hipLaunchKernelGGL(sitk_debug_occupy_kernel, dim3(workgroups), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), ticks,
+  hipLaunchKernelGGL(sitk_debug_occupy_kernel, dim3(workgroups), dim3(256), 19744, reinterpret_cast<hipStream_t>(stream), ticks,
                      (int*)nullptr);
   return sitk_rt::check_launch("debug_occupy");
 }

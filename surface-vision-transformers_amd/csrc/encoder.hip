@@ -438,6 +438,9 @@ extern "C" int sitk_overlap_layers_(const sitk_overlap* o);
 extern "C" int sitk_overlap_cus_(const sitk_overlap* o);
 extern "C" int sitk_overlap_caller_joins_(const sitk_overlap* o);
 extern "C" int sitk_overlap_max_layers_(const sitk_overlap* o);
+extern "C" int sitk_overlap_tail_cus_(const sitk_overlap* o);
+extern "C" void sitk_overlap_reset_done_(sitk_overlap* o);
+extern "C" void* sitk_overlap_next_done_(sitk_overlap* o);
 
 SITK_F16_TWIN(sitk_encoder_bwd_overlap)
 extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* P, const sitk_layer_params* G,
@@ -468,6 +471,7 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
   const int side_max = (overlap && S.wg_batch && S.wgrad_ws_side_bytes && !c.timeline)        // (a timeline times ONE stream)
                            ? std::min(sitk_overlap_layers_(overlap), layer_end - layer_begin) : 0;
   const int side_cus = sitk_overlap_cus_(overlap);
+  sitk_overlap_reset_done_(overlap);
   int n_side = 0;
   std::vector<sitk_wgrad_desc> wg_side;
   std::vector<LnFinalizeEntry> ln_entries;
@@ -572,6 +576,13 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
         SITK_TRY(sitk_gemm_wgrad_group_ws_cus(wg_side.data(), (int)wg_side.size(), dt, S.wgrad_ws_side, S.wgrad_ws_side_bytes,
                                               side_cus, side));
         wg_side.clear();
+        // the weight / bias gradients of this launch's layers are final behind it: a data-parallel caller reduces them from
+        // here on (sitk_overlap_wait_side_launch), beside the rest of the chain
+        hipEvent_t done = reinterpret_cast<hipEvent_t>(sitk_overlap_next_done_(overlap));
+        if (done && hipEventRecord(done, side) != hipSuccess) {
+          set_error("encoder_bwd_overlap: event record on the side stream failed");
+          return SITK_ERR_LAUNCH;
+        }
       }
     }
     else if (S.wg_batch) wg_all.insert(wg_all.end(), wg, wg + 4);       // launched once, after the slice's last layer
@@ -580,6 +591,12 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
     if (qkv_fused(c) && l > layer_begin && mlp_fused(c) && sitk_ln_gemm_mlp_bwd_supported(R, D, 3 * I, M, dt)) {
       // d to_qkv + LayerNorm backward of THIS layer and the MLP backward of the NEXT one (l - 1) in one launch: same 96-row
       // workgroups, the second half reads back the rows its own workgroup has just written (dx, dxc_next)
+      // ALIASING, intended: `dres` of the first half (the residual gradient d x_mid of layer l, read) and `dx_mid` of the second
+      // half (d x_mid of layer l - 1, written) are BOTH S.dxB, and the second half's `dy` / `dy_c` are the `dx` / `dxc_next` the
+      // first half has just stored.  This is safe because the two halves give a workgroup the SAME 96 rows: a workgroup reads
+      // its rows of S.dxB in the first half, stores its rows of dx / dxc_next, drains them (`s_waitcnt vmcnt(0)` + the workgroup
+      // barrier between the halves), and only then overwrites its own rows of S.dxB; no workgroup touches another's rows.  A
+      // change of either half's row partition breaks this (test_ln_gemm_mlp_bwd_pair_launch_is_bitwise_the_two_launches).
       const LayerActs& an = L.layers[l - 1];
       const int sn = slot(l - 1);
       float* part2n = S.ln_partials + (size_t)(2 * (l - 1) + 1) * S.ln_partial_floats;
@@ -631,7 +648,9 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
       wg_all.resize(before);
   }
   if (S.wg_batch && !wg_all.empty()) {
-    SITK_TRY(sitk_gemm_wgrad_group_ws(wg_all.data(), (int)wg_all.size(), dt, S.wgrad_ws, S.wgrad_ws_bytes, stream));
+    // (a data-parallel caller leaves the all-reduce channels' CUs out of the tail launch: sitk_overlap_set_tail_cus)
+    SITK_TRY(sitk_gemm_wgrad_group_ws_cus(wg_all.data(), (int)wg_all.size(), dt, S.wgrad_ws, S.wgrad_ws_bytes,
+                                          overlap ? sitk_overlap_tail_cus_(overlap) : 256, stream));
     SITK_MARK("wgrad");
   }
   // every LayerNorm parameter gradient of the slice in one reduction launch; with a side stream it runs there, behind the

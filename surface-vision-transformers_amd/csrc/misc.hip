@@ -673,30 +673,37 @@ __global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, flo
   const float lr = (float)state[0];
   const int64_t nvec = n >> 2;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  // A gradient that is not finite (an f16 intermediate that overflowed behind the loss scale) must not reach the parameters or
-  // the momentum: the vector it sits in is skipped (zeroed like every consumed gradient) and counted in `nonfinite`.
+  // nonfinite != NULL (the engine passes it in the loss-scaled f16 mode only): a gradient element that is not finite -- an f16
+  // intermediate that overflowed behind the loss scale -- must not reach the parameters or the momentum: that ELEMENT is skipped
+  // (zeroed like every consumed gradient) and counted.  NULL: the reference's behaviour, tools/train.py:291 -- no guard, a
+  // diverged run shows NaN parameters.
+  const bool guard = nonfinite != nullptr;
   int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
-    f32x4 pv = load4(p + 4 * i);
+    const f32x4 pv = load4(p + 4 * i);
     const f32x4 graw = load4(g + 4 * i) * gscale;
     if (zero) store4(g + 4 * i, z);
-    if (!(fabsf(graw[0]) <= 3.0e38f && fabsf(graw[1]) <= 3.0e38f && fabsf(graw[2]) <= 3.0e38f && fabsf(graw[3]) <= 3.0e38f)) {
-      ++bad;
-      continue;
-    }
     f32x4 gv = graw + pv * wd;
+    f32x4 bv = z, bold = z;
     if (momentum != 0.f) {
-      f32x4 bv = load4(buf + 4 * i) * momentum + gv;
-      store4(buf + 4 * i, bv);
+      bold = load4(buf + 4 * i);
+      bv = bold * momentum + gv;
       gv = nesterov ? gv + bv * momentum : bv;
     }
-    store4(p + 4 * i, pv - gv * lr);
+    f32x4 pn = pv - gv * lr;
+    if (guard) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(fabsf(graw[e]) <= 3.0e38f)) { ++bad; pn[e] = pv[e]; bv[e] = bold[e]; }
+    }
+    if (momentum != 0.f) store4(buf + 4 * i, bv);
+    store4(p + 4 * i, pn);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (nvec << 2) + threadIdx.x;
     const float graw = g[i] * gscale;
     if (zero) g[i] = 0.f;
-    if (fabsf(graw) <= 3.0e38f) {
+    if (!guard || fabsf(graw) <= 3.0e38f) {
       float gv = graw + p[i] * wd;
       if (momentum != 0.f) {
         const float bv = buf[i] * momentum + gv;
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, fl
   int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float pv = p[i], gv = g[i] * gscale;
-    if (!(fabsf(gv) <= 3.0e38f)) {                       // not finite: skipped and counted (see sgd_dev_kernel)
+    if (nonfinite && !(fabsf(gv) <= 3.0e38f)) {          // not finite, guarded mode: skipped and counted (see sgd_dev_kernel)
       ++bad;
       if (zero) g[i] = 0.f;
       continue;

@@ -32,13 +32,19 @@ _ALIGN = 64  # floats (256 B): every parameter view is 16-byte aligned with room
 class FlatParams:
     """Flat fp32 storage for parameters / gradients / optimizer state of a module."""
 
-    def __init__(self, module, device, grad_extra=0):
+    def __init__(self, module, device, grad_extra=0, order=None):
+        """order: key(parameter) -> sortable; the buffer then holds the parameters sorted by it (stable: module order within
+        one key).  The data-parallel engine orders by the point of the step at which a gradient becomes final, so that
+        every all-reduce bucket is ONE contiguous range.  Nothing else depends on the order: the module's parameters are
+        views (state_dict / checkpoints unchanged), the optimizer pass is elementwise."""
         self.params = []
         seen = set()
         for p in module.parameters():
             if id(p) not in seen:
                 seen.add(id(p))
                 self.params.append(p)
+        if order is not None:
+            self.params.sort(key=order)
         self.offsets, off = {}, 0
         for p in self.params:
             self.offsets[id(p)] = (off, p.numel())
@@ -104,18 +110,51 @@ def grad_write_stages(model, task, slices, head_deferred=False):
     return stage
 
 
-def grad_bucket_plan(fp, stage, n_slices):
+def side_launch_groups(layer_begin, layer_end, side_layers):
+    """The layers whose weight + bias gradients each side launch of sitk_encoder_bwd_overlap carries (include/sitk.h, ABI 10):
+    launch i = layers layer_end - 1 - 2 i and layer_end - 2 - 2 i, the last one a single layer when the count is odd."""
+    s = min(side_layers, layer_end - layer_begin)
+    groups, top = [], layer_end
+    while layer_end - top < s:
+        n = min(2, s - (layer_end - top))
+        groups.append(list(range(top - n, top)))
+        top -= n
+    return groups
+
+
+def grad_write_stages_side(model, task, groups):
+    """The side-stream form's counterpart of grad_write_stages: stage i < len(groups) = behind side launch i (the Linear weights
+    and biases of its layers -- the launch writes nothing else); stage len(groups) = behind the finish stage: every LayerNorm
+    parameter (one reduction at the end of backward sums their partials), the layers whose weight gradients run in the tail
+    launch behind the chain, the patch embedding, cls_token, pos_embedding, mlp_head.* and, under MPP, to_original.* and
+    mask_token."""
+    sit = model.transformer if task == "mpp" else model
+    final = len(groups)
+    stage = {id(p): final for p in model.parameters()}
+    for i, layers in enumerate(groups):
+        for l in layers:
+            for name, p in sit.transformer.layers[l].named_parameters():
+                if ".norm." not in "." + name:
+                    stage[id(p)] = i
+    return stage
+
+
+def grad_bucket_plan(fp, stage, n_slices, limit=None):
     """All-reduce ranges of the flat gradient buffer per point of the step: plan[i] (i < n_slices - 1) is issued right
     after backward slice i, plan[n_slices - 1] after `_finish_backward` (the last slice's gradients travel with the
     finish stage: nothing is left to overlap them with).  Adjacent parameters of one point merge into one range (the
     alignment padding between them rides along), so every float of the buffer is reduced exactly once and never before
-    the kernel that writes it has been enqueued."""
+    the kernel that writes it has been enqueued.  limit: the floats from `limit` on belong to parameters the optimizer does not
+    touch (TrainEngine(optimize="sit")): they are not reduced."""
     last = n_slices - 1
     plan = [[] for _ in range(n_slices)]
     order = sorted(fp.params, key=lambda p: fp.offsets[id(p)][0])
+    limit = fp.total if limit is None else limit
     for k, p in enumerate(order):
         lo = fp.offsets[id(p)][0]
         hi = fp.offsets[id(order[k + 1])][0] if k + 1 < len(order) else fp.total
+        if lo >= limit:
+            continue
         pt = min(stage[id(p)], last)
         if plan[pt] and plan[pt][-1][1] == lo:
             plan[pt][-1] = (plan[pt][-1][0], hi)
@@ -147,6 +186,14 @@ class TrainEngine:
                   (bench.py's headline; -11 us per step): after load_batch() / step(x, ...) / device indices it has to wait
                   for that copy, which sits behind the whole previous step on the main stream -- no overlap, one more event
                   (bench.py reports this form too: also.new_batch_every_step).
+    optimize:     task='mpp' only.  'all' (default): the optimizer updates every parameter of the pre-training module that receives a
+                  gradient -- the encoder, the patch embedding, cls_token / pos_embedding AND the head of models/mpp.py:66,74
+                  (to_original.*, mask_token), i.e. torch.optim.X(ssl.parameters()).  'sit': the scope of the REFERENCE loop,
+                  tools/pretrain.py:267-280, which builds its optimizer over model.parameters() -- the SiT alone: to_original.* and
+                  mask_token keep their initial values for the whole run.  Their gradients are still produced (the
+                  weight-gradient launch and the column sums carry them) but neither applied nor all-reduced.  In BOTH modes
+                  mlp_head.* is left alone under MPP: its gradient is None in the reference (the head is not on the MPP path), and
+                  torch's optimizers skip such parameters -- momentum, weight decay and all.
     use_graph:    True = the step is replayed from hipGraph(s) (one per segment); False = eager launches.
                   None (default) with wgrad_overlap None: the faster of the two forms measured for the configuration --
                   eager + 8 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192); under a process
@@ -162,7 +209,7 @@ class TrainEngine:
     def __init__(self, model, batch_size, *, task="regression", input_layout="surface", loss="mse", optimizer="sgd",
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
-                 wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True):
+                 wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True, dp_channels=None, optimize=None):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -196,7 +243,8 @@ class TrainEngine:
         self.keep_grads = keep_grads
         # {lr, beta1^t, beta2^t, t} in device memory: read by the optimizer kernels, so captured graphs follow set_lr()
         self.hyper = torch.tensor([lr, 1.0, 1.0, 0.0], dtype=torch.float64, device=self.device)
-        # gradient elements the optimizer pass found not finite and skipped (device counter; `nonfinite_count` reads it)
+        # gradient elements the optimizer pass found not finite and skipped (device counter; `nonfinite_count` reads it).  The
+        # guard is on in the loss-scaled f16 mode only: bf16 / f32 behave like the reference's optimizer.step() (tools/train.py:291)
         self.nonfinite = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self.norm = None
         if normalise is not None:
@@ -217,7 +265,31 @@ class TrainEngine:
         self._unscale_in_place = keep_grads or self.dp
         self.nsteps = 0
 
-        self.fp = FlatParams(self.module, self.device, grad_extra=self.D * self.ld + 4 * _ALIGN + self.D)
+        # backward slices (last layer first) and the gradient ranges that become final after each
+        tr = sit.transformer
+        fused = self.dtype != rt.F32 and bool(rt.lib.sitk_mlp_fused_supported(self.D, tr.mlp_dim, self.dtype))
+        # Data parallelism on the 16-bit fused path, eager launches (the default there): the SAME launch sequence as on one GPU
+        # -- one backward call, the first 2 / 3 of the layers' weight gradients on the side stream, two layers per side launch,
+        # the rest in one tail launch behind the chain -- plus one all-reduce bucket per side launch: the library records an
+        # event behind each (sitk_overlap_wait_side_launch), and the flat buffers are ordered by write stage so that a
+        # launch's gradients are one contiguous range (round 4: two buckets, the first -- 58 % of the bytes -- final only 40 us
+        # after the chain; now the first 3.5 MB are final ~1.4 ms into a 2.4 ms step and the last bucket is the tail's).
+        self.dp_side = bool(self.dp and fused and wgrad_overlap is None and use_graph is not True and bwd_slices is None
+                            and tr.depth >= 2)
+        self._side_groups = side_launch_groups(0, tr.depth, min(tr.depth - 1, max(1, round(2 / 3 * tr.depth)))) if self.dp_side else []
+        if optimize not in (None, "all", "sit") or (optimize == "sit" and task != "mpp"):
+            raise rt.SitkError("TrainEngine: optimize is 'all' or 'sit' (task='mpp' only)")
+        self.optimize = (optimize or "all") if task == "mpp" else "all"
+        # parameters the optimizer pass does not touch live at the END of the flat buffers (see `optimize`)
+        frozen = set()
+        if task == "mpp":
+            frozen |= {id(p) for p in sit.mlp_head.parameters()}
+            if self.optimize == "sit":
+                frozen |= {id(p) for p in self.ssl.to_original.parameters()} | {id(self.ssl.mask_token)}
+        side_stage = grad_write_stages_side(self.module, task, self._side_groups) if self.dp_side else {}
+        self.fp = FlatParams(self.module, self.device, grad_extra=self.D * self.ld + 4 * _ALIGN + self.D,
+                             order=lambda p: (id(p) in frozen, side_stage.get(id(p), 0)))
+        self.n_opt = min([self.fp.offsets[i][0] for i in frozen], default=self.fp.total)
         dev, f32 = self.device, torch.float32
         B, P, N, D, K, ld = self.B, self.P, self.N, self.D, self.K, self.ld
         self.cfg = ops.encoder_cfg(B, N, D, tr.depth, tr.heads, tr.mlp_dim, self.dtype)
@@ -277,19 +349,9 @@ class TrainEngine:
         else:
             raise ValueError(optimizer)
 
-        # backward slices (last layer first) and the gradient ranges that become final after each
-        fused = self.dtype != rt.F32 and bool(rt.lib.sitk_mlp_fused_supported(self.D, tr.mlp_dim, self.dtype))
-        # Data parallelism on the 16-bit fused path, eager launches (the default there): TWO slices -- the first 2 / 3 of the
-        # layers, whose weight gradients all go to the side stream beside the rest of the chain exactly as on one GPU, and the
-        # rest, whose weight gradients run on the main stream behind the chain.  The first slice's bucket is all-reduced from the
-        # side stream's context (the process group's stream then waits for the side stream, the main chain for nothing), the
-        # second behind the finish stage.
-        self.dp_side = bool(self.dp and fused and wgrad_overlap is None and use_graph is not True and bwd_slices is None
-                            and tr.depth >= 2)
         if self.dp_side:
-            k = min(tr.depth - 1, max(1, round(2 / 3 * tr.depth)))
-            self.slices = [(tr.depth - k, tr.depth), (0, tr.depth - k)]
-            bwd_slices = 2
+            self.slices = [(0, tr.depth)]
+            bwd_slices = 1
         if bwd_slices is None:
             # every extra slice costs ~35 us (its own weight-gradient launch and reduction: 2.77 / 2.82 / 2.86 / 2.89 ms per
             # step for 1 / 2 / 3 / 4 slices, SiT-tiny B = 64) and hides that fraction of the gradient all-reduce less
@@ -309,10 +371,8 @@ class TrainEngine:
             # ms to enqueue a step of 2.5 ms, so eager launches cost nothing: 2.54 against 2.55 ms without the side stream)
             raise rt.SitkError("wgrad_overlap needs one GPU, one backward slice and eager launches (use_graph=False)")
         if self.dp_side:
-            wgrad_overlap = sum(le - lb for lb, le in self.slices[:-1])
-            max_side = max(le - lb for lb, le in self.slices)
-        else:
-            max_side = int(wgrad_overlap)
+            wgrad_overlap = sum(len(g) for g in self._side_groups)
+        max_side = int(wgrad_overlap)
         self.wgrad_overlap = int(wgrad_overlap)
         # workgroups of one side launch (two layers): 42 = the CUs the dim-192 chain's one-wave kernels leave idle
         self.wgrad_overlap_cus = int(wgrad_overlap_cus) if wgrad_overlap_cus else 42
@@ -330,17 +390,20 @@ class TrainEngine:
             self._tok_bufs = (self.tokens, torch.zeros_like(self.tokens))
             self._ev_gather, self._ev_inp, self._inp_dirty = torch.cuda.Event(), torch.cuda.Event(), False
         if self.dp_side:
-            # Bucket i of this form becomes final when the SIDE stream has finished slice i's weight gradients and LayerNorm
-            # reduction: an event recorded there right behind the slice's launches.  The all-reduce is issued from a small
-            # stream of its own that waits for THAT event only -- not from the side stream's context, whose tail by then holds
-            # later slices' work that waits for the end of the whole chain (the 58 % bucket could not start
-            # before all of backward had finished).
-            self._ev_slice = [torch.cuda.Event() for _ in self.slices[:-1]]
+            # Bucket i is final behind side launch i (an event the library records on the side stream); its all-reduce is issued
+            # from a small stream of its own that waits for THAT event only -- not from the side stream's context, whose tail by
+            # then holds later launches.  The one weight-gradient launch behind the chain leaves the channels' CUs free.
             self._ar_stream = torch.cuda.Stream(device=self.device)
+            self.dp_channels = int(dp_channels) if dp_channels else 16
+            rt.check(rt.lib.sitk_overlap_set_tail_cus(self._overlap, max(64, 256 - self.dp_channels)))
         if use_graph is None:
             use_graph = not self._overlap
-        self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices, head_deferred=self._head_deferred),
-                                           len(self.slices))
+        if self.dp_side:
+            self.bucket_plan = grad_bucket_plan(self.fp, side_stage, len(self._side_groups) + 1, limit=self.n_opt)
+        else:
+            self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices,
+                                                                           head_deferred=self._head_deferred), len(self.slices),
+                                                limit=self.n_opt)
         self.use_graph = use_graph
         self._graphs = None
         self._pending = []
@@ -523,8 +586,6 @@ class TrainEngine:
     def _backward_slice(self, lb, le):
         if lb == 0 and self.dx_c is not None:
             # the slice that ends at layer 0 also carries the patch embedding's weight gradient (one launch for all)
-            if self.dp_side:
-                rt.check(rt.lib.sitk_overlap_set_layers(self._overlap, 0))           # last slice: its weight gradients on the main stream
             lin = self.sit.to_patch_embedding[1]
             extra = None
             if self.task == "mpp":
@@ -535,13 +596,6 @@ class TrainEngine:
                 self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, lb, le, self.tokens, self.fp.g(lin.weight),
                 self.fp.g(lin.bias), self.dx_c, self.P, extra=extra,   # written straight into the (D, K) gradient (tokens: zero pad to ld)
                 overlap=self._overlap)
-            return
-        if self.dp_side:
-            rt.check(rt.lib.sitk_overlap_set_layers(self._overlap, le - lb))          # the whole slice beside the next slice's chain
-            rt.check(rt.lib.sitk_encoder_bwd_overlap(C.byref(self.cfg), self.Pa, self.Ga, self.x0.data_ptr(), self.dx.data_ptr(),
-                                                     self.acts.data_ptr(), self.acts.numel(), self.scratch.data_ptr(),
-                                                     self.scratch.numel(), lb, le, None, None, None, None, 0, None, self._overlap,
-                                                     self._s()))
             return
         ops.encoder_bwd(self.cfg, self.Pa, self.Ga, self.x0, self.dx, self.acts, self.scratch, layer_begin=lb, layer_end=le)
 
@@ -595,8 +649,9 @@ class TrainEngine:
 
     @property
     def nonfinite_count(self):
-        """Gradient elements skipped so far because they were not finite (a host read: syncs).  Not zero in f16 mode means an
-        intermediate overflowed behind the loss scale: the parameters are intact (the optimizer pass skips such elements)."""
+        """Gradient ELEMENTS skipped so far because they were not finite (a host read: syncs).  f16 mode only (always 0 in bf16 /
+        f32, which run unguarded like the reference): not zero means an intermediate overflowed behind the loss scale; the
+        parameters are intact (the optimizer pass skips such elements; the loss scale itself does not react)."""
         return int(self.nonfinite.item())
 
     def set_lr(self, lr):
@@ -611,17 +666,22 @@ class TrainEngine:
         # the gradients were already unscaled in place (kept gradients; data parallelism, where every rank has its own S)
         inv_s = self.gscale[1:2].data_ptr() if self.loss_scaled and not self._unscale_in_place else None
         zero = int(not self.keep_grads)
-        n_extra = fp.grad_all.numel() - fp.total if zero else 0
+        # the pass covers the first n_opt floats; the gradients of the parameters it leaves alone (behind them, see `optimize`)
+        # are cleared with the per-step accumulators, never applied
+        n = self.n_opt
+        n_extra = fp.grad_all.numel() - n if zero else 0
+        keep_idx = self._loss_extra_idx + (fp.total - n)
         keep_dst = self.loss.data_ptr() if zero else None
+        guard = self.nonfinite.data_ptr() if self.loss_scaled else None
         if o["kind"] == "sgd":
-            rt.check(L.sitk_sgd_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), rt.ptr(self.state[0]), fp.total,
+            rt.check(L.sitk_sgd_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), rt.ptr(self.state[0]), n,
                                          self.hyper.data_ptr(), o["momentum"], o["wd"], int(o["nesterov"]), scale, zero,
-                                         n_extra, self._loss_extra_idx, keep_dst, inv_s, self.nonfinite.data_ptr(), s))
+                                         n_extra, keep_idx, keep_dst, inv_s, guard, s))
         else:
             rt.check(L.sitk_adam_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), self.state[0].data_ptr(),
-                                          self.state[1].data_ptr(), fp.total, self.hyper.data_ptr(), o["betas"][0],
+                                          self.state[1].data_ptr(), n, self.hyper.data_ptr(), o["betas"][0],
                                           o["betas"][1], o["eps"], o["wd"], int(o["kind"] == "adamw"), scale, zero, n_extra,
-                                          self._loss_extra_idx, keep_dst, inv_s, self.nonfinite.data_ptr(), s))
+                                          keep_idx, keep_dst, inv_s, guard, s))
 
     # ---- segments: [fwd + loss + head/backward slice 0], [slice 1], ..., [finish + optimizer] ------------
     def _segment_fns(self):
@@ -745,25 +805,26 @@ class TrainEngine:
             return self.loss
         for i, fn in enumerate(segs):
             self._run(fn, i)
-            if i < len(segs) - 1 and self.dp_side:
-                self._ev_slice[i].record(self._side_torch)      # slice i's weight gradients + LayerNorm reduction end here
-            elif i < len(segs) - 1:
+            if i < len(segs) - 1:
                 for lo, hi in self.bucket_plan[i]:      # final now: reduce while the remaining slices run
                     self._allreduce(lo, hi)
         if self.dp_side:
-            # The early slices' weight gradients and LayerNorm reductions are on the SIDE stream: each bucket is reduced behind
-            # the event recorded there at the end of ITS slice (see __init__), so it runs beside the rest of the chain.  The
-            # collectives are ISSUED only now, behind the host's enqueue of the whole chain: should the process group's stream
-            # (or the small stream below) share a hardware queue with the main stream (ROCm maps streams of one priority onto
-            # few queues), its wait sits BEHIND the chain's launches in that queue instead of in front of them (issued right
-            # after the first slice it stalled the chain for 350 us: 3.14 ms per step).
-            for i in range(len(segs) - 1):
-                self._ar_stream.wait_event(self._ev_slice[i])
+            # The side launches' weight gradients are on the SIDE stream: each bucket is reduced behind the event the library
+            # recorded there at the end of ITS launch, so it runs beside the rest of the chain.  The collectives are ISSUED only
+            # now, behind the host's enqueue of the whole chain: should the process group's stream (or the small stream below)
+            # share a hardware queue with the main stream (ROCm maps streams of one priority onto few queues), its wait sits
+            # BEHIND the chain's launches in that queue instead of in front of them (issued right after the first slice it
+            # stalled the chain for 350 us: 3.14 ms per step).
+            n_side = rt.lib.sitk_overlap_side_launches(self._overlap)
+            if n_side != len(self._side_groups):
+                raise rt.SitkError(f"engine: {n_side} side launches, bucket plan built for {len(self._side_groups)}")
+            for i in range(n_side):
+                rt.check(rt.lib.sitk_overlap_wait_side_launch(self._overlap, i, self._ar_stream.cuda_stream))
                 with torch.cuda.stream(self._ar_stream):
                     for lo, hi in self.bucket_plan[i]:
                         self._allreduce(lo, hi)
         self._run(self._finish_backward, "finish")
-        for lo, hi in self.bucket_plan[len(segs) - 1]:  # the last slice's gradients + everything `finish` wrote
+        for lo, hi in self.bucket_plan[-1]:             # the last slice's gradients + everything `finish` wrote
             self._allreduce(lo, hi)
         for w in self._pending:
             w.wait()

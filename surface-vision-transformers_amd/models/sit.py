@@ -9,7 +9,8 @@ replaced by `Transformer` below, whose parameters keep the PreNorm-generation la
 (layers.i.0.norm / .0.fn.to_qkv / .0.fn.to_out.0 / .1.norm / .1.fn.net.0 / .1.fn.net.3).
 
 All arithmetic runs in libsitk.so (HIP, gfx950).  Additions over the reference API:
-  * `compute_dtype` ('bf16' default | 'f32'): MFMA operand type (see include/sitk.h);
+  * `compute_dtype` ('bf16' default | 'f16' | 'f32'): MFMA operand type (see include/sitk.h; 'f16' = the mode that meets
+    the reference-parity bar of 1e-3 at bf16 speed, backward on a loss-scaled gradient stream; 'f32' = verification mode);
   * forward also accepts a raw channels-last surface (B, 40962, C) and gathers the patches on the
     GPU (tools/preprocessing.py:74-84) with the table registered for (num_patches, num_vertices).
 There is no CPU forward: tensors must be on the GPU.

@@ -88,7 +88,9 @@ def stage_weight(w, dtype, ldc=None, want_c=True, want_t=True):
 def gemm_nt(A, W, out, dtype, M=None, N=None, K=None, epilogue=EPI_STORE, bias=None, aux=None, out2=None,
             amap=None, omap=None, auxmap=None):
     """out[m, n] = sum_k A[m, k] W[n, k] (+ epilogue).  A: compute dtype or fp32; W: compute dtype;
-    out: compute dtype or fp32.  2-D tensors with unit inner stride; leading dims from strides."""
+    out: compute dtype or fp32.  2-D tensors with unit inner stride; leading dims from strides.
+    EPI_BIAS_GELU (ABI 9): `out` receives gelu'(u) - 1/2 of u = acc + bias (the CENTRED derivative EPI_DGELU's `aux` expects),
+    NOT the pre-activation u; `out2` receives gelu(u)."""
     rt.require_cuda(A, W, out, bias, aux, out2)
     code = rt.dtype_code(dtype)
     d = rt.GemmDesc()
@@ -182,7 +184,8 @@ def mlp_fused_supported(D, M, dtype):
 
 def mlp_fwd(x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
     """out = x + gelu(LN(x) W1^T + b1) W2^T + b2; returns (out, h, mean, rstd, gd, g) (saved tensors or None):
-    gd = gelu'(u), g = gelu(u) of the pre-activation u = LN(x) W1^T + b1 (the derivative is saved, not u)."""
+    gd = gelu'(u) - 1/2 (CENTRED: backward multiplies by gd + 1/2), g = gelu(u) of the pre-activation u = LN(x) W1^T + b1
+    (ABI 9: the derivative is saved, not u -- a caller that reads `gd` as u gets wrong values)."""
     rt.require_cuda(x, ln_w, ln_b, w1_c, b1, w2_c, b2)
     rows, D = x.shape
     M = w1_c.shape[0]
@@ -192,12 +195,12 @@ def mlp_fwd(x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
     h = torch.empty((rows, D), dtype=td, device=x.device) if save else None
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
-    u = torch.empty((rows, M), dtype=td, device=x.device) if save else None
+    gd = torch.empty((rows, M), dtype=td, device=x.device) if save else None      # gelu'(u) - 1/2, not u (ABI 9)
     g = torch.empty((rows, M), dtype=td, device=x.device) if want_g else None
     rt.check(rt.lib.sitk_mlp_fwd(x.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(), w1_c.data_ptr(), b1.data_ptr(),
-                                 w2_c.data_ptr(), b2.data_ptr(), rt.ptr(h), rt.ptr(mean), rt.ptr(rstd), rt.ptr(u), rt.ptr(g),
+                                 w2_c.data_ptr(), b2.data_ptr(), rt.ptr(h), rt.ptr(mean), rt.ptr(rstd), rt.ptr(gd), rt.ptr(g),
                                  out.data_ptr(), rows, D, M, code, rt.stream_ptr()))
-    return out, h, mean, rstd, u, g
+    return out, h, mean, rstd, gd, g
 
 
 def attn_out_mlp_fused_supported(rows, D, I, M, dtype):
@@ -206,7 +209,7 @@ def attn_out_mlp_fused_supported(rows, D, I, M, dtype):
 
 def attn_out_mlp_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, save=True, want_g=False):
     """x_mid = x + o Wo^T + bo; out = x_mid + gelu(LN(x_mid) W1^T + b1) W2^T + b2.
-    Returns (out, xmid, h, mean, rstd, gd, g) (gd = gelu'(u), see mlp_fwd)."""
+    Returns (out, xmid, h, mean, rstd, gd, g) (gd = gelu'(u) - 1/2, see mlp_fwd)."""
     rt.require_cuda(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2)
     rows, D = x.shape
     M, I = w1_c.shape[0], o_c.shape[1]
@@ -216,17 +219,17 @@ def attn_out_mlp_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, dtype, sa
     h = torch.empty((rows, D), dtype=td, device=x.device) if save else None
     mean = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if save else None
-    u = torch.empty((rows, M), dtype=td, device=x.device) if save else None
+    gd = torch.empty((rows, M), dtype=td, device=x.device) if save else None      # gelu'(u) - 1/2, not u (ABI 9)
     g = torch.empty((rows, M), dtype=td, device=x.device) if want_g else None
     rt.check(rt.lib.sitk_attn_out_mlp_fwd(o_c.data_ptr(), wo_c.data_ptr(), bo.data_ptr(), x.data_ptr(), xmid.data_ptr(),
                                           ln_w.data_ptr(), ln_b.data_ptr(), w1_c.data_ptr(), b1.data_ptr(), w2_c.data_ptr(),
-                                          b2.data_ptr(), rt.ptr(h), rt.ptr(mean), rt.ptr(rstd), rt.ptr(u), rt.ptr(g),
+                                          b2.data_ptr(), rt.ptr(h), rt.ptr(mean), rt.ptr(rstd), rt.ptr(gd), rt.ptr(g),
                                           out.data_ptr(), rows, D, I, M, code, rt.stream_ptr()))
-    return out, xmid, h, mean, rstd, u, g
+    return out, xmid, h, mean, rstd, gd, g
 
 
 def attn_out_mlp_next_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, n_ln_w, n_ln_b, n_wqkv_c, dtype, want_g=False):
-    """attn_out_mlp_fwd + the next block's LayerNorm and to_qkv.  Returns (out, xmid, h, mean, rstd, u, g, n_h, n_mean,
+    """attn_out_mlp_fwd + the next block's LayerNorm and to_qkv.  Returns (out, xmid, h, mean, rstd, gd, g, n_h, n_mean,
     n_rstd, n_qkv)."""
     rows, D = x.shape
     M, I, N3 = w1_c.shape[0], o_c.shape[1], n_wqkv_c.shape[0]
@@ -236,19 +239,19 @@ def attn_out_mlp_next_fwd(o_c, wo_c, bo, x, ln_w, ln_b, w1_c, b1, w2_c, b2, n_ln
     out, xmid = torch.empty_like(x), torch.empty_like(x)
     h, n_h = torch.empty((rows, D), dtype=td, device=dev), torch.empty((rows, D), dtype=td, device=dev)
     mean, rstd, n_mean, n_rstd = (torch.empty(rows, dtype=torch.float32, device=dev) for _ in range(4))
-    u = torch.empty((rows, M), dtype=td, device=dev)
+    gd = torch.empty((rows, M), dtype=td, device=dev)      # gelu'(u) - 1/2 (ABI 9), not the pre-activation
     g = torch.empty((rows, M), dtype=td, device=dev) if want_g else None
     n_qkv = torch.empty((rows, N3), dtype=td, device=dev)
     rt.check(rt.lib.sitk_attn_out_mlp_next_fwd(
         o_c.data_ptr(), wo_c.data_ptr(), bo.data_ptr(), x.data_ptr(), xmid.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
         w1_c.data_ptr(), b1.data_ptr(), w2_c.data_ptr(), b2.data_ptr(), h.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-        u.data_ptr(), rt.ptr(g), out.data_ptr(), n_ln_w.data_ptr(), n_ln_b.data_ptr(), n_wqkv_c.data_ptr(), n_h.data_ptr(),
+        gd.data_ptr(), rt.ptr(g), out.data_ptr(), n_ln_w.data_ptr(), n_ln_b.data_ptr(), n_wqkv_c.data_ptr(), n_h.data_ptr(),
         n_mean.data_ptr(), n_rstd.data_ptr(), n_qkv.data_ptr(), N3, rows, D, I, M, code, rt.stream_ptr()))
-    return out, xmid, h, mean, rstd, u, g, n_h, n_mean, n_rstd, n_qkv
+    return out, xmid, h, mean, rstd, gd, g, n_h, n_mean, n_rstd, n_qkv
 
 
 def mlp_bwd(dy, dy_c, x, mean, rstd, ln_w, w2t_c, w1t_c, gd, dtype):
-    """gd = the gelu'(u) saved by the fused forward.  Returns (dx, dx_c, du, partials (workgroups, 2, D)).
+    """gd = the gelu'(u) - 1/2 saved by the fused forward.  Returns (dx, dx_c, du, partials (workgroups, 2, D)).
     dy_c = None: the kernel rounds dy itself and also returns the compute-dtype copy it wrote (sitk_mlp_bwd_cast):
     (dx, dx_c, du, partials, dy_c)."""
     rows, D = x.shape

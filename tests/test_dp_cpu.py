@@ -88,6 +88,80 @@ def test_bucket_plan_reduces_every_gradient_once_and_only_after_it_is_written(ta
         assert not any(a <= lo < b for a, b in plan[0]), "to_original reduced with slice 0 again"
 
 
+@pytest.mark.parametrize("optimize", ["all", "sit"])
+@pytest.mark.parametrize("task", ["regression", "mpp"])
+@pytest.mark.parametrize("depth,side", [(12, 8), (4, 3), (2, 1), (6, 4)])
+def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, depth, side, optimize):
+    """Round 5: the data-parallel form of the fused path all-reduces one bucket per SIDE LAUNCH of
+    sitk_encoder_bwd_overlap.  The spec, restated from include/sitk.h (ABI 10) and csrc/encoder.hip's launch order, not from
+    sitk.engine: side launch i carries the Linear weight + bias gradients of layers depth - 1 - 2 i and depth - 2 - 2 i (a
+    single layer last when `side` is odd); every LayerNorm parameter, the tail launch's layers, the patch embedding,
+    cls_token, pos_embedding, mlp_head.*, to_original.*, mask_token are final only behind the finish stage.  Checks: (a) the
+    flat buffer ordered by write stage makes every bucket ONE contiguous range; (b) ranges are disjoint and cover [0, n_opt);
+    (c) no parameter sits in a bucket issued before its writer; (d) parameters outside the optimizer's scope are not reduced."""
+    import sitk  # noqa: F401
+    from sitk import engine
+    if optimize == "sit" and task != "mpp":
+        pytest.skip("optimize='sit' is an MPP option")
+    ssl = _mpp_module(depth)
+    module = ssl if task == "mpp" else ssl.transformer
+    sit = ssl.transformer
+    groups = engine.side_launch_groups(0, depth, side)
+    want_groups, top = [], depth
+    while depth - top < side:
+        n = min(2, side - (depth - top))
+        want_groups.append(list(range(top - n, top)))
+        top -= n
+    assert groups == want_groups and sum(len(g) for g in groups) == side
+    stage = engine.grad_write_stages_side(module, task, groups)
+    frozen = set()
+    if task == "mpp":
+        frozen |= {id(p) for p in sit.mlp_head.parameters()}
+        if optimize == "sit":
+            frozen |= {id(p) for p in ssl.to_original.parameters()} | {id(ssl.mask_token)}
+    fp = engine.FlatParams(module, "cpu", order=lambda p: (id(p) in frozen, stage[id(p)]))
+    n_opt = min([fp.offsets[i][0] for i in frozen], default=fp.total)
+    plan = engine.grad_bucket_plan(fp, stage, len(groups) + 1, limit=n_opt)
+    assert len(plan) == len(groups) + 1
+    assert all(len(rs) == 1 for rs in plan), plan                                                   # (a)
+    flat_ranges = sorted(r for point in plan for r in point)
+    assert flat_ranges[0][0] == 0 and flat_ranges[-1][1] == n_opt
+    assert all(a[1] == b[0] for a, b in zip(flat_ranges, flat_ranges[1:])), flat_ranges              # (b)
+    prefix = "transformer." if task == "mpp" else ""
+    for name, p in module.named_parameters():
+        lo, n = fp.offsets[id(p)]
+        if id(p) in frozen:
+            assert lo >= n_opt, name                                                                # (d)
+            continue
+        point = next(i for i, rs in enumerate(plan) if any(a <= lo and lo + n <= b for a, b in rs))
+        short = name.removeprefix(prefix)
+        writer = len(groups)                                     # finish stage
+        if short.startswith("transformer.layers.") and ".norm." not in short:
+            layer = int(short.split(".")[2])
+            writer = next((i for i, g in enumerate(groups) if layer in g), len(groups))
+        assert point == writer, (name, point, writer)                                               # (c) (and not late either)
+    if task == "mpp" and optimize == "all":
+        assert fp.offsets[id(ssl.to_original.weight)][0] < n_opt
+
+
+def test_flat_params_order_keeps_module_views_and_values():
+    """FlatParams(order=...) only permutes the flat storage: every parameter keeps its values and is a view of its own range."""
+    import sitk  # noqa: F401
+    from sitk import engine
+    ssl = _mpp_module(2)
+    before = {n: p.detach().clone() for n, p in ssl.named_parameters()}
+    names = {id(p): n for n, p in ssl.named_parameters()}
+    fp = engine.FlatParams(ssl, "cpu", order=lambda p: -len(names[id(p)]))
+    assert fp.still_flat()
+    seen = torch.zeros(fp.total, dtype=torch.bool)
+    for n, p in ssl.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+        o, k = fp.offsets[id(p)]
+        assert not bool(seen[o:o + k].any())
+        seen[o:o + k] = True
+        assert p.grad.data_ptr() == fp.grad.data_ptr() + 4 * o
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

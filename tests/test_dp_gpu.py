@@ -289,7 +289,8 @@ def _worker4(rank, world, port, q):
     shard = slice(rank * B4 // world, (rank + 1) * B4 // world)
     eng = engine.TrainEngine(_make4(), B4 // world, input_layout="surface", lr=LR4, momentum=0.9, process_group=dist.group.WORLD,
                              device="cuda:0")
-    assert eng.dp_side and not eng.use_graph and eng._prefetch        # two slices, side stream, prefetched gather
+    assert eng.dp_side and not eng.use_graph and eng._prefetch        # one bucket per side launch, prefetched gather
+    assert eng._side_groups == [[4, 5], [2, 3]] and len(eng.bucket_plan) == 3
     for _ in range(3):
         eng.step(x[shard].cuda(), y[shard].cuda())
     torch.cuda.synchronize()
@@ -300,8 +301,8 @@ def _worker4(rank, world, port, q):
 
 
 def test_two_rank_side_stream_form_matches_single_process_full_batch():
-    """The data-parallel form bench.py runs on N GPUs (dim 192, bf16: two backward slices, the first one's weight gradients and
-    its bucket's all-reduce on the side stream, raw-surface gather prefetched) on 2 ranks over gloo against the one-GPU engine
+    """The data-parallel form bench.py runs on N GPUs (dim 192, bf16: the one-GPU launch sequence, one all-reduce bucket behind
+    each side launch of weight gradients + the final one, raw-surface gather prefetched) on 2 ranks over gloo against the one-GPU engine
     on the whole batch, after 3 steps, per tensor relative to its update."""
     import sitk  # noqa: F401
     from sitk import engine
@@ -455,8 +456,8 @@ def test_one_rank_rccl_group_runs_the_data_parallel_step(task, use_graph):
     assert err < 1e-6, err
 
 
-# ---- the data-parallel form WITH the side stream (16-bit fused path, the default there): two slices; the first one's weight
-# gradients run on the side stream and its bucket is all-reduced from that stream's context
+# ---- the data-parallel form WITH the side stream (16-bit fused path, the default there): the one-GPU launch sequence; every
+# side launch of weight gradients is one bucket, all-reduced behind the event the library records on the side stream
 KW320 = dict(sit_oracle.MODEL_SIZES["tiny"], depth=4, num_patches=320, num_vertices=153, num_channels=4)
 B320 = 8          # 8 x 321 = 2 568 tokens: enough for the large-tile weight-gradient path the side stream uses
 LR320 = 0.002     # (a step size at which three steps of this model descend: at 0.05 the loss explodes and amplifies every rounding)
@@ -486,12 +487,14 @@ def _rccl_side_worker(port, dtype, q):
     x, y = _data320()
     eng = engine.TrainEngine(_make_model320(dtype), B320, input_layout="patched", lr=LR320, momentum=0.9,
                              process_group=dist.group.WORLD, device="cuda:0")
-    assert eng.dp and eng.dp_side and not eng.use_graph and eng.slices == [(1, 4), (0, 1)] and eng.wgrad_overlap == 3
+    # one backward call, layers 3, 2 and 1 on the side stream in two side launches = two early buckets + the final one
+    assert eng.dp and eng.dp_side and not eng.use_graph and eng.slices == [(0, 4)] and eng.wgrad_overlap == 3
+    assert eng._side_groups == [[2, 3], [1]] and len(eng.bucket_plan) == 3 and all(len(b) == 1 for b in eng.bucket_plan)
     losses = []
     for _ in range(3):
         losses.append(float(eng.step(x.cuda(), y.cuda())))
     torch.cuda.synchronize()
-    q.put((eng.fp.flat.cpu().numpy(), losses))
+    q.put(({n: t.detach().cpu().numpy() for n, t in eng.module.named_parameters()}, losses))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -510,15 +513,24 @@ def test_one_rank_rccl_group_with_side_stream_matches_plain_engine(dtype):
     x, y = _data320()
     model = _make_model320(dtype)
     init = {n: t.detach().clone() for n, t in model.named_parameters()}
-    ref = engine.TrainEngine(model, B320, input_layout="patched", lr=LR320, momentum=0.9, use_graph=True, device="cuda:0")
+    # (1) against the one-GPU engine's DEFAULT form -- eager, the same three layers on the side stream: the data-parallel form
+    # is that launch sequence plus the buckets' all-reduces (a copy on a one-rank group), in flat buffers of another order:
+    # every parameter must come out BIT-EQUAL after three steps
+    ref = engine.TrainEngine(model, B320, input_layout="patched", lr=LR320, momentum=0.9, device="cuda:0")
+    assert ref._overlap and ref.wgrad_overlap == 3 and not ref.use_graph
     want_losses = [float(ref.step(x.cuda(), y.cuda())) for _ in range(3)]
-    assert max(abs(a - b) / abs(b) for a, b in zip(losses, want_losses)) < 1e-4, (losses, want_losses)
-    got = torch.from_numpy(got)
+    assert losses == want_losses, (losses, want_losses)
     for n, t in ref.module.named_parameters():
-        o, k = ref.fp.offsets[id(t)]
+        assert torch.equal(torch.from_numpy(got[n]), t.detach().cpu()), n
+    # (2) against the hipGraph form without a side stream: same operands, same kernels; the weight-gradient tiles sum their
+    # tokens in another order (whole-token tiles on the side stream against token-split tiles + slab) and three steps feed the
+    # differences back through 16-bit roundings
+    model2 = _make_model320(dtype)
+    ref2 = engine.TrainEngine(model2, B320, input_layout="patched", lr=LR320, momentum=0.9, use_graph=True, device="cuda:0")
+    want_losses = [float(ref2.step(x.cuda(), y.cuda())) for _ in range(3)]
+    assert max(abs(a - b) / abs(b) for a, b in zip(losses, want_losses)) < 1e-4, (losses, want_losses)
+    for n, t in ref2.module.named_parameters():
         want = t.detach().cpu().double().reshape(-1)
         upd = float((want - init[n].double().reshape(-1)).norm())
-        err = float((got[o:o + k].double() - want).norm())
-        # same operands, same kernels; the weight-gradient tiles sum their tokens in another order (whole-token tiles on the side
-        # stream against token-split tiles + slab) and three steps feed the differences back through 16-bit roundings
+        err = float((torch.from_numpy(got[n]).double().reshape(-1) - want).norm())
         assert err < 2e-2 * upd + 2.4e-7 * float(want.norm()), (n, err / max(upd, 1e-30))

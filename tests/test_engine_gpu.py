@@ -122,6 +122,65 @@ def test_mpp_engine_gradients_match_autograd_path(pk, dtype):
     assert all(np.isfinite(ls)) and np.mean(ls[-3:]) < np.mean(ls[:3]), ls
 
 
+@pytest.mark.parametrize("dtype,optimizer", [("f32", "sgd"), ("bf16", "sgd"), ("f32", "adamw")])
+def test_mpp_engine_optimizer_scope_of_the_reference_loop(pk, dtype, optimizer):
+    """tools/pretrain.py:267-280 builds its optimizer over `model.parameters()` -- the SiT -- so
+    `to_original.*` and `mask_token` (models/mpp.py:66,74) keep their initial values for the whole run, and `mlp_head.*` (not on
+    the MPP path: grad None) is skipped by torch's optimizers, weight decay and all.  TrainEngine(task='mpp', optimize='sit')
+    is that loop: three steps with weight decay > 0 against the module path + torch.optim.X(model.parameters()) replaying the
+    engine's draws -- the SiT's parameters follow, `to_original.*`, `mask_token`, `mlp_head.*` stay BIT-unchanged.
+    optimize='all' (the default) updates the MPP head too (and still leaves mlp_head alone)."""
+    sit, mpp, engine = pk
+    B, P, V = 3, 320, 153
+    lr, wd = 0.02, 0.05
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], depth=2, num_patches=P, num_vertices=V, num_channels=4)
+    ssl = mpp.masked_patch_pretraining(sit.SiT(**kw, compute_dtype=dtype), 192, 4 * V, "cpu", mask_prob=0.75,
+                                       replace_prob=0.8, swap_prob=0.02, channels=4, num_vertices=V)
+    _load(ssl, 5)
+    init = {k: p.detach().clone() for k, p in ssl.named_parameters()}
+    ref = copy.deepcopy(ssl).to(DEV)
+    ssl_all = copy.deepcopy(ssl)
+    x = torch.from_numpy(detgen.normal("me/x", (B, 40962, 4), seed=1)).to(DEV)
+    if optimizer == "sgd":
+        opt = torch.optim.SGD(ref.transformer.parameters(), lr=lr, momentum=0.9, weight_decay=wd)
+        ekw = dict(optimizer="sgd", momentum=0.9, weight_decay=wd)
+    else:
+        opt = torch.optim.AdamW(ref.transformer.parameters(), lr=lr, weight_decay=wd)
+        ekw = dict(optimizer="adamw", weight_decay=wd)
+    eng = engine.TrainEngine(ssl, B, task="mpp", input_layout="surface", lr=lr, use_graph=False, optimize="sit", **ekw)
+    assert eng.n_opt < eng.fp.total
+    lerr = 0.0
+    for _ in range(3):
+        l_eng = float(eng.step(x))
+        rnd = {k: v.clone() for k, v in eng.last_randoms.items()}
+        opt.zero_grad()
+        l_ref, _ = ref(x, randoms=rnd)
+        l_ref.backward()
+        opt.step()
+        lerr = max(lerr, abs(l_eng - float(l_ref)) / float(l_ref))
+    check(f"engine/mpp_sit_scope_{optimizer}", "loss", dtype, lerr, "out")
+    frozen = ("to_original.", "mask_token", "transformer.mlp_head.")
+    worst = (0.0, "")
+    for (k, p), (_, q) in zip(ssl.named_parameters(), ref.named_parameters()):
+        if k.startswith(frozen):
+            assert torch.equal(p.detach().cpu(), init[k]), f"{k} moved under optimize='sit'"
+            assert torch.equal(q.detach().cpu(), init[k]), f"{k} moved on the reference-style module path"
+            continue
+        upd = q.detach().cpu() - init[k]
+        assert float(upd.abs().max()) > 0, k
+        worst = max(worst, (rel(p.detach().cpu() - init[k], upd), k))
+    print("worst parameter update:", worst)
+    check(f"engine/mpp_sit_scope_{optimizer}", "update_rel", dtype, worst[0], "grad")
+    assert float(eng.fp.grad_all.abs().max()) == 0.0              # the frozen parameters' gradients are cleared with the rest
+    # optimize='all': the head of models/mpp.py moves, mlp_head still does not
+    eng_all = engine.TrainEngine(ssl_all, B, task="mpp", input_layout="surface", lr=lr, use_graph=False, **ekw)
+    assert eng_all.optimize == "all"
+    eng_all.step(x)
+    for k, p in ssl_all.named_parameters():
+        moved = not torch.equal(p.detach().cpu(), init[k])
+        assert moved == (not k.startswith("transformer.mlp_head.")), (k, moved)
+
+
 @pytest.mark.parametrize("mode", ["graph", "side_stream"])
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_engine_bench_config_matches_autograd_path(pk, dtype, mode):
@@ -163,6 +222,47 @@ def test_engine_bench_config_matches_autograd_path(pk, dtype, mode):
     print("worst parameter update:", worst)
     check("engine/bench_tiny_b64", "update_rel", dtype, worst[0], "grad")
     assert eng.fp.still_flat()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_engine_bench_config_against_cpu_oracle(pk, dtype):
+    """VERDICT r4 next 2(a) / ADVICE: the BENCHMARKED configuration itself -- SiT-tiny, depth 12, 320 patches, B = 64, raw
+    (B, 40962, 4) surfaces, the engine's DEFAULT launch form (16-bit: eager, 8 layers' weight gradients on the side stream, the
+    chained `d to_qkv` + MLP backward and merged attention backward launches, prefetched gather) -- ONE step with kept
+    gradients against oracle/sit_oracle.py on the CPU on the same batch: the reference's loop body, tools/train.py:280-291
+    (forward, MSE, backward).  Until round 5 this configuration met the oracle at B = 4 only (golden tiny320_cls) and the engine
+    at B = 64 only another HIP path.  Bars: f32 2e-4 / 1e-3; f16 north_star's fixed 1e-3 on the loss, on every gradient's NORM
+    and on every gradient element-wise (relative to the tensor); bf16 under its recorded bars and fixed ceilings."""
+    sit, _, engine = pk
+    B = 64
+    kw = dict(sit_oracle.MODEL_SIZES["tiny"], num_patches=320, num_vertices=153, num_channels=4)
+    m = sit.SiT(**kw, compute_dtype=dtype)
+    _load(m, 21)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((B, 40962, 4), generator=g)
+    y = torch.randn((B,), generator=g) * 2 + 40
+    ref = sit_oracle.SiT(**kw)
+    ref.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+    from sitk import tables
+    table = tables.load_table(320, 153)                                                 # (P, V) uint16, sha-pinned to the reference CSV
+    tok = torch.from_numpy(sit_oracle.gather_tokens(x.numpy(), table))                  # (B, P, V * C), f = v * C + c
+    xp = tok.reshape(B, 320, 153, 4).permute(0, 3, 1, 2).contiguous()                   # the reference's (B, C, P, V) input
+    l_ref, g_ref = _oracle_grads_cpu(ref, lambda mod: torch.nn.functional.mse_loss(mod(xp).squeeze(-1), y))
+    eng = engine.TrainEngine(m, B, input_layout="surface", lr=0.0, momentum=0.0, keep_grads=True)
+    if dtype != "f32":
+        assert eng._overlap and not eng.use_graph and eng.wgrad_overlap == 8 and eng._prefetch, "not the benchmarked launch form"
+    loss = float(eng.step(x.to(DEV), y.to(DEV)))
+    case = "engine/bench_tiny_b64_oracle"
+    check(case, "loss", dtype, abs(loss - l_ref) / abs(l_ref), "loss")
+    worst_n, worst_e = (0.0, ""), (0.0, "")
+    for k, p in m.named_parameters():
+        gn, rn = float(p.grad.double().norm()), float(g_ref[k].double().norm())
+        worst_n = max(worst_n, (abs(gn - rn) / rn, k))
+        worst_e = max(worst_e, (rel(p.grad, g_ref[k]), k))
+    print("worst gradient norm:", worst_n, " worst gradient (element-wise, relative to the tensor):", worst_e)
+    check(case, "gnorm", dtype, worst_n[0], "grad")
+    check(case, "grad_rel", dtype, worst_e[0], "grad")
+    assert eng.nonfinite_count == 0
 
 
 @pytest.mark.parametrize("mode", ["graph", "side_stream"])
@@ -343,9 +443,7 @@ def test_optimizer_skips_and_counts_nonfinite_gradients(pk, optimizer):
     if optimizer == "sgd":
         rt.check(rt.lib.sitk_sgd_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), n, hyper.data_ptr(), 0.9, 0.0, 0, 1.0, 1, 0, -1,
                                           None, None, cnt.data_ptr(), rt.stream_ptr()))
-        bad = torch.zeros(n, dtype=torch.bool, device=DEV)
-        for i in (5, 1000, 4100):
-            bad[i // 4 * 4:i // 4 * 4 + 4] = True                # SGD skips the 16-byte vector the element sits in
+        bad = ~torch.isfinite(gref)                              # per ELEMENT (ABI 10; ABI 9 skipped the 16-byte vector)
         ref = p0 - 0.1 * gref
         assert int(cnt) == 3
     else:
@@ -358,6 +456,18 @@ def test_optimizer_skips_and_counts_nonfinite_gradients(pk, optimizer):
     assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(m).all())
     assert float((p[~bad] - ref[~bad]).abs().max()) < 1e-4
     assert float(g.abs().max()) == 0.0                            # consumed gradients are zeroed, the skipped ones too
+    # nonfinite = NULL (what the engine passes in bf16 / f32): no guard, like optimizer.step() of tools/train.py:291 -- the
+    # non-finite elements reach their parameters (and only theirs)
+    p, g, m, v = p0.clone(), gref.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    hyper = torch.tensor([0.1, 1.0, 1.0, 0.0], dtype=torch.float64, device=DEV)
+    if optimizer == "sgd":
+        rt.check(rt.lib.sitk_sgd_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), n, hyper.data_ptr(), 0.9, 0.0, 0, 1.0, 1, 0, -1,
+                                          None, None, None, rt.stream_ptr()))
+    else:
+        rt.check(rt.lib.sitk_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, hyper.data_ptr(), 0.9, 0.999,
+                                           1e-8, 0.0, 0, 1.0, 1, 0, -1, None, None, None, rt.stream_ptr()))
+    assert not bool(torch.isfinite(p[bad]).any()) and bool(torch.isfinite(p[~bad]).all())
+    assert float((p[~bad] - ref[~bad]).abs().max()) < 1e-4
 
 
 @pytest.mark.parametrize("optimizer", ["sgd", "adam", "adamw"])

@@ -344,8 +344,10 @@ def _attn_ref(qkv, B, N, H, scale):
                                    # tails (N % 64 = 1, 20, 0, 63, 33), several (batch, head) pairs; above 2048: tiled kernels
                                    (2, 1281, 6), (1, 385, 2), (1, 500, 1), (2, 640, 2), (1, 1023, 1), (1, 2048, 1), (1, 1313, 3),
                                    (1, 2100, 1),
-                                   # unit-packed kernels (h16, 320 < N <= 336): workgroups of one and of two heads, a padding
-                                   # wave (3 x 21 = 63 units), every width's head count, all tails of the last 16-row block
+                                   # 320 < N <= 336 (the 321-token configurations; sequence-resident kernels): every width's
+                                   # head count, several samples, all tails of the last 16-row block.  (The shapes were added for
+                                   # round 4's unit-packed experiment -- csrc/experimental/attn_pk.inc, diagnostic build only,
+                                   # SITK_ATTN_PK=1 -- and exercise the shipped kernels' partial last tile.)
                                    (5, 321, 3), (2, 321, 6), (1, 321, 12), (3, 330, 3), (2, 336, 2), (1, 322, 1), (2, 321, 1)])
 def test_attention_fwd_bwd(ops, dtype, B, N, H):
     td = tdt(dtype)

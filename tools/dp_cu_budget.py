@@ -4,10 +4,13 @@ a copy -- the 2.46 ms "per-rank" step says nothing about the CUs and the time a 
 The data-parallel form of the step on a ONE-rank RCCL group (every collective on the real backend), plus, behind every
 bucket's all-reduce and ordered exactly like it (a high-priority stream that waits for the stream the collective was issued
 from; the step's main stream waits for it where it waits for the collective), a DUMMY kernel of `--channels` workgroups x 512
-threads that holds its CUs for the time the bucket needs on the wire: bytes / (--gbs GB/s) (22 MB in
-~0.25 ms per ring = 88 GB/s; the mesh algorithm is ~7x faster).  Needs the diagnostic build:
+threads that holds its CUs for the time the bucket needs on the wire: --latency-us + bytes / (--gbs GB/s) (SURVEY section 5:
+22 MB in ~0.25 ms per ring = 88 GB/s; the mesh algorithm is ~7x faster; 30 us for the launch + the ring's hops of a small
+message).  Round 5: the stand-in has the footprint of RCCL's own kernel on gfx950 (256 threads, 19 744 B of LDS, 280 registers:
+csrc/core.hip), the step is the per-side-launch bucket form, and `--side-cus` / `--channels` take lists to sweep.  Needs the
+diagnostic build:
 
-    SITK_LIB=$PWD/surface-vision-transformers_amd/libsitk_ab.so python tools/dp_cu_budget.py [--channels 32 --gbs 88]
+    SITK_LIB=$PWD/surface-vision-transformers_amd/libsitk_ab.so python tools/dp_cu_budget.py [--channels 16 --side-cus 42,34,26]
 """
 import argparse
 import ctypes
@@ -36,7 +39,10 @@ class _Both:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--channels", type=int, default=32)
+    ap.add_argument("--channels", default="16", help="comma list: workgroups of the stand-in = NCCL_MAX_NCHANNELS the engine plans for")
+    ap.add_argument("--side-cus", default="42", help="comma list: workgroups of one side launch of weight gradients")
+    ap.add_argument("--latency-us", type=float, default=30.0, help="fixed part of a bucket's stand-in time")
+    ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--gbs", type=float, default=88.0, help="wire rate of one bucket's all-reduce, GB/s of gradient bytes")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--prio", type=int, default=0, help="priority of the stream the dummy runs on (0 = default, like the process group of bench.py; -1 = high)")
@@ -45,7 +51,9 @@ def main():
     os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
-    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(a.channels))
+    chans = [int(c) for c in a.channels.split(",")]
+    sides = [int(c) for c in a.side_cus.split(",")]
+    os.environ.setdefault("NCCL_MAX_NCHANNELS", str(max(chans)))
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     dist.init_process_group("nccl", device_id=dev, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=False))
@@ -54,25 +62,27 @@ def main():
     lib.sitk_debug_occupy.restype = ctypes.c_int
     hp = torch.cuda.Stream(device=dev, priority=a.prio)
     B = 64
-    res = {}
-    for mode in ("collective only", "collective + dummy channels"):
+    print(f"# stand-in: latency {a.latency_us:.0f} us + bytes / {a.gbs:.0f} GB/s per bucket, stream priority {a.prio}, {a.steps} steps, {a.dtype}")
+    for side in sides:
+      for ch in [0] + chans:
         torch.manual_seed(1234)
         model = SiT(dim=192, depth=12, heads=3, mlp_dim=768, dim_head=64, num_patches=320, num_vertices=153, num_channels=4,
-                    compute_dtype="bf16")
-        eng = engine.TrainEngine(model, B, input_layout="surface", lr=1e-5, momentum=0.9, process_group=dist.group.WORLD, device=dev)
-        assert eng.dp_side, "expected the two-slice side-stream form"
-        if mode != "collective only":
+                    compute_dtype=a.dtype)
+        eng = engine.TrainEngine(model, B, input_layout="surface", lr=1e-5, momentum=0.9, process_group=dist.group.WORLD, device=dev,
+                                 wgrad_overlap_cus=side, dp_channels=(ch or chans[0]))
+        assert eng.dp_side, "expected the side-stream form"
+        log = []
+        if ch:
             orig = eng._allreduce
-            log = []
 
-            def wrapped(lo, hi, orig=orig, eng=eng, log=log):
+            def wrapped(lo, hi, orig=orig, eng=eng, log=log, ch=ch):
                 n0 = len(eng._pending)
                 orig(lo, hi)
-                us = max(1, int((hi - lo) * 4 / (a.gbs * 1e3)))
+                us = max(1, int(a.latency_us + (hi - lo) * 4 / (a.gbs * 1e3)))
                 ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
                 ev0.record(torch.cuda.current_stream())
                 hp.wait_event(ev0)
-                assert lib.sitk_debug_occupy(a.channels, us, hp.cuda_stream) == 0
+                assert lib.sitk_debug_occupy(ch, us, hp.cuda_stream) == 0
                 ev1.record(hp)
                 eng._pending[n0] = _Both(eng._pending[n0], ev1)
                 log.append(((hi - lo) * 4, us))
@@ -92,14 +102,14 @@ def main():
             if i % 10 == 9:
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
-        res[mode] = (time.perf_counter() - t0) / a.steps * 1e3
-        extra = ""
-        if mode != "collective only":
-            per = log[-len(eng.bucket_plan[0]) - len(eng.bucket_plan[1]):]
-            extra = "  buckets (bytes, dummy us): " + ", ".join(f"({b}, {u})" for b, u in per)
-        print(f"{mode:30s}: {res[mode]:.3f} ms per step (host enqueue {host / a.steps * 1e3:.3f} ms){extra}", flush=True)
-    print(f"dummy all-reduce channels ({a.channels} workgroups x 512 threads at {a.gbs:.0f} GB/s) cost "
-          f"{(res['collective + dummy channels'] - res['collective only']) * 1e3:+.0f} us per step")
+        ms = (time.perf_counter() - t0) / a.steps * 1e3
+        if not ch:
+            base = ms
+        nb = sum(len(b) for b in eng.bucket_plan)
+        extra = "  buckets (bytes, stand-in us): " + ", ".join(f"({b}, {u})" for b, u in log[-nb:]) if ch else ""
+        print(f"side launch {side:3d} workgroups, stand-in {ch:2d} channels: {ms:.3f} ms per step ({(ms - base) * 1e3:+5.0f} us; host enqueue "
+              f"{host / a.steps * 1e3:.3f} ms){extra}", flush=True)
+        del eng, model
     dist.destroy_process_group()
 
 

@@ -43,7 +43,7 @@ def main():
          2.0 * R * M * D, R * (D + 2 * M) * 2),
         ("net.3 + res   (N=D, K=M, fp32 out)", lambda s: ops.gemm_nt(s["u"], s["w2"], s["ox"], dt, epilogue=ops.EPI_BIAS_RES, bias=s["bD"], aux=s["x32"]),
          2.0 * R * D * M, R * (M * 2 + 8 * D)),
-        ("d net.3 gelu' (N=M, K=D, reads u)", lambda s: ops.gemm_nt(s["h"], s["w2_t"], s["ou"], dt, epilogue=ops.EPI_DGELU, aux=s["u"]),
+        ("d net.3 gelu' (N=M, K=D, reads gd = gelu'(u) - 1/2)", lambda s: ops.gemm_nt(s["h"], s["w2_t"], s["ou"], dt, epilogue=ops.EPI_DGELU, aux=s["u"]),
          2.0 * R * D * M, R * (D + 2 * M) * 2),
         ("d net.0       (N=D, K=M, store)", lambda s: ops.gemm_nt(s["u"], s["w1_t"], s["oh"], dt), 2.0 * R * D * M, R * (M + D) * 2),
         ("d to_out      (N=I, K=D, store)", lambda s: ops.gemm_nt(s["h"], s["wo"].t().contiguous() if False else s["wo"], s["oh"], dt),
