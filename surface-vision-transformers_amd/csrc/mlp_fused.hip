@@ -778,6 +778,8 @@ __global__ __launch_bounds__(128 * TG) void mlp_kernel(MlpParams p) {
 // workgroup the same 96 rows, and everything the second reads of the first's output (dx fp32 and its compute-dtype copy) are
 // that workgroup's OWN rows: behind a workgroup barrier they come back from this XCD's L2 instead of crossing HBM, and the
 // chain has one launch boundary per layer less.  12 waves x 16 tokens only (the geometry of the one-round shapes).
+// The caller may ALIAS p1's dres (read by the first half) with p2's dx_mid output (written by the second): both halves own the
+// same rows, and the second half starts behind the drain + barrier below (csrc/encoder.hip passes S.dxB for both).
 __global__ __launch_bounds__(768) void ln_gemm_mlp_bwd_kernel(LnGemmParams p1, MlpParams p2) {
   static_assert(lg_bwd_smem<6, 1>() <= MLP_SMEM, "LDS plan");
   __shared__ __attribute__((aligned(256))) char smem[MLP_SMEM];
