@@ -396,14 +396,15 @@ int sitk_overlap_set_layers(sitk_overlap* o, int layers);
 int sitk_overlap_fork(sitk_overlap* o, sitk_stream_t stream);
 int sitk_overlap_join(sitk_overlap* o, sitk_stream_t stream);
 /* Data parallelism (ABI 10; the reference has none: tools/train.py:72 picks one device).  A call of sitk_encoder_bwd_overlap
- * over layers [layer_begin, layer_end) with s = min(`layers`, layer_end - layer_begin) side layers makes ceil(s / 2) side
- * launches: launch i carries the weight + bias gradients (to_qkv, to_out, net.0, net.3 -- NOT the LayerNorm parameters, which
- * one reduction at the end of the call finishes) of layers layer_end - 1 - 2 i and layer_end - 2 - 2 i (the last launch holds
- * one layer when s is odd).  Behind each launch and its slab reduction the call records an event on the side stream:
+ * over layers [layer_begin, layer_end) with s = min(`layers`, layer_end - layer_begin) side layers makes ceil(s / g) side
+ * launches (g = 2 layers per launch, or what sitk_overlap_set_group set: 1 .. 3): launch i carries the weight + bias gradients
+ * (to_qkv, to_out, net.0, net.3 -- NOT the LayerNorm parameters, which one reduction at the end of the call finishes) of the
+ * g layers below layer_end - g i (the last launch holds the s mod g that are left).  Behind each launch and its slab reduction the call records an event on the side stream:
  * sitk_overlap_side_launches = how many the last call made; sitk_overlap_wait_side_launch makes `stream` wait for launch i,
  * behind which those layers' gradients are FINAL -- the caller all-reduces that bucket from `stream` while the chain goes on.
  * sitk_overlap_set_tail_cus: the one weight-gradient launch behind the chain (the layers that did not go to the side stream)
  * is sized for `cus` CUs instead of the chip's 256, so that the all-reduce channels still running beside it keep theirs. */
+int sitk_overlap_set_group(sitk_overlap* o, int layers_per_launch);
 int sitk_overlap_side_launches(const sitk_overlap* o);
 int sitk_overlap_wait_side_launch(sitk_overlap* o, int i, sitk_stream_t stream);
 int sitk_overlap_set_tail_cus(sitk_overlap* o, int cus);

@@ -504,9 +504,14 @@ SITK_DEV u32x4 pack_pair_h16(const f32x4& a, const f32x4& b) {
 constexpr float kRescaleThr = 8.0f;
 
 // rows [0, ntiles*64) x 64 bf16 columns of `src` (leading dim ld) -> LDS tiles [t][64][128 B]; rows >= nrows are zero
+SITK_DEV void dma_pieces_h16(char* dst, const h16* __restrict__ src, size_t ld, int nrows, int npieces, int wave, int lane, int nwaves);
 SITK_DEV void dma_rows_h16(char* dst, const h16* __restrict__ src, size_t ld, int nrows, int ntiles, int wave, int lane, int nwaves) {
+  dma_pieces_h16(dst, src, ld, nrows, ntiles * 8, wave, lane, nwaves);
+}
+// the same for an image of `npieces` pieces of 8 rows (a compact image ends with the last 32-row pair that holds rows)
+SITK_DEV void dma_pieces_h16(char* dst, const h16* __restrict__ src, size_t ld, int nrows, int npieces, int wave, int lane, int nwaves) {
   const char* zero = reinterpret_cast<const char*>(g_zero_page_attn);
-  for (int q = wave; q < ntiles * 8; q += nwaves) {      // one piece = 8 rows x 128 B
+  for (int q = wave; q < npieces; q += nwaves) {         // one piece = 8 rows x 128 B
     const int row = q * 8 + (lane >> 3), r64 = row & 63;
     const int chunk = (lane & 7) ^ (attn_res_key(r64) << 1);
     const char* g = row < nrows ? reinterpret_cast<const char*>(src + (size_t)row * ld + chunk * 8) : zero;
@@ -633,7 +638,21 @@ __device__ unsigned long long g_res_stamps[RES_STAMP_WGS][16][RES_STAMP_N];
 #endif
 constexpr int FOLD_D = 192, FOLD_KS = FOLD_D / 32;
 constexpr int RES_DQ_SMEM = 2 * (RES_MAX_N / 64) * 8192, RES_DQ_SMEM_FOLD = RES_DQ_SMEM + 64 * FOLD_D * 2;
-template <int WAVES, bool FOLD>
+// QRES (round 5; merged FOLD kernel, 320 < N <= 352: the 321-token configurations of dim 192): the operand images are COMPACT
+// -- 22 blocks of 16 rows = 45 056 B instead of six 64-row tiles = 49 152 B; the sixth tile of 321 tokens holds ONE row, and the
+// transposed reads touch 32-row pairs -- so that K, V, the head's Wo^T slice AND Q fit the CU together:
+//   [ statistics 3 072 | K 45 056 | Q 45 056 | V 45 056 | Wo^T 24 576 ] = 162 816 B of 163 840.
+// The query side reads its q fragments from the Q image (no global q reads), the key side finds Q already there (no second
+// transfer), reads its k fragments from the K image, which nothing overwrites, and its v fragments from registers (first tile,
+// read before the barrier) or from the head of the V image (second tile: the waves' second tiles are key tiles 0 .. n2 - 1, and
+// dO lands on the LAST 45 056 bytes of [V | Wo^T], so V's first 24 576 bytes = 192 keys survive).  What crosses HBM / L2 twice
+// in the classic plan and once here: q (7.9 MB per launch at B = 64), k and v (15.8 MB).  Same arithmetic, same bits.
+constexpr int QRES_NB = 22, QRES_IMG = QRES_NB * 2048, QRES_STATS = 2 * RES_MAX_N * 4, QRES_W = 64 * FOLD_D * 2;
+constexpr int QRES_MAX_N = QRES_NB * 16, QRES_MIN_N = 321;
+constexpr int QRES_SMEM = QRES_STATS + 3 * QRES_IMG + QRES_W;
+static_assert(QRES_SMEM <= 160 * 1024, "QRES LDS plan");
+static_assert((QRES_NB - 16) * 2048 <= QRES_W, "the second tiles' v rows (key tiles 0 .. QRES_NB - 17) must survive the dO image");
+template <int WAVES, bool FOLD, bool QRES = false>
 SITK_DEV void attn_bwd_dq_res_body(char* smem, int bid, const h16* __restrict__ qkv, const h16* __restrict__ o,
                                    const h16* __restrict__ d_o, const float* __restrict__ lse, float* __restrict__ delta,
                                    h16* __restrict__ dqkv, int N, int H, float scale, const h16* __restrict__ dxmid,
@@ -644,11 +663,19 @@ SITK_DEV void attn_bwd_dq_res_body(char* smem, int bid, const h16* __restrict__ 
   const int h = bid % H, b = bid / H, I = H * 64, nkt = (N + 63) / 64;
   const size_t ld = (size_t)3 * I;
   const T* base = qkv + (size_t)b * N * ld;
-  char* sK = smem;
-  char* sV = smem + (RES_MAX_N / 64) * 8192;   // fixed distance: one address register serves both tiles
-  dma_rows_h16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
-  dma_rows_h16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
-  char* sW = smem + 2 * (RES_MAX_N / 64) * 8192;   // FOLD: [k-step panel 0..5][64 rows][64 B], 16-B slots XOR (row >> 2) & 3
+  static_assert(!QRES || FOLD, "QRES is a plan of the FOLD kernel");
+  char* sK = smem + (QRES ? QRES_STATS : 0);
+  char* sV = QRES ? sK + 2 * QRES_IMG : smem + (RES_MAX_N / 64) * 8192;   // fixed distance: one address register serves both tiles
+  char* sQ = sK + QRES_IMG;                        // QRES only
+  if constexpr (QRES) {
+    dma_pieces_h16(sK, base + I + h * 64, ld, N, 2 * QRES_NB, wave, lane, WAVES);
+    dma_pieces_h16(sV, base + 2 * I + h * 64, ld, N, 2 * QRES_NB, wave, lane, WAVES);
+    dma_pieces_h16(sQ, base + h * 64, ld, N, 2 * QRES_NB, wave, lane, WAVES);
+  } else {
+    dma_rows_h16(sK, base + I + h * 64, ld, N, nkt, wave, lane, WAVES);
+    dma_rows_h16(sV, base + 2 * I + h * 64, ld, N, nkt, wave, lane, WAVES);
+  }
+  char* sW = QRES ? sV + QRES_IMG : smem + 2 * (RES_MAX_N / 64) * 8192;   // FOLD: [k-step panel 0..5][64 rows][64 B], 16-B slots XOR (row >> 2) & 3
   if constexpr (FOLD) {
     for (int pc = wave; pc < 4 * FOLD_KS; pc += WAVES) {     // one piece = 16 rows x 64 B of one panel
       const int panel = pc >> 2, row = (pc & 3) * 16 + (lane >> 2), kq = (lane & 3) ^ ((row >> 2) & 3);
@@ -695,7 +722,8 @@ SITK_DEV void attn_bwd_dq_res_body(char* smem, int bid, const h16* __restrict__ 
         for (int e = 0; e < 4; ++e) { pk[e] = (h16)acc[2 * ks][e]; pk[e + 4] = (h16)acc[2 * ks + 1][e]; }
         dof[ks] = __builtin_bit_cast(u32x4, pk);
         const int eo = ks * 32 + fq * 8;
-        qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
+        if constexpr (QRES) qf[ks] = *reinterpret_cast<const u32x4*>(sQ + qt * 2048 + lo.row[ks]);   // (rows >= N: zeros, never stored)
+        else qf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)qc * ld + h * 64 + eo);
         const h16x8 ov = *reinterpret_cast<const h16x8*>(o + ((size_t)b * N + qc) * I + h * 64 + eo);
 #pragma unroll
         for (int e = 0; e < 8; ++e) dpart += (float)pk[e] * (float)ov[e];
@@ -772,10 +800,13 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dq_res_kernel(const h16* 
 }
 
 constexpr int RES_DKV_SMEM = 2 * (RES_MAX_N / 64) * 8192 + 2 * RES_MAX_N * 4;
-template <int WAVES>
+// QRES (see above): Q is already in LDS, k fragments come from the K image, v fragments from `vpre` (the wave's first tile) or
+// from the surviving head of the V image (its second tile); a wave's FIRST tile is key tile n2 + wave, its second tile `wave`
+// (n2 = tiles - WAVES of them), so that the second tiles are the first n2.
+template <int WAVES, bool QRES = false>
 SITK_DEV void attn_bwd_dkv_res_body(char* smem, int bid, const h16* __restrict__ qkv, const h16* __restrict__ d_o,
                                     const float* __restrict__ lse, const float* __restrict__ delta, h16* __restrict__ dqkv,
-                                    int N, int H, float scale RES_ST_PARAM) {
+                                    int N, int H, float scale, const u32x4 (&vpre)[2] RES_ST_PARAM) {
   using T = h16;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -785,10 +816,16 @@ SITK_DEV void attn_bwd_dkv_res_body(char* smem, int bid, const h16* __restrict__
   // row statistics FIRST: every LDS read of the sweep then is `address register + 16-bit immediate`
   float* sL = reinterpret_cast<float*>(smem);
   float* sD = sL + RES_MAX_N;
-  char* sQ = smem + 2 * RES_MAX_N * 4;
-  char* sDO = sQ + (RES_MAX_N / 64) * 8192;    // fixed distance: one address register serves both tiles
-  dma_rows_h16(sQ, base + h * 64, ld, N, nqt, wave, lane, WAVES);
-  dma_rows_h16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, nqt, wave, lane, WAVES);
+  char* sQ = QRES ? smem + QRES_STATS + QRES_IMG : smem + 2 * RES_MAX_N * 4;
+  char* sDO = QRES ? smem + QRES_STATS + 2 * QRES_IMG + QRES_W : sQ + (RES_MAX_N / 64) * 8192;    // fixed distance: one address register serves both tiles
+  const char* sKf = smem + QRES_STATS;         // QRES: the K image of the query side, untouched
+  const char* sVf = smem + QRES_STATS + 2 * QRES_IMG;   // QRES: the first QRES_W bytes of the V image (keys 0 .. 191) survive the dO image
+  if constexpr (QRES) {
+    dma_pieces_h16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, 2 * QRES_NB, wave, lane, WAVES);
+  } else {
+    dma_rows_h16(sQ, base + h * 64, ld, N, nqt, wave, lane, WAVES);
+    dma_rows_h16(sDO, d_o + (size_t)b * N * I + h * 64, (size_t)I, N, nqt, wave, lane, WAVES);
+  }
   for (int r = tid; r < nqt * 64; r += WAVES * 64) {
     const size_t ridx = ((size_t)b * H + h) * N + min(r, N - 1);
     sL[r] = r < N ? -lse[ridx] * kLog2e : -INFINITY;   // negated (added below); exp2(x - inf) = 0 for padded query rows
@@ -800,14 +837,28 @@ SITK_DEV void attn_bwd_dkv_res_body(char* smem, int bid, const h16* __restrict__
   RES_STAMP(7);
   const float c = scale * kLog2e;
   const LaneOffs lo = lane_offs_h16(lane);
-  for (int kt = wave; kt * 16 < N; kt += WAVES) {
+  const int n16 = (N + 15) >> 4, n2 = QRES ? max(n16 - WAVES, 0) : 0;      // QRES: tiles of the second round = key tiles 0 .. n2 - 1
+  for (int round = 0;; ++round) {
+    int kt;
+    if constexpr (QRES) {
+      kt = round == 0 ? n2 + wave : wave;
+      if (round > 1 || (round == 1 && wave >= n2) || kt >= n16) break;
+    } else {
+      kt = wave + round * WAVES;
+      if (kt >= n16) break;
+    }
     const int key = kt * 16 + fr, kc = min(key, N - 1);
     u32x4 kf[2], vf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int eo = ks * 32 + fq * 8;
-      kf[ks] = scale_frag(*reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo), c);   // log2-domain scores
-      vf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + eo);
+      if constexpr (QRES) {
+        kf[ks] = scale_frag(*reinterpret_cast<const u32x4*>(sKf + kt * 2048 + lo.row[ks]), c);              // (rows >= N: zeros, never stored)
+        vf[ks] = round == 0 ? vpre[ks] : *reinterpret_cast<const u32x4*>(sVf + kt * 2048 + lo.row[ks]);
+      } else {
+        kf[ks] = scale_frag(*reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + I + h * 64 + eo), c);   // log2-domain scores
+        vf[ks] = *reinterpret_cast<const u32x4*>(base + (size_t)kc * ld + 2 * I + h * 64 + eo);
+      }
     }
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -845,7 +896,7 @@ SITK_DEV void attn_bwd_dkv_res_body(char* smem, int bid, const h16* __restrict__
         store4(row + 2 * I + 16 * dt + 4 * fq, dv[dt]);
       }
     }
-    RES_STAMP(kt < WAVES ? 8 : 9);
+    RES_STAMP(round == 0 && kt < WAVES + n2 ? 8 : 9);
   }
 }
 
@@ -857,7 +908,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const h16*
 #ifdef SITK_AB
   unsigned long long* st = nullptr;
 #endif
-  attn_bwd_dkv_res_body<WAVES>(smem, (int)blockIdx.x, qkv, d_o, lse, delta, dqkv, N, H, scale RES_ST_ARG);
+  const u32x4 none[2] = {};
+  attn_bwd_dkv_res_body<WAVES>(smem, (int)blockIdx.x, qkv, d_o, lse, delta, dqkv, N, H, scale, none RES_ST_ARG);
 }
 
 // The two sides in ONE launch (round 4): a workgroup owns its (sample, head) through both -- the query side first (dQ, delta,
@@ -865,24 +917,35 @@ __global__ __launch_bounds__(WAVES * 64) void attn_bwd_dkv_res_kernel(const h16*
 // just written (L2) and on q, k, v that the first half has just pulled through this XCD's L2.  One launch boundary per layer
 // less, and q, k, v cross HBM once instead of twice (section 8, round 4).  The single-side kernels above stay for profiling
 // (sitk_attention_bwd_phases with phases 1 or 2).
-template <bool FOLD>
+template <bool FOLD, bool QRES = false>
 __global__ __launch_bounds__(1024) void attn_bwd_res_kernel(const h16* __restrict__ qkv, const h16* __restrict__ o,
                                                             const h16* __restrict__ d_o, const float* __restrict__ lse,
                                                             float* __restrict__ delta, h16* __restrict__ dqkv, int N, int H,
                                                             float scale, const h16* __restrict__ dxmid, const h16* __restrict__ wo_t,
                                                             h16* __restrict__ d_o_out) {
-  constexpr int SMEM = (FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM) > RES_DKV_SMEM ? (FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM) : RES_DKV_SMEM;
+  constexpr int SMEM0 = (FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM) > RES_DKV_SMEM ? (FOLD ? RES_DQ_SMEM_FOLD : RES_DQ_SMEM) : RES_DKV_SMEM;
+  constexpr int SMEM = QRES ? QRES_SMEM : SMEM0;
   __shared__ __attribute__((aligned(256))) char smem[SMEM];
   const int bid = xcd_remap(blockIdx.x, gridDim.x);      // the H workgroups of a sample on one XCD (they share its dxmid rows)
 #ifdef SITK_AB
   unsigned long long stamps[RES_STAMP_N] = {}, *st = stamps;
   st[0] = __builtin_amdgcn_s_memtime();
 #endif
-  attn_bwd_dq_res_body<16, FOLD>(smem, bid, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out RES_ST_ARG);
+  attn_bwd_dq_res_body<16, FOLD, QRES>(smem, bid, qkv, o, d_o, lse, delta, dqkv, N, H, scale, dxmid, wo_t, d_o_out RES_ST_ARG);
+  u32x4 vpre[2] = {};
+  if constexpr (QRES) {       // the v fragments of this wave's first key tile, before the dO image lands on those rows of V
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n16 = (N + 15) >> 4, kt = max(n16 - 16, 0) + wave;
+    if (kt < n16) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        vpre[ks] = *reinterpret_cast<const u32x4*>(smem + QRES_STATS + 2 * QRES_IMG + kt * 2048 + attn_res_off(lane & 15, ks * 64 + (lane >> 4) * 16));
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave's dO / delta stores have left the CU ...
   __syncthreads();                                       // ... and nobody reads the K / V image any more
   RES_STAMP(5);
-  attn_bwd_dkv_res_body<16>(smem, bid, qkv, FOLD ? d_o_out : d_o, lse, delta, dqkv, N, H, scale RES_ST_ARG);
+  attn_bwd_dkv_res_body<16, QRES>(smem, bid, qkv, FOLD ? d_o_out : d_o, lse, delta, dqkv, N, H, scale, vpre RES_ST_ARG);
 #ifdef SITK_AB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   st[10] = __builtin_amdgcn_s_memtime();
@@ -1450,6 +1513,13 @@ static int run_bwd_proj(const void* qkv, const void* o, const void* dxmid, const
 #ifdef SITK_AB
   { int rc; if (pk_try_bwd_proj(qkv, o, dxmid, wo_t, d_o, lse, delta, dqkv, B, N, H, scale, s, phases, &rc)) return rc; }
 #endif
+  if (phases == 3 && N >= QRES_MIN_N && N <= QRES_MAX_N && sitk_ab_switch("SITK_ATTN_QRES", 1)) {    // ... with Q resident (the 321-token shapes)
+    hipLaunchKernelGGL((attn_bwd_res_kernel<true, true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
+                       reinterpret_cast<const h16*>(o), (const h16*)nullptr, lse, delta, reinterpret_cast<h16*>(dqkv), N, H,
+                       scale, reinterpret_cast<const h16*>(dxmid), reinterpret_cast<const h16*>(wo_t),
+                       reinterpret_cast<h16*>(d_o));
+    return check_launch("attention_bwd_proj_res_q");
+  }
   if (phases == 3 && sitk_ab_switch("SITK_ATTN_MERGED", 1)) {    // both sides in one launch
     hipLaunchKernelGGL((attn_bwd_res_kernel<true>), dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
                        reinterpret_cast<const h16*>(o), (const h16*)nullptr, lse, delta, reinterpret_cast<h16*>(dqkv), N, H,

@@ -81,7 +81,7 @@ struct sitk_overlap {
                                   // max_layers + 1: sitk_overlap_fork / _join
   std::vector<hipEvent_t> done;   // [i]: recorded on the side stream behind side launch i (+ its slab reduction) of the last
                                   // sitk_encoder_bwd_overlap call: the gradients that launch wrote are final there
-  int max_layers = 0, layers = 0, cus = 0, caller_joins = 0, n_done = 0, tail_cus = 256;
+  int max_layers = 0, layers = 0, cus = 0, caller_joins = 0, n_done = 0, tail_cus = 256, group = 2;
 };
 extern "C" sitk_overlap* sitk_overlap_create(int max_layers, int cus, int caller_joins) {
   if (max_layers < 1 || max_layers > 64 || cus < 1 || cus > 128) { sitk_rt::set_error("overlap: bad arguments"); return nullptr; }
@@ -134,6 +134,11 @@ extern "C" int sitk_overlap_set_tail_cus(sitk_overlap* o, int cus) {
   o->tail_cus = cus;
   return SITK_OK;
 }
+extern "C" int sitk_overlap_set_group(sitk_overlap* o, int layers_per_launch) {
+  if (!o || layers_per_launch < 1 || layers_per_launch > 3) { sitk_rt::set_error("overlap_set_group: 1..3 layers per side launch"); return SITK_ERR_INVALID; }
+  o->group = layers_per_launch;
+  return SITK_OK;
+}
 extern "C" int sitk_overlap_side_launches(const sitk_overlap* o) { return o ? o->n_done : 0; }
 extern "C" int sitk_overlap_wait_side_launch(sitk_overlap* o, int i, sitk_stream_t stream) {
   if (!o || i < 0 || i >= o->n_done) { sitk_rt::set_error("overlap_wait_side_launch: launch %d of %d", i, o ? o->n_done : 0); return SITK_ERR_INVALID; }
@@ -169,6 +174,7 @@ extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_event_(sitk_
 extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_layers_(const sitk_overlap* o) { return o ? o->layers : 0; }
 extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_cus_(const sitk_overlap* o) { return o ? o->cus : 0; }
 extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_tail_cus_(const sitk_overlap* o) { return o ? o->tail_cus : 256; }
+extern "C" __attribute__((visibility("hidden"))) int sitk_overlap_group_(const sitk_overlap* o) { return o ? o->group : 2; }
 extern "C" __attribute__((visibility("hidden"))) void sitk_overlap_reset_done_(sitk_overlap* o) { if (o) o->n_done = 0; }
 // the event behind the next side launch (null when the object has no room left: cannot happen, one launch holds >= 1 layer)
 extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_next_done_(sitk_overlap* o) {

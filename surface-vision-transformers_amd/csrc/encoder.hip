@@ -207,9 +207,10 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
     if (L.scratch.wgrad_ws_bytes) L.scratch.wgrad_ws_bytes += (size_t)128 * 128 * 192 * 4;   // + the patch embedding's and the caller's extra tiles (sitk_encoder_bwd_extra)
     L.scratch.wgrad_ws = stake(L.scratch.wgrad_ws_bytes);
     {
-      sitk_wgrad_desc wg8[8];
-      for (int i = 0; i < 8; ++i) wg8[i] = wg4[i % 4];
-      L.scratch.wgrad_ws_side_bytes = std::max(sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype), sitk_gemm_wgrad_group_ws_bytes(wg8, 8, c.dtype));
+      sitk_wgrad_desc wg12[12];
+      for (int i = 0; i < 12; ++i) wg12[i] = wg4[i % 4];
+      L.scratch.wgrad_ws_side_bytes = std::max(std::max(sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype), sitk_gemm_wgrad_group_ws_bytes(wg12, 8, c.dtype)),
+                                               sitk_gemm_wgrad_group_ws_bytes(wg12, 12, c.dtype));     // one, two or three layers per side launch
     }
     L.scratch.wgrad_ws_side = stake(L.scratch.wgrad_ws_side_bytes);
   }
@@ -439,6 +440,7 @@ extern "C" int sitk_overlap_cus_(const sitk_overlap* o);
 extern "C" int sitk_overlap_caller_joins_(const sitk_overlap* o);
 extern "C" int sitk_overlap_max_layers_(const sitk_overlap* o);
 extern "C" int sitk_overlap_tail_cus_(const sitk_overlap* o);
+extern "C" int sitk_overlap_group_(const sitk_overlap* o);
 extern "C" void sitk_overlap_reset_done_(sitk_overlap* o);
 extern "C" void* sitk_overlap_next_done_(sitk_overlap* o);
 
@@ -471,6 +473,7 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
   const int side_max = (overlap && S.wg_batch && S.wgrad_ws_side_bytes && !c.timeline)        // (a timeline times ONE stream)
                            ? std::min(sitk_overlap_layers_(overlap), layer_end - layer_begin) : 0;
   const int side_cus = sitk_overlap_cus_(overlap);
+  const int side_group = sitk_overlap_group_(overlap);      // layers per side launch (2; sitk_overlap_set_group)
   sitk_overlap_reset_done_(overlap);
   int n_side = 0;
   std::vector<sitk_wgrad_desc> wg_side;
@@ -567,7 +570,7 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
       // 2.59 / 2.50 ms per step against 2.43, profiles/README.md round 3).
       wg_side.insert(wg_side.end(), wg, wg + 4);
       ++n_side;
-      if ((int)wg_side.size() == 8 || n_side == side_max) {
+      if ((int)wg_side.size() == 4 * side_group || n_side == side_max) {
         hipEvent_t ev = reinterpret_cast<hipEvent_t>(sitk_overlap_event_(overlap, n_side - 1));
         if (hipEventRecord(ev, hs) != hipSuccess || hipStreamWaitEvent(side, ev, 0) != hipSuccess) {
           set_error("encoder_bwd_overlap: fork of the side stream failed");

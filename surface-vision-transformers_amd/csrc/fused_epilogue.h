@@ -27,6 +27,13 @@ constexpr int FE_SMEM_BYTES = fe_smem_bytes(4);            // 100352
 // 128-row ones as long as all of them still fit on the 256 CUs at once (BASELINE config 2: 20 544 rows = 214
 // workgroups of 96 instead of 161 of 128).
 static inline int fused_block_rows(int64_t rows) { return (rows + 95) / 96 <= 256 ? 96 : 128; }
+// the BACKWARD kernels' choice (d to_qkv + norm backward, MLP backward and their pair launch share one partition).  Diagnostic
+// build: SITK_BWD_ROWS128=1 forces 128-row workgroups -- 161 instead of 214 at BASELINE config 2 -- to measure what room for the
+// all-reduce channels of a data-parallel step costs (tools/dp_cu_budget.py); the shipped library takes fused_block_rows().
+static inline int fused_bwd_block_rows(int64_t rows) {
+  static const int force128 = sitk_ab_switch("SITK_BWD_ROWS128", 0);
+  return force128 ? 128 : fused_block_rows(rows);
+}
 
 // v[i][t]: this wave's finished half of dh -- features 96 hh + 16 i + 4 fq + e of token 16 TT tg + 16 t + fr
 // (pair exchange already done).  smem: >= FE_SMEM_BYTES, free for use by every wave (callers sync before).

@@ -239,7 +239,7 @@ extern "C" int sitk_ln_gemm_fwd(const float* x, const float* ln_w, const float* 
 }
 
 extern "C" size_t sitk_ln_gemm_bwd_partial_floats(int64_t rows) {
-  return rows > 0 ? (size_t)cdiv64(rows, fused_block_rows(rows)) * 2 * LG_D : 0;
+  return rows > 0 ? (size_t)cdiv64(rows, fused_bwd_block_rows(rows)) * 2 * LG_D : 0;
 }
 
 SITK_F16_TWIN(sitk_ln_gemm_bwd)
@@ -257,8 +257,8 @@ extern "C" int sitk_ln_gemm_bwd(const void* dy, const void* wt_c, const float* x
   p.R = (int)rows; p.N = N;
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   static const int tt1 = sitk_ab_switch("SITK_LG_TT1", 1);   // 12 waves x 16 tokens; 0: the 6 x 32 variant (A/B)
-  if (fused_block_rows(rows) == 96 && tt1) hipLaunchKernelGGL((ln_gemm_bwd_kernel<6, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
-  else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL(ln_gemm_bwd_kernel<3>, dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  if (fused_bwd_block_rows(rows) == 96 && tt1) hipLaunchKernelGGL((ln_gemm_bwd_kernel<6, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
+  else if (fused_bwd_block_rows(rows) == 96) hipLaunchKernelGGL(ln_gemm_bwd_kernel<3>, dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL(ln_gemm_bwd_kernel<4>, dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("ln_gemm_bwd");
 }

@@ -911,7 +911,7 @@ extern "C" int sitk_mlp_debug_stamps(unsigned long long* out64) {
 }
 
 extern "C" size_t sitk_mlp_bwd_partial_floats(int64_t rows) {
-  return rows > 0 ? (size_t)cdiv64(rows, fused_block_rows(rows)) * 2 * MLP_D : 0;
+  return rows > 0 ? (size_t)cdiv64(rows, fused_bwd_block_rows(rows)) * 2 * MLP_D : 0;
 }
 
 static int mlp_bwd_launch(const float* dy, const void* dy_c, void* dy_c_make, const float* x, const float* mean, const float* rstd,
@@ -935,8 +935,8 @@ static int mlp_bwd_launch(const float* dy, const void* dy_c, void* dy_c_make, co
   else if (var == 6) hipLaunchKernelGGL((mlp_kernel<true, 6>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   else
 #endif
-  if (fused_block_rows(rows) == 96 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<true, 0, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
-  else if (fused_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<true, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
+  if (fused_bwd_block_rows(rows) == 96 && mlp_tt1()) hipLaunchKernelGGL((mlp_kernel<true, 0, 6, false, false, 1>), dim3(cdiv((int)rows, 96)), dim3(768), 0, hs, p);
+  else if (fused_bwd_block_rows(rows) == 96) hipLaunchKernelGGL((mlp_kernel<true, 0, 3>), dim3(cdiv((int)rows, 96)), dim3(384), 0, hs, p);
   else hipLaunchKernelGGL((mlp_kernel<true, 0, 4>), dim3(cdiv((int)rows, 128)), dim3(512), 0, hs, p);
   return check_launch("mlp_bwd");
 }
@@ -968,7 +968,7 @@ SITK_F16_TWIN(sitk_ln_gemm_mlp_bwd_supported)
 extern "C" int sitk_ln_gemm_mlp_bwd_supported(int64_t rows, int D, int N, int M, int dtype) {
   SITK_FORWARD_F16(dtype, sitk_ln_gemm_mlp_bwd_supported, rows, D, N, M, dtype);
   return sitk_mlp_fused_supported(D, M, dtype) && N % 64 == 0 && N >= 64 && rows > 0 && rows * (int64_t)N < (1ll << 30) &&
-         fused_block_rows(rows) == 96 && mlp_tt1() && sitk_ab_switch("SITK_LG_TT1", 1) && sitk_ab_switch("SITK_BWD_PAIR", 1);
+         fused_bwd_block_rows(rows) == 96 && mlp_tt1() && sitk_ab_switch("SITK_LG_TT1", 1) && sitk_ab_switch("SITK_BWD_PAIR", 1);
 }
 
 SITK_F16_TWIN(sitk_ln_gemm_mlp_bwd)

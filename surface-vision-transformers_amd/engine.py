@@ -110,13 +110,13 @@ def grad_write_stages(model, task, slices, head_deferred=False):
     return stage
 
 
-def side_launch_groups(layer_begin, layer_end, side_layers):
+def side_launch_groups(layer_begin, layer_end, side_layers, per_launch=2):
     """The layers whose weight + bias gradients each side launch of sitk_encoder_bwd_overlap carries (include/sitk.h, ABI 10):
-    launch i = layers layer_end - 1 - 2 i and layer_end - 2 - 2 i, the last one a single layer when the count is odd."""
+    launch i = the `per_launch` layers below layer_end - per_launch i, the last one what is left of `side_layers`."""
     s = min(side_layers, layer_end - layer_begin)
     groups, top = [], layer_end
     while layer_end - top < s:
-        n = min(2, s - (layer_end - top))
+        n = min(per_launch, s - (layer_end - top))
         groups.append(list(range(top - n, top)))
         top -= n
     return groups
@@ -209,7 +209,8 @@ class TrainEngine:
     def __init__(self, model, batch_size, *, task="regression", input_layout="surface", loss="mse", optimizer="sgd",
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
-                 wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True, dp_channels=None, optimize=None):
+                 wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True, dp_channels=None, optimize=None,
+                 wgrad_overlap_group=None):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -274,9 +275,13 @@ class TrainEngine:
         # event behind each (sitk_overlap_wait_side_launch), and the flat buffers are ordered by write stage so that a
         # launch's gradients are one contiguous range (round 4: two buckets, the first -- 58 % of the bytes -- final only 40 us
         # after the chain; now the first 3.5 MB are final ~1.4 ms into a 2.4 ms step and the last bucket is the tail's).
-        self.dp_side = bool(self.dp and fused and wgrad_overlap is None and use_graph is not True and bwd_slices is None
-                            and tr.depth >= 2)
-        self._side_groups = side_launch_groups(0, tr.depth, min(tr.depth - 1, max(1, round(2 / 3 * tr.depth)))) if self.dp_side else []
+        self.dp_side = bool(self.dp and fused and use_graph is not True and bwd_slices is None and tr.depth >= 2
+                            and (wgrad_overlap is None or wgrad_overlap > 0))
+        self.wgrad_overlap_group = int(wgrad_overlap_group) if wgrad_overlap_group else 2
+        n_side_layers = min(tr.depth - 1, max(1, round(2 / 3 * tr.depth))) if wgrad_overlap is None else min(tr.depth - 1, int(wgrad_overlap))
+        self._side_groups = side_launch_groups(0, tr.depth, n_side_layers, self.wgrad_overlap_group) if self.dp_side else []
+        if self.dp_side:
+            wgrad_overlap = None
         if optimize not in (None, "all", "sit") or (optimize == "sit" and task != "mpp"):
             raise rt.SitkError("TrainEngine: optimize is 'all' or 'sit' (task='mpp' only)")
         self.optimize = (optimize or "all") if task == "mpp" else "all"
@@ -377,6 +382,8 @@ class TrainEngine:
         # workgroups of one side launch (two layers): 42 = the CUs the dim-192 chain's one-wave kernels leave idle
         self.wgrad_overlap_cus = int(wgrad_overlap_cus) if wgrad_overlap_cus else 42
         self._overlap = rt.lib.sitk_overlap_create(max_side, self.wgrad_overlap_cus, 1) if wgrad_overlap > 0 else None
+        if self._overlap and self.wgrad_overlap_group != 2:
+            rt.check(rt.lib.sitk_overlap_set_group(self._overlap, self.wgrad_overlap_group))
         self._head_deferred = bool(self._overlap) and bool(head_deferred) and task == "regression"
         self._side = rt.lib.sitk_overlap_stream(self._overlap) if self._overlap else None
         self._side_torch = torch.cuda.ExternalStream(self._side, device=self.device) if self._overlap else None
@@ -816,7 +823,14 @@ class TrainEngine:
             # BEHIND the chain's launches in that queue instead of in front of them (issued right after the first slice it
             # stalled the chain for 350 us: 3.14 ms per step).
             n_side = rt.lib.sitk_overlap_side_launches(self._overlap)
-            if n_side != len(self._side_groups):
+            if n_side == 0:
+                # no side launch was made (fewer than 2 048 tokens per rank: the large-tile weight-gradient path the side stream
+                # uses does not take such a batch, every layer's gradients ran on the main stream inside the call): the early
+                # buckets are final here, behind the chain -- reduce them from this stream, nothing to overlap with
+                for i in range(len(self._side_groups)):
+                    for lo, hi in self.bucket_plan[i]:
+                        self._allreduce(lo, hi)
+            elif n_side != len(self._side_groups):
                 raise rt.SitkError(f"engine: {n_side} side launches, bucket plan built for {len(self._side_groups)}")
             for i in range(n_side):
                 rt.check(rt.lib.sitk_overlap_wait_side_launch(self._overlap, i, self._ar_stream.cuda_stream))

@@ -113,6 +113,7 @@ _SIGS = {
     "sitk_overlap_set_layers": (C.c_int, [_P, _I]),
     "sitk_overlap_fork": (C.c_int, [_P, _P]),
     "sitk_overlap_join": (C.c_int, [_P, _P]),
+    "sitk_overlap_set_group": (C.c_int, [_P, _I]),
     "sitk_overlap_side_launches": (C.c_int, [_P]),
     "sitk_overlap_wait_side_launch": (C.c_int, [_P, _I, _P]),
     "sitk_overlap_set_tail_cus": (C.c_int, [_P, _I]),

@@ -376,7 +376,7 @@ def test_bench_mpp_gpus_2_as_typed_prints_one_json_line():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--task", "mpp", "--gpus", "2", "--backend", "gloo",
                         "--no-cpu-baseline", "--no-probe", "--steps", "3", "--warmup", "2", "--batch", "4"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[:3000] + "\n...\n" + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
@@ -395,7 +395,7 @@ def test_bench_gpus_2_as_typed_prints_one_json_line():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline",
                         "--no-probe", "--steps", "3", "--warmup", "2", "--batch", "4"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=root)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[:3000] + "\n...\n" + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])

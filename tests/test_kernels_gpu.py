@@ -388,6 +388,38 @@ def test_attention_bwd_with_to_out_backward_folded(ops, B, N, H, h16):
     assert rel(dqkv, dqkv_ref) < 4e-3
 
 
+@pytest.mark.parametrize("h16", H16S)
+@pytest.mark.parametrize("B,N,H", [(2, 321, 3), (5, 321, 3), (1, 322, 1), (2, 336, 2), (1, 337, 3), (3, 352, 3), (1, 345, 6)])
+def test_attention_bwd_q_resident_plan_is_bitwise_the_two_launches(ops, B, N, H, h16):
+    """Round 5: for 320 < N <= 352 the merged backward launch (d to_out folded in) keeps K, V, the head's Wo^T slice AND Q in LDS
+    together (compact 22-block operand images), reads its q / k fragments from those images, its first v fragments from registers
+    taken in front of the phase barrier, and visits the key tiles in another order -- same arithmetic per row, so dqkv, d_o and
+    delta must be BIT-equal to the query-side + key-side launches (sitk_attention_bwd_phases 1 then 2), which read the same
+    fragments from global memory.  Shapes: every head count, ragged last blocks (1, 2, 16, 17, 32 rows in the last 32-row pair),
+    several samples (workgroups of one sample share an XCD)."""
+    from sitk import runtime as rt
+    dtype, td, D, I = h16, tdt(h16), 192, H * 64
+    qkv = rnd("atq/qkv", (B * N, 3 * I), 1.0).to(td)
+    dxmid = rnd("atq/dx", (B * N, D), 1.0).to(td)
+    wo_t = rnd("atq/wo", (I, D), 0.1).to(td)
+    o, lse = ops.attention_fwd(qkv, B, N, H, 0.125, dtype)
+    assert ops.attention_bwd_proj_supported(N, D, dtype)
+
+    def run(phase_list):
+        dqkv = torch.full_like(qkv, float("nan"))
+        d_o = torch.full_like(o, float("nan"))
+        delta = torch.full_like(lse, float("nan"))
+        for ph in phase_list:
+            rt.check(rt.lib.sitk_attention_bwd_phases(qkv.data_ptr(), o.data_ptr(), None, dxmid.data_ptr(), wo_t.data_ptr(),
+                                                      d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), B, N, H, D,
+                                                      0.125, rt.dtype_code(dtype), ph, rt.stream_ptr()))
+        return dqkv, d_o, delta
+    a, b = run([3]), run([1, 2])
+    for name, x, y in zip(("dqkv", "d_o", "delta"), a, b):
+        assert bool(torch.isfinite(x.float()).all()), name
+        assert torch.equal(x, y), (name, float((x.float() - y.float()).abs().max()))
+
+
 def test_attention_large_scores_online_softmax(ops):
     """Forces the running-max rescale: one key per row dominates in a late tile."""
     B, N, H = 1, 200, 1

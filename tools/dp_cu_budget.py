@@ -41,8 +41,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--channels", default="16", help="comma list: workgroups of the stand-in = NCCL_MAX_NCHANNELS the engine plans for")
     ap.add_argument("--side-cus", default="42", help="comma list: workgroups of one side launch of weight gradients")
+    ap.add_argument("--configs", default=None, help="instead of the two lists: layers:per_launch:workgroups:channels,... (layers on the side "
+                    "stream, layers per side launch, workgroups a side launch is planned for, stand-in channels)")
     ap.add_argument("--latency-us", type=float, default=30.0, help="fixed part of a bucket's stand-in time")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--timeline", action="store_true", help="HIP-event timeline of three steps (no profiler attached): when each bucket is "
+                    "ready, when its stand-in starts / ends, when the chain, the finish stage and the optimizer end")
     ap.add_argument("--gbs", type=float, default=88.0, help="wire rate of one bucket's all-reduce, GB/s of gradient bytes")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--prio", type=int, default=0, help="priority of the stream the dummy runs on (0 = default, like the process group of bench.py; -1 = high)")
@@ -63,15 +67,20 @@ def main():
     hp = torch.cuda.Stream(device=dev, priority=a.prio)
     B = 64
     print(f"# stand-in: latency {a.latency_us:.0f} us + bytes / {a.gbs:.0f} GB/s per bucket, stream priority {a.prio}, {a.steps} steps, {a.dtype}")
-    for side in sides:
-      for ch in [0] + chans:
+    if a.configs:
+        cfgs = [tuple(int(v) for v in c.split(":")) for c in a.configs.split(",")]
+        cfgs = [c2 for c in cfgs for c2 in ((c[0], c[1], c[2], 0), c)]
+    else:
+        cfgs = [(None, 2, side, ch) for side in sides for ch in [0] + chans]
+    for nlay, group, side, ch in cfgs:
+      if True:
         torch.manual_seed(1234)
         model = SiT(dim=192, depth=12, heads=3, mlp_dim=768, dim_head=64, num_patches=320, num_vertices=153, num_channels=4,
                     compute_dtype=a.dtype)
         eng = engine.TrainEngine(model, B, input_layout="surface", lr=1e-5, momentum=0.9, process_group=dist.group.WORLD, device=dev,
-                                 wgrad_overlap_cus=side, dp_channels=(ch or chans[0]))
+                                 wgrad_overlap_cus=side, dp_channels=(ch or chans[0]), wgrad_overlap=nlay, wgrad_overlap_group=group)
         assert eng.dp_side, "expected the side-stream form"
-        log = []
+        log, tl = [], []
         if ch:
             orig = eng._allreduce
 
@@ -79,9 +88,13 @@ def main():
                 n0 = len(eng._pending)
                 orig(lo, hi)
                 us = max(1, int(a.latency_us + (hi - lo) * 4 / (a.gbs * 1e3)))
-                ev0, ev1 = torch.cuda.Event(), torch.cuda.Event()
+                ev0, ev1 = torch.cuda.Event(enable_timing=a.timeline), torch.cuda.Event(enable_timing=a.timeline)
                 ev0.record(torch.cuda.current_stream())
                 hp.wait_event(ev0)
+                if a.timeline:
+                    evs = torch.cuda.Event(enable_timing=True)
+                    evs.record(hp)
+                    tl.append(("ready", ev0)); tl.append(("stand-in start", evs)); tl.append(("stand-in end", ev1))
                 assert lib.sitk_debug_occupy(ch, us, hp.cuda_stream) == 0
                 ev1.record(hp)
                 eng._pending[n0] = _Both(eng._pending[n0], ev1)
@@ -105,9 +118,35 @@ def main():
         ms = (time.perf_counter() - t0) / a.steps * 1e3
         if not ch:
             base = ms
+        if a.timeline:
+            # three more steps with events on the main stream: step start, end of the backward call (chain + tail launch enqueued
+            # behind it), end of the finish stage, end of the optimizer
+            orig_fin, orig_opt, orig_seg = eng._finish_backward, eng._optimizer, eng._segment_fns
+
+            def mark(label):
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream())
+                tl.append((label, e))
+
+            def seg_fns():
+                fns = orig_seg()
+                return [lambda fn=fn: (fn(), mark("backward call done (main stream)")) for fn in fns]
+            eng._segment_fns = seg_fns
+            eng._finish_backward = lambda: (orig_fin(), mark("finish stage done"))
+            eng._optimizer = lambda: (orig_opt(), mark("optimizer done"))
+            for st in range(3):
+                tl.clear()
+                torch.cuda.synchronize()
+                mark("step start")
+                eng.step()
+                torch.cuda.synchronize()
+                t0 = tl[0][1]
+                print(f"  timeline of step {st} (us from the step's start; events in issue order):")
+                for label, e in tl[1:]:
+                    print(f"    {t0.elapsed_time(e) * 1e3:9.1f}  {label}")
         nb = sum(len(b) for b in eng.bucket_plan)
         extra = "  buckets (bytes, stand-in us): " + ", ".join(f"({b}, {u})" for b, u in log[-nb:]) if ch else ""
-        print(f"side launch {side:3d} workgroups, stand-in {ch:2d} channels: {ms:.3f} ms per step ({(ms - base) * 1e3:+5.0f} us; host enqueue "
+        print(f"{eng.wgrad_overlap} side layers, {group} per launch, {side:3d} workgroups, stand-in {ch:2d} channels: {ms:.3f} ms per step ({(ms - base) * 1e3:+5.0f} us; host enqueue "
               f"{host / a.steps * 1e3:.3f} ms){extra}", flush=True)
         del eng, model
     dist.destroy_process_group()
