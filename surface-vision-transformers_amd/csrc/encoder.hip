@@ -470,7 +470,10 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
   // four weight gradients run as ONE grouped launch.
   hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
   hipStream_t side = reinterpret_cast<hipStream_t>(sitk_overlap_stream_(overlap));
-  const int side_max = (overlap && S.wg_batch && S.wgrad_ws_side_bytes && !c.timeline)        // (a timeline times ONE stream)
+  // (a timeline times ONE stream: side launches are off while one is attached -- except in the diagnostic build under
+  // SITK_TIMELINE_SIDE=1, where tools/dp_cu_budget.py wants the main chain's marks WITH the side stream running)
+  static const int timeline_side = sitk_ab_switch("SITK_TIMELINE_SIDE", 0);
+  const int side_max = (overlap && S.wg_batch && S.wgrad_ws_side_bytes && (!c.timeline || timeline_side))
                            ? std::min(sitk_overlap_layers_(overlap), layer_end - layer_begin) : 0;
   const int side_cus = sitk_overlap_cus_(overlap);
   const int side_group = sitk_overlap_group_(overlap);      // layers per side launch (2; sitk_overlap_set_group)

@@ -122,20 +122,20 @@ def side_launch_groups(layer_begin, layer_end, side_layers, per_launch=2):
     return groups
 
 
-def grad_write_stages_side(model, task, groups):
+def grad_write_stages_side(model, task, groups, per_bucket=1):
     """The side-stream form's counterpart of grad_write_stages: stage i < len(groups) = behind side launch i (the Linear weights
     and biases of its layers -- the launch writes nothing else); stage len(groups) = behind the finish stage: every LayerNorm
     parameter (one reduction at the end of backward sums their partials), the layers whose weight gradients run in the tail
     launch behind the chain, the patch embedding, cls_token, pos_embedding, mlp_head.* and, under MPP, to_original.* and
-    mask_token."""
+    mask_token.  per_bucket > 1: `per_bucket` consecutive side launches form ONE bucket (final behind the last of them)."""
     sit = model.transformer if task == "mpp" else model
-    final = len(groups)
+    final = (len(groups) + per_bucket - 1) // per_bucket
     stage = {id(p): final for p in model.parameters()}
     for i, layers in enumerate(groups):
         for l in layers:
             for name, p in sit.transformer.layers[l].named_parameters():
                 if ".norm." not in "." + name:
-                    stage[id(p)] = i
+                    stage[id(p)] = i // per_bucket           # per_bucket consecutive side launches share one all-reduce bucket
     return stage
 
 
@@ -210,7 +210,7 @@ class TrainEngine:
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
                  wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True, dp_channels=None, optimize=None,
-                 wgrad_overlap_group=None):
+                 wgrad_overlap_group=None, dp_stream_priority=0, dp_bucket_launches=None):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -291,7 +291,15 @@ class TrainEngine:
             frozen |= {id(p) for p in sit.mlp_head.parameters()}
             if self.optimize == "sit":
                 frozen |= {id(p) for p in self.ssl.to_original.parameters()} | {id(self.ssl.mask_token)}
-        side_stage = grad_write_stages_side(self.module, task, self._side_groups) if self.dp_side else {}
+        # Side launches per all-reduce bucket.  Measured with a stand-in of RCCL's footprint and SURVEY section 5's wire time on
+        # the bucket's own stream (profiles/r05_dp_budget.txt): every collective costs the step ~30 us whatever its size or
+        # duration (a 16-workgroup kernel that wants whole CUs finds them only at a kernel boundary of the chain), while an
+        # early bucket's wire time hides -- 1 launch per bucket (4 + 1 collectives) +280 - 300 us per step, 2 per bucket +185,
+        # ALL side launches in one early bucket (1 + 1 collectives, the early one beside the tail launch) +126 - 148 us: the
+        # default.  (More, smaller buckets start earlier and are the safer choice if the wire turns out slower than 88 GB/s.)
+        self.dp_bucket_launches = max(1, int(dp_bucket_launches)) if dp_bucket_launches else max(1, len(self._side_groups))
+        self._n_early = (len(self._side_groups) + self.dp_bucket_launches - 1) // self.dp_bucket_launches
+        side_stage = grad_write_stages_side(self.module, task, self._side_groups, self.dp_bucket_launches) if self.dp_side else {}
         self.fp = FlatParams(self.module, self.device, grad_extra=self.D * self.ld + 4 * _ALIGN + self.D,
                              order=lambda p: (id(p) in frozen, side_stage.get(id(p), 0)))
         self.n_opt = min([self.fp.offsets[i][0] for i in frozen], default=self.fp.total)
@@ -400,13 +408,13 @@ class TrainEngine:
             # Bucket i is final behind side launch i (an event the library records on the side stream); its all-reduce is issued
             # from a small stream of its own that waits for THAT event only -- not from the side stream's context, whose tail by
             # then holds later launches.  The one weight-gradient launch behind the chain leaves the channels' CUs free.
-            self._ar_stream = torch.cuda.Stream(device=self.device)
+            self._ar_stream = torch.cuda.Stream(device=self.device, priority=int(dp_stream_priority))
             self.dp_channels = int(dp_channels) if dp_channels else 16
             rt.check(rt.lib.sitk_overlap_set_tail_cus(self._overlap, max(64, 256 - self.dp_channels)))
         if use_graph is None:
             use_graph = not self._overlap
         if self.dp_side:
-            self.bucket_plan = grad_bucket_plan(self.fp, side_stage, len(self._side_groups) + 1, limit=self.n_opt)
+            self.bucket_plan = grad_bucket_plan(self.fp, side_stage, self._n_early + 1, limit=self.n_opt)
         else:
             self.bucket_plan = grad_bucket_plan(self.fp, grad_write_stages(self.module, task, self.slices,
                                                                            head_deferred=self._head_deferred), len(self.slices),
@@ -827,16 +835,18 @@ class TrainEngine:
                 # no side launch was made (fewer than 2 048 tokens per rank: the large-tile weight-gradient path the side stream
                 # uses does not take such a batch, every layer's gradients ran on the main stream inside the call): the early
                 # buckets are final here, behind the chain -- reduce them from this stream, nothing to overlap with
-                for i in range(len(self._side_groups)):
+                for i in range(self._n_early):
                     for lo, hi in self.bucket_plan[i]:
                         self._allreduce(lo, hi)
             elif n_side != len(self._side_groups):
                 raise rt.SitkError(f"engine: {n_side} side launches, bucket plan built for {len(self._side_groups)}")
-            for i in range(n_side):
-                rt.check(rt.lib.sitk_overlap_wait_side_launch(self._overlap, i, self._ar_stream.cuda_stream))
-                with torch.cuda.stream(self._ar_stream):
-                    for lo, hi in self.bucket_plan[i]:
-                        self._allreduce(lo, hi)
+            else:
+                for i in range(self._n_early):
+                    last = min((i + 1) * self.dp_bucket_launches, n_side) - 1      # the bucket is final behind its LAST side launch
+                    rt.check(rt.lib.sitk_overlap_wait_side_launch(self._overlap, last, self._ar_stream.cuda_stream))
+                    with torch.cuda.stream(self._ar_stream):
+                        for lo, hi in self.bucket_plan[i]:
+                            self._allreduce(lo, hi)
         self._run(self._finish_backward, "finish")
         for lo, hi in self.bucket_plan[-1]:             # the last slice's gradients + everything `finish` wrote
             self._allreduce(lo, hi)

@@ -90,8 +90,9 @@ def test_bucket_plan_reduces_every_gradient_once_and_only_after_it_is_written(ta
 
 @pytest.mark.parametrize("optimize", ["all", "sit"])
 @pytest.mark.parametrize("task", ["regression", "mpp"])
+@pytest.mark.parametrize("per_bucket", [1, 2, 3])
 @pytest.mark.parametrize("depth,side", [(12, 8), (4, 3), (2, 1), (6, 4)])
-def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, depth, side, optimize):
+def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, depth, side, optimize, per_bucket):
     """Round 5: the data-parallel form of the fused path all-reduces one bucket per SIDE LAUNCH of
     sitk_encoder_bwd_overlap.  The spec, restated from include/sitk.h (ABI 10) and csrc/encoder.hip's launch order, not from
     sitk.engine: side launch i carries the Linear weight + bias gradients of layers depth - 1 - 2 i and depth - 2 - 2 i (a
@@ -113,7 +114,8 @@ def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, d
         want_groups.append(list(range(top - n, top)))
         top -= n
     assert groups == want_groups and sum(len(g) for g in groups) == side
-    stage = engine.grad_write_stages_side(module, task, groups)
+    stage = engine.grad_write_stages_side(module, task, groups, per_bucket)
+    n_early = (len(groups) + per_bucket - 1) // per_bucket
     frozen = set()
     if task == "mpp":
         frozen |= {id(p) for p in sit.mlp_head.parameters()}
@@ -121,8 +123,8 @@ def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, d
             frozen |= {id(p) for p in ssl.to_original.parameters()} | {id(ssl.mask_token)}
     fp = engine.FlatParams(module, "cpu", order=lambda p: (id(p) in frozen, stage[id(p)]))
     n_opt = min([fp.offsets[i][0] for i in frozen], default=fp.total)
-    plan = engine.grad_bucket_plan(fp, stage, len(groups) + 1, limit=n_opt)
-    assert len(plan) == len(groups) + 1
+    plan = engine.grad_bucket_plan(fp, stage, n_early + 1, limit=n_opt)
+    assert len(plan) == n_early + 1
     assert all(len(rs) == 1 for rs in plan), plan                                                   # (a)
     flat_ranges = sorted(r for point in plan for r in point)
     assert flat_ranges[0][0] == 0 and flat_ranges[-1][1] == n_opt
@@ -135,10 +137,13 @@ def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, d
             continue
         point = next(i for i, rs in enumerate(plan) if any(a <= lo and lo + n <= b for a, b in rs))
         short = name.removeprefix(prefix)
-        writer = len(groups)                                     # finish stage
+        writer = n_early                                         # finish stage
         if short.startswith("transformer.layers.") and ".norm." not in short:
             layer = int(short.split(".")[2])
-            writer = next((i for i, g in enumerate(groups) if layer in g), len(groups))
+            launch = next((i for i, g in enumerate(groups) if layer in g), None)
+            # bucket b is issued behind its LAST side launch, min((b + 1) per_bucket, launches) - 1 >= the layer's own launch
+            writer = n_early if launch is None else launch // per_bucket
+            assert launch is None or min((writer + 1) * per_bucket, len(groups)) - 1 >= launch
         assert point == writer, (name, point, writer)                                               # (c) (and not late either)
     if task == "mpp" and optimize == "all":
         assert fp.offsets[id(ssl.to_original.weight)][0] < n_opt

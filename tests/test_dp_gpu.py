@@ -290,7 +290,7 @@ def _worker4(rank, world, port, q):
     eng = engine.TrainEngine(_make4(), B4 // world, input_layout="surface", lr=LR4, momentum=0.9, process_group=dist.group.WORLD,
                              device="cuda:0")
     assert eng.dp_side and not eng.use_graph and eng._prefetch        # one bucket per side launch, prefetched gather
-    assert eng._side_groups == [[4, 5], [2, 3]] and len(eng.bucket_plan) == 3
+    assert eng._side_groups == [[4, 5], [2, 3]] and len(eng.bucket_plan) == 2       # one early bucket (both side launches) + the final one
     for _ in range(3):
         eng.step(x[shard].cuda(), y[shard].cuda())
     torch.cuda.synchronize()
@@ -478,7 +478,7 @@ def _data320():
     return x, y
 
 
-def _rccl_side_worker(port, dtype, q):
+def _rccl_side_worker(port, dtype, q, per_bucket=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -486,10 +486,12 @@ def _rccl_side_worker(port, dtype, q):
     from sitk import engine
     x, y = _data320()
     eng = engine.TrainEngine(_make_model320(dtype), B320, input_layout="patched", lr=LR320, momentum=0.9,
-                             process_group=dist.group.WORLD, device="cuda:0")
+                             process_group=dist.group.WORLD, device="cuda:0", dp_bucket_launches=per_bucket)
     # one backward call, layers 3, 2 and 1 on the side stream in two side launches = two early buckets + the final one
     assert eng.dp and eng.dp_side and not eng.use_graph and eng.slices == [(0, 4)] and eng.wgrad_overlap == 3
-    assert eng._side_groups == [[2, 3], [1]] and len(eng.bucket_plan) == 3 and all(len(b) == 1 for b in eng.bucket_plan)
+    # (default: all side launches in ONE early bucket; the test also runs one launch per bucket)
+    assert eng._side_groups == [[2, 3], [1]] and len(eng.bucket_plan) == (3 if per_bucket == 1 else 2)
+    assert all(len(b) == 1 for b in eng.bucket_plan)
     losses = []
     for _ in range(3):
         losses.append(float(eng.step(x.cuda(), y.cuda())))
@@ -499,13 +501,13 @@ def _rccl_side_worker(port, dtype, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_one_rank_rccl_group_with_side_stream_matches_plain_engine(dtype):
+@pytest.mark.parametrize("dtype,per_bucket", [("bf16", None), ("f16", None), ("bf16", 1)])
+def test_one_rank_rccl_group_with_side_stream_matches_plain_engine(dtype, per_bucket):
     import sitk  # noqa: F401
     from sitk import engine
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_side_worker, args=(_free_port(), dtype, q))
+    p = ctx.Process(target=_rccl_side_worker, args=(_free_port(), dtype, q, per_bucket))
     p.start()
     got, losses = q.get(timeout=300)
     p.join(timeout=120)

@@ -45,6 +45,12 @@ def main():
                     "stream, layers per side launch, workgroups a side launch is planned for, stand-in channels)")
     ap.add_argument("--latency-us", type=float, default=30.0, help="fixed part of a bucket's stand-in time")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--main-prio", type=int, default=0, help="-1: run the step itself on a HIGH-priority stream (main high, all-reduce path "
+                    "normal, side stream lowest: three priority classes = three sets of hardware queues)")
+    ap.add_argument("--own-stream", type=int, default=1, help="1: the stand-in runs on a stream of its own behind an event (round 4's form); "
+                    "0: on the stream the bucket's all-reduce was issued from (the engine's bucket stream / the main stream)")
+    ap.add_argument("--per-bucket", type=int, default=None, help="side launches per all-reduce bucket (engine default: 2)")
+    ap.add_argument("--standin-us", type=float, default=None, help="fixed stand-in time per bucket instead of latency + bytes / rate")
     ap.add_argument("--timeline", action="store_true", help="HIP-event timeline of three steps (no profiler attached): when each bucket is "
                     "ready, when its stand-in starts / ends, when the chain, the finish stage and the optimizer end")
     ap.add_argument("--gbs", type=float, default=88.0, help="wire rate of one bucket's all-reduce, GB/s of gradient bytes")
@@ -60,7 +66,7 @@ def main():
     os.environ.setdefault("NCCL_MAX_NCHANNELS", str(max(chans)))
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=dev, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=False))
+    dist.init_process_group("nccl", device_id=dev, pg_options=dist.ProcessGroupNCCL.Options(is_high_priority_stream=(a.prio < 0)))
     lib = ctypes.CDLL(rt.LIB_PATH)
     lib.sitk_debug_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.sitk_debug_occupy.restype = ctypes.c_int
@@ -78,31 +84,49 @@ def main():
         model = SiT(dim=192, depth=12, heads=3, mlp_dim=768, dim_head=64, num_patches=320, num_vertices=153, num_channels=4,
                     compute_dtype=a.dtype)
         eng = engine.TrainEngine(model, B, input_layout="surface", lr=1e-5, momentum=0.9, process_group=dist.group.WORLD, device=dev,
-                                 wgrad_overlap_cus=side, dp_channels=(ch or chans[0]), wgrad_overlap=nlay, wgrad_overlap_group=group)
+                                 wgrad_overlap_cus=side, dp_channels=(ch or chans[0]), wgrad_overlap=nlay, wgrad_overlap_group=group,
+                                 dp_stream_priority=a.prio, dp_bucket_launches=a.per_bucket)
         assert eng.dp_side, "expected the side-stream form"
         log, tl = [], []
+        if not ch and a.timeline:
+            orig0 = eng._allreduce
+
+            def ready_only(lo, hi, orig0=orig0):
+                orig0(lo, hi)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream())
+                tl.append(("ready", e))
+            eng._allreduce = ready_only
         if ch:
             orig = eng._allreduce
 
             def wrapped(lo, hi, orig=orig, eng=eng, log=log, ch=ch):
                 n0 = len(eng._pending)
                 orig(lo, hi)
-                us = max(1, int(a.latency_us + (hi - lo) * 4 / (a.gbs * 1e3)))
+                us = max(1, int(a.latency_us + (hi - lo) * 4 / (a.gbs * 1e3))) if a.standin_us is None else max(1, int(a.standin_us))
                 ev0, ev1 = torch.cuda.Event(enable_timing=a.timeline), torch.cuda.Event(enable_timing=a.timeline)
-                ev0.record(torch.cuda.current_stream())
-                hp.wait_event(ev0)
+                cur = torch.cuda.current_stream()
+                ds = hp if a.own_stream else cur
+                if a.own_stream or a.timeline:
+                    ev0.record(cur)
+                if a.own_stream:
+                    hp.wait_event(ev0)
                 if a.timeline:
                     evs = torch.cuda.Event(enable_timing=True)
-                    evs.record(hp)
+                    evs.record(ds)
                     tl.append(("ready", ev0)); tl.append(("stand-in start", evs)); tl.append(("stand-in end", ev1))
-                assert lib.sitk_debug_occupy(ch, us, hp.cuda_stream) == 0
-                ev1.record(hp)
+                if a.standin_us is None or a.standin_us > 0:          # (--standin-us 0: the events alone, no kernel)
+                    assert lib.sitk_debug_occupy(ch, us, ds.cuda_stream) == 0
+                ev1.record(ds)
                 eng._pending[n0] = _Both(eng._pending[n0], ev1)
                 log.append(((hi - lo) * 4, us))
             eng._allreduce = wrapped
         g = torch.Generator(device=dev).manual_seed(100)
         x = torch.randn((B, 40962, 4), device=dev, generator=g)
         y = torch.randn((B,), device=dev, generator=g) * 2 + 40
+        torch.cuda.synchronize()
+        if a.main_prio:
+            torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=a.main_prio))
         eng.load_batch(x, y)
         for _ in range(5):
             eng.step()
@@ -134,9 +158,15 @@ def main():
             eng._segment_fns = seg_fns
             eng._finish_backward = lambda: (orig_fin(), mark("finish stage done"))
             eng._optimizer = lambda: (orig_opt(), mark("optimizer done"))
+            import ctypes as C
+            cap = 4096
+            ktl = rt.lib.sitk_timeline_create(cap) if os.environ.get("SITK_TIMELINE_SIDE") == "1" else None
             for st in range(3):
                 tl.clear()
                 torch.cuda.synchronize()
+                if ktl:
+                    rt.lib.sitk_timeline_reset(ktl)
+                    eng.cfg.timeline = ktl
                 mark("step start")
                 eng.step()
                 torch.cuda.synchronize()
@@ -144,6 +174,20 @@ def main():
                 print(f"  timeline of step {st} (us from the step's start; events in issue order):")
                 for label, e in tl[1:]:
                     print(f"    {t0.elapsed_time(e) * 1e3:9.1f}  {label}")
+                if ktl and st == 2:
+                    us, lab = (C.c_float * cap)(), (C.c_char_p * cap)()
+                    n = rt.lib.sitk_timeline_read(ktl, us, lab, cap)
+                    acc, seg = 0.0, []
+                    for i in range(n):
+                        k = lab[i].decode()
+                        if k == "begin":
+                            seg.append("   | " + f"(gap {us[i]:.0f})")
+                            continue
+                        seg.append(f"{k} {us[i]:.1f}")
+                    print("  main-stream kernels of step 2 (sitk_timeline: interval from the previous mark, us): " + ", ".join(seg))
+            if ktl:
+                eng.cfg.timeline = None
+                rt.lib.sitk_timeline_destroy(ktl)
         nb = sum(len(b) for b in eng.bucket_plan)
         extra = "  buckets (bytes, stand-in us): " + ", ".join(f"({b}, {u})" for b, u in log[-nb:]) if ch else ""
         print(f"{eng.wgrad_overlap} side layers, {group} per launch, {side:3d} workgroups, stand-in {ch:2d} channels: {ms:.3f} ms per step ({(ms - base) * 1e3:+5.0f} us; host enqueue "
