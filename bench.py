@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches")
     ap.add_argument("--graph", action="store_true", help="force hipGraph replay (no side stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="time bound of the CPU oracle loop (rank 0)")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: the patch gather on the main stream, in front of the patch embedding")
     ap.add_argument("--wgrad-overlap", type=int, default=None,
@@ -355,7 +356,7 @@ def main():
         if not args.no_cpu_baseline:
             # at EVERY N (north_star: "in the same run"): rank 0 times the oracle behind the timed region while the other ranks
             # sleep on the rendezvous store (a blocking socket read: no spinning thread competes for the host's cores)
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
     if pg is not None:
         from datetime import timedelta

@@ -392,14 +392,18 @@ def test_bench_gpus_2_as_typed_prints_one_json_line():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline",
-                        "--no-probe", "--steps", "3", "--warmup", "2", "--batch", "4"], capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--cpu-baseline-seconds",
+                        "2", "--no-probe", "--steps", "3", "--warmup", "2", "--batch", "4"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[:3000] + "\n...\n" + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["value"] > 0
+    # north_star: the CPU reference timed "in the same run" at EVERY N -- rank 0 runs the oracle loop behind the timed region while
+    # the other ranks sleep on the rendezvous store (VERDICT r4 missing 6)
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle/sit_oracle.py" in cb["sample"]
 
 
 # ---- RCCL under the engine: a ONE-rank NCCL (= RCCL) group runs the data-parallel form of the step -- backward slices, one
