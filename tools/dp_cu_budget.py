@@ -2,8 +2,8 @@
 a copy -- the 2.46 ms "per-rank" step says nothing about the CUs and the time a real all-reduce takes.)
 
 The data-parallel form of the step on a ONE-rank RCCL group (every collective on the real backend), plus, behind every
-bucket's all-reduce and ordered exactly like it (a high-priority stream that waits for the stream the collective was issued
-from; the step's main stream waits for it where it waits for the collective), a DUMMY kernel of `--channels` workgroups x 512
+bucket's all-reduce, on the stream the collective was issued from (--own-stream 1: on a stream of its own behind an event, round 4's
+form, whose cost turned out to be that extra stream: profiles/r05_dp_budget.txt), a DUMMY kernel of `--channels` workgroups x 256
 threads that holds its CUs for the time the bucket needs on the wire: --latency-us + bytes / (--gbs GB/s) (SURVEY section 5:
 22 MB in ~0.25 ms per ring = 88 GB/s; the mesh algorithm is ~7x faster; 30 us for the launch + the ring's hops of a small
 message).  Round 5: the stand-in has the footprint of RCCL's own kernel on gfx950 (256 threads, 19 744 B of LDS, 280 registers:
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--main-prio", type=int, default=0, help="-1: run the step itself on a HIGH-priority stream (main high, all-reduce path "
                     "normal, side stream lowest: three priority classes = three sets of hardware queues)")
-    ap.add_argument("--own-stream", type=int, default=1, help="1: the stand-in runs on a stream of its own behind an event (round 4's form); "
+    ap.add_argument("--own-stream", type=int, default=0, help="1: the stand-in runs on a stream of its own behind an event (round 4's form); "
                     "0: on the stream the bucket's all-reduce was issued from (the engine's bucket stream / the main stream)")
     ap.add_argument("--per-bucket", type=int, default=None, help="side launches per all-reduce bucket (engine default: 2)")
     ap.add_argument("--standin-us", type=float, default=None, help="fixed stand-in time per bucket instead of latency + bytes / rate")
