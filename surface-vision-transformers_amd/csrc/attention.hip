@@ -617,6 +617,11 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_res_kernel(const h16* __r
   }
 }
 
+#ifdef SITK_AB
+// (diagnostic build only: QT query tiles per wave in the resident forward -- measured slower, see the file's header)
+#include "experimental/attn_qt.inc"
+#endif
+
 // FOLD (D = 192): the gradient of the attention output is computed here instead of by a GEMM launch of its own:
 //   dO[q, 64 h + c] = sum_j dxmid[q, j] * Wo[j, 64 h + c]      (to_out backward, utils/utils.py:26 layout: wo_t = Wo^T, (I, D))
 // The head's 64 rows of wo_t (24 KB) sit in LDS next to K and V; per 16-query tile the product is taken TRANSPOSED
@@ -1487,6 +1492,13 @@ static int run_fwd(const void* qkv, void* o, float* lse, int B, int N, int H, fl
     { int rc; if (pk_try_fwd(qkv, o, lse, B, N, H, scale, s, &rc)) return rc; }
 #endif
     if (N <= RES_MAX_N) {
+#ifdef SITK_AB
+      static const int qt_var = sitk_ab_switch("SITK_ATTN_FWD_QT", 0);     // 82 = 8 waves x 2 tiles, 83 = 8 x 3, 122 = 12 x 2
+      if (qt_var == 82) hipLaunchKernelGGL((attn_fwd_resq_kernel<8, 2>), dim3(B * H), dim3(512), 0, s, reinterpret_cast<const h16*>(qkv), reinterpret_cast<h16*>(o), lse, N, H, scale);
+      else if (qt_var == 83) hipLaunchKernelGGL((attn_fwd_resq_kernel<8, 3>), dim3(B * H), dim3(512), 0, s, reinterpret_cast<const h16*>(qkv), reinterpret_cast<h16*>(o), lse, N, H, scale);
+      else if (qt_var == 122) hipLaunchKernelGGL((attn_fwd_resq_kernel<12, 2>), dim3(B * H), dim3(768), 0, s, reinterpret_cast<const h16*>(qkv), reinterpret_cast<h16*>(o), lse, N, H, scale);
+      else
+#endif
       hipLaunchKernelGGL(attn_fwd_res_kernel<16>, dim3(B * H), dim3(1024), 0, s, reinterpret_cast<const h16*>(qkv),
                          reinterpret_cast<h16*>(o), lse, N, H, scale);
       return check_launch("attention_fwd_res");
