@@ -122,20 +122,40 @@ def side_launch_groups(layer_begin, layer_end, side_layers, per_launch=2):
     return groups
 
 
+def side_bucket_sizes(n_launches, per_bucket):
+    """Side launches per early all-reduce bucket as a list: an int k -> buckets of k consecutive launches (the last one
+    smaller); a sequence -> those sizes, and side launches it does not cover travel with the FINAL bucket (behind the finish
+    stage, which joins the side stream)."""
+    if isinstance(per_bucket, int):
+        k = max(1, per_bucket)
+        return [min(k, n_launches - i) for i in range(0, n_launches, k)]
+    sizes = [int(v) for v in per_bucket]
+    if any(v < 1 for v in sizes) or sum(sizes) > n_launches:
+        raise ValueError(f"dp_bucket_launches {sizes}: sizes >= 1 that cover at most the {n_launches} side launches")
+    return sizes
+
+
 def grad_write_stages_side(model, task, groups, per_bucket=1):
-    """The side-stream form's counterpart of grad_write_stages: stage i < len(groups) = behind side launch i (the Linear weights
-    and biases of its layers -- the launch writes nothing else); stage len(groups) = behind the finish stage: every LayerNorm
-    parameter (one reduction at the end of backward sums their partials), the layers whose weight gradients run in the tail
-    launch behind the chain, the patch embedding, cls_token, pos_embedding, mlp_head.* and, under MPP, to_original.* and
-    mask_token.  per_bucket > 1: `per_bucket` consecutive side launches form ONE bucket (final behind the last of them)."""
+    """The side-stream form's counterpart of grad_write_stages: stage b < n_early = behind the LAST side launch of early bucket b
+    (the Linear weights and biases of its launches' layers -- a side launch writes nothing else); stage n_early = behind the
+    finish stage: every LayerNorm parameter (one reduction at the end of backward sums their partials), the layers whose weight
+    gradients run in the tail launch behind the chain, side launches no early bucket covers, the patch embedding, cls_token,
+    pos_embedding, mlp_head.* and, under MPP, to_original.* and mask_token.  per_bucket: see side_bucket_sizes."""
     sit = model.transformer if task == "mpp" else model
-    final = (len(groups) + per_bucket - 1) // per_bucket
+    sizes = side_bucket_sizes(len(groups), per_bucket)
+    final = len(sizes)
+    bucket_of = {}
+    i = 0
+    for b, n in enumerate(sizes):
+        for _ in range(n):
+            bucket_of[i] = b
+            i += 1
     stage = {id(p): final for p in model.parameters()}
     for i, layers in enumerate(groups):
         for l in layers:
             for name, p in sit.transformer.layers[l].named_parameters():
                 if ".norm." not in "." + name:
-                    stage[id(p)] = i // per_bucket           # per_bucket consecutive side launches share one all-reduce bucket
+                    stage[id(p)] = bucket_of.get(i, final)
     return stage
 
 
@@ -291,14 +311,19 @@ class TrainEngine:
             frozen |= {id(p) for p in sit.mlp_head.parameters()}
             if self.optimize == "sit":
                 frozen |= {id(p) for p in self.ssl.to_original.parameters()} | {id(self.ssl.mask_token)}
-        # Side launches per all-reduce bucket.  Measured with a stand-in of RCCL's footprint and SURVEY section 5's wire time on
-        # the bucket's own stream (profiles/r05_dp_budget.txt): every collective costs the step ~30 us whatever its size or
-        # duration (a 16-workgroup kernel that wants whole CUs finds them only at a kernel boundary of the chain), while an
-        # early bucket's wire time hides -- 1 launch per bucket (4 + 1 collectives) +280 - 300 us per step, 2 per bucket +185,
-        # ALL side launches in one early bucket (1 + 1 collectives, the early one beside the tail launch) +126 - 148 us: the
-        # default.  (More, smaller buckets start earlier and are the safer choice if the wire turns out slower than 88 GB/s.)
-        self.dp_bucket_launches = max(1, int(dp_bucket_launches)) if dp_bucket_launches else max(1, len(self._side_groups))
-        self._n_early = (len(self._side_groups) + self.dp_bucket_launches - 1) // self.dp_bucket_launches
+        # Side launches per early all-reduce bucket.  Measured with a stand-in of RCCL's footprint and SURVEY section 5's wire time
+        # on the bucket's own stream (profiles/r05_dp_budget.txt): every collective costs the step ~30 us whatever its size or
+        # duration (a 16-workgroup kernel that wants whole CUs finds them only at a kernel boundary of the chain), while an early
+        # bucket's wire time hides -- one launch per bucket (4 + 1 collectives) +280 - 300 us per step, two per bucket +177 - 186,
+        # ALL side launches in one early bucket (beside the tail launch) +137 - 143, [all but the last, the last] +144 - 166 -- and
+        # with the wire at HALF the assumed rate +290 against +236 - 251: the default is the latter, one collective more for a
+        # first bucket that is on the wire a whole side launch before the chain ends.
+        # (an int = launches per bucket; a list = the early buckets' sizes, uncovered launches travel with the final bucket: [3] =
+        # the first three side launches early -- on the wire a whole side launch before the chain ends --, the fourth with the tail)
+        n_launches = len(self._side_groups)
+        self.dp_bucket_launches = dp_bucket_launches if dp_bucket_launches else ([n_launches - 1, 1] if n_launches >= 2 else 1)
+        self._bucket_sizes = side_bucket_sizes(len(self._side_groups), self.dp_bucket_launches) if self.dp_side else []
+        self._n_early = len(self._bucket_sizes)
         side_stage = grad_write_stages_side(self.module, task, self._side_groups, self.dp_bucket_launches) if self.dp_side else {}
         self.fp = FlatParams(self.module, self.device, grad_extra=self.D * self.ld + 4 * _ALIGN + self.D,
                              order=lambda p: (id(p) in frozen, side_stage.get(id(p), 0)))
@@ -842,7 +867,7 @@ class TrainEngine:
                 raise rt.SitkError(f"engine: {n_side} side launches, bucket plan built for {len(self._side_groups)}")
             else:
                 for i in range(self._n_early):
-                    last = min((i + 1) * self.dp_bucket_launches, n_side) - 1      # the bucket is final behind its LAST side launch
+                    last = sum(self._bucket_sizes[:i + 1]) - 1                     # the bucket is final behind its LAST side launch
                     rt.check(rt.lib.sitk_overlap_wait_side_launch(self._overlap, last, self._ar_stream.cuda_stream))
                     with torch.cuda.stream(self._ar_stream):
                         for lo, hi in self.bucket_plan[i]:

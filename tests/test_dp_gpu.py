@@ -290,7 +290,7 @@ def _worker4(rank, world, port, q):
     eng = engine.TrainEngine(_make4(), B4 // world, input_layout="surface", lr=LR4, momentum=0.9, process_group=dist.group.WORLD,
                              device="cuda:0")
     assert eng.dp_side and not eng.use_graph and eng._prefetch        # one bucket per side launch, prefetched gather
-    assert eng._side_groups == [[4, 5], [2, 3]] and len(eng.bucket_plan) == 2       # one early bucket (both side launches) + the final one
+    assert eng._side_groups == [[4, 5], [2, 3]] and len(eng.bucket_plan) == 3       # two early buckets (one per side launch) + the final one
     for _ in range(3):
         eng.step(x[shard].cuda(), y[shard].cuda())
     torch.cuda.synchronize()
@@ -493,8 +493,8 @@ def _rccl_side_worker(port, dtype, q, per_bucket=None):
                              process_group=dist.group.WORLD, device="cuda:0", dp_bucket_launches=per_bucket)
     # one backward call, layers 3, 2 and 1 on the side stream in two side launches = two early buckets + the final one
     assert eng.dp and eng.dp_side and not eng.use_graph and eng.slices == [(0, 4)] and eng.wgrad_overlap == 3
-    # (default: all side launches in ONE early bucket; the test also runs one launch per bucket)
-    assert eng._side_groups == [[2, 3], [1]] and len(eng.bucket_plan) == (3 if per_bucket == 1 else 2)
+    # (default: [all side launches but the last, the last] + the final bucket; the test also runs ALL launches in one early bucket)
+    assert eng._side_groups == [[2, 3], [1]] and len(eng.bucket_plan) == (2 if per_bucket == 2 else 3)
     assert all(len(b) == 1 for b in eng.bucket_plan)
     losses = []
     for _ in range(3):
@@ -505,7 +505,7 @@ def _rccl_side_worker(port, dtype, q, per_bucket=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dtype,per_bucket", [("bf16", None), ("f16", None), ("bf16", 1)])
+@pytest.mark.parametrize("dtype,per_bucket", [("bf16", None), ("f16", None), ("bf16", 2)])
 def test_one_rank_rccl_group_with_side_stream_matches_plain_engine(dtype, per_bucket):
     import sitk  # noqa: F401
     from sitk import engine

@@ -49,7 +49,8 @@ def main():
                     "normal, side stream lowest: three priority classes = three sets of hardware queues)")
     ap.add_argument("--own-stream", type=int, default=0, help="1: the stand-in runs on a stream of its own behind an event (round 4's form); "
                     "0: on the stream the bucket's all-reduce was issued from (the engine's bucket stream / the main stream)")
-    ap.add_argument("--per-bucket", type=int, default=None, help="side launches per all-reduce bucket (engine default: 2)")
+    ap.add_argument("--per-bucket", default=None, help="side launches per early all-reduce bucket: an int, or a comma list of bucket sizes "
+                    "(launches it does not cover travel with the final bucket); engine default: all side launches in one early bucket")
     ap.add_argument("--standin-us", type=float, default=None, help="fixed stand-in time per bucket instead of latency + bytes / rate")
     ap.add_argument("--timeline", action="store_true", help="HIP-event timeline of three steps (no profiler attached): when each bucket is "
                     "ready, when its stand-in starts / ends, when the chain, the finish stage and the optimizer end")
@@ -85,7 +86,7 @@ def main():
                     compute_dtype=a.dtype)
         eng = engine.TrainEngine(model, B, input_layout="surface", lr=1e-5, momentum=0.9, process_group=dist.group.WORLD, device=dev,
                                  wgrad_overlap_cus=side, dp_channels=(ch or chans[0]), wgrad_overlap=nlay, wgrad_overlap_group=group,
-                                 dp_stream_priority=a.prio, dp_bucket_launches=a.per_bucket)
+                                 dp_stream_priority=a.prio, dp_bucket_launches=(None if a.per_bucket is None else (int(a.per_bucket) if a.per_bucket.isdigit() else [int(v) for v in a.per_bucket.split(",")])))
         assert eng.dp_side, "expected the side-stream form"
         log, tl = [], []
         if not ch and a.timeline:
