@@ -88,10 +88,21 @@ def test_bucket_plan_reduces_every_gradient_once_and_only_after_it_is_written(ta
         assert not any(a <= lo < b for a, b in plan[0]), "to_original reduced with slice 0 again"
 
 
-@pytest.mark.parametrize("optimize", ["all", "sit"])
-@pytest.mark.parametrize("task", ["regression", "mpp"])
-@pytest.mark.parametrize("per_bucket", [1, 2, 3, [1], [2, 1]])
-@pytest.mark.parametrize("depth,side", [(12, 8), (4, 3), (2, 1), (6, 4)])
+def _side_plan_cases():
+    """(task, depth, side layers, optimizer scope, side launches per bucket): every combination that exists -- optimize='sit' is an
+    MPP option, explicit bucket sizes must not cover more side launches than the depth makes."""
+    cases = []
+    for depth, side in [(12, 8), (4, 3), (2, 1), (6, 4)]:
+        launches = (side + 1) // 2
+        for per_bucket in [1, 2, 3, [1], [2, 1], [launches - 1, 1] if launches >= 2 else [1]]:
+            if not isinstance(per_bucket, int) and sum(per_bucket) > launches:
+                continue
+            for task, optimize in [("regression", "all"), ("mpp", "all"), ("mpp", "sit")]:
+                cases.append((task, depth, side, optimize, per_bucket))
+    return cases
+
+
+@pytest.mark.parametrize("task,depth,side,optimize,per_bucket", _side_plan_cases())
 def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, depth, side, optimize, per_bucket):
     """Round 5: the data-parallel form of the fused path all-reduces one bucket per SIDE LAUNCH of
     sitk_encoder_bwd_overlap.  The spec, restated from include/sitk.h (ABI 10) and csrc/encoder.hip's launch order, not from
@@ -102,8 +113,6 @@ def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, d
     (c) no parameter sits in a bucket issued before its writer; (d) parameters outside the optimizer's scope are not reduced."""
     import sitk  # noqa: F401
     from sitk import engine
-    if optimize == "sit" and task != "mpp":
-        pytest.skip("optimize='sit' is an MPP option")
     ssl = _mpp_module(depth)
     module = ssl if task == "mpp" else ssl.transformer
     sit = ssl.transformer
@@ -114,8 +123,6 @@ def test_side_launch_bucket_plan_is_one_range_per_launch_and_never_early(task, d
         want_groups.append(list(range(top - n, top)))
         top -= n
     assert groups == want_groups and sum(len(g) for g in groups) == side
-    if not isinstance(per_bucket, int) and sum(per_bucket) > len(groups):
-        pytest.skip("bucket sizes cover more side launches than this depth makes")
     stage = engine.grad_write_stages_side(module, task, groups, per_bucket)
     sizes = engine.side_bucket_sizes(len(groups), per_bucket)
     n_early = len(sizes)
