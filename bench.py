@@ -12,13 +12,14 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or typed bare -
 launcher as a CHILD process (before anything touches the GPU), relays its output and exits with its return code.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  also         : (default N = 1 run only) the other numbers the docs quote, timed behind the headline under the same clock --
-                 f16 mode, the data-parallel form of the step, BASELINE configs 3 and 5 (child processes, 10 steps each) and
-                 the headline with a new batch loaded every step
+  also         : (default N = 1 run only; skipped under a profiler and for A/B flags) the other numbers the docs quote, timed
+                 behind the headline under the same clock -- the f16 mode IN this process with the headline's steps / warmup (the
+                 parity-compliant figure), the headline with a new batch loaded every step, and as child processes (10 steps
+                 each) the data-parallel form of the step and BASELINE configs 3 and 5
   roofline     : the dominant kernel (by time share in profiles/) timed live with HIP events on the launch
                  stream, with its algorithmic FLOPs per launch
   cpu_baseline : the CPU oracle (oracle/sit_oracle.py, "port") on this host's cores, config
-                 BASELINE configs[0] (B = 4), bounded to ~15 s
+                 BASELINE configs[0] (B = 4), bounded to ~15 s; at every N (rank 0, behind the timed region)
 """
 import argparse
 import json
