@@ -26,7 +26,14 @@ constexpr int FE_SMEM_BYTES = fe_smem_bytes(4);            // 100352
 // workgroups (one per CU), so its duration is that of ONE workgroup: 96-row workgroups are 25 % shorter than
 // 128-row ones as long as all of them still fit on the 256 CUs at once (BASELINE config 2: 20 544 rows = 214
 // workgroups of 96 instead of 161 of 128).
-static inline int fused_block_rows(int64_t rows) { return (rows + 95) / 96 <= 256 ? 96 : 128; }
+// Larger problems run in rounds of 256 workgroups: the choice is the one with fewer rounds x rows -- 96 rows again wherever
+// its last round costs less than what 128-row workgroups add to every round (B = 128: two rounds either way, 2 x 96 against
+// 2 x 128).  Round 5: until then every problem of more than 256 x 96 rows took 128-row workgroups, which also sent it down the
+// less fused path (the block-tail and chained backward kernels exist for 96 rows only): 4.78 ms per step at B = 128.
+static inline int fused_block_rows(int64_t rows) {
+  const int64_t r96 = ((rows + 95) / 96 + 255) / 256 * 96, r128 = ((rows + 127) / 128 + 255) / 256 * 128;
+  return r96 <= r128 ? 96 : 128;
+}
 // the BACKWARD kernels' choice (d to_qkv + norm backward, MLP backward and their pair launch share one partition).  Diagnostic
 // build: SITK_BWD_ROWS128=1 forces 128-row workgroups -- 161 instead of 214 at BASELINE config 2 -- to measure what room for the
 // all-reduce channels of a data-parallel step costs (tools/dp_cu_budget.py); the shipped library takes fused_block_rows().

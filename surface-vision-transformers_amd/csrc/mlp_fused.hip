@@ -856,7 +856,7 @@ static int attn_out_mlp_launch(const void* o_c, const void* wo_c, const float* b
   SITK_REQUIRE((mean == nullptr) == (rstd == nullptr), "%s: mean and rstd go together", what);
   SITK_TRY(mlp_check(what, rows, D, M, dtype));
   SITK_REQUIRE(sitk_attn_out_mlp_fused_supported(rows, D, I, M, dtype),
-               "%s: needs heads * 64 == 192 and at most 24576 rows (got I %d rows %lld)", what, I, (long long)rows);
+               "%s: needs heads * 64 == 192 and a row count that takes 96-row workgroups (got I %d rows %lld)", what, I, (long long)rows);
   MlpParams p = {};
   p.o = reinterpret_cast<const h16*>(o_c); p.wo = reinterpret_cast<const h16*>(wo_c); p.bo = bo; p.xmid = xmid;
   p.x = x; p.gamma = ln_w; p.beta = ln_b;
@@ -981,7 +981,7 @@ extern "C" int sitk_ln_gemm_mlp_bwd(const void* dqkv, const void* wqkv_t_c, cons
   SITK_REQUIRE(dqkv && wqkv_t_c && x && mean1 && rstd1 && ln1_w && dx && dx_c && partials1 && xmid && mean2 && rstd2 && ln2_w &&
                w2t_c && w1t_c && gd && du && dx_mid && dx_mid_c && partials2, "ln_gemm_mlp_bwd: null pointer");
   SITK_REQUIRE(sitk_ln_gemm_mlp_bwd_supported(rows, D, N, M, dtype),
-               "ln_gemm_mlp_bwd: needs h16, dim 192, 96-row workgroups (at most 24576 rows) (got rows %lld dim %d N %d mlp_dim %d)",
+               "ln_gemm_mlp_bwd: needs h16, dim 192 and a row count that takes 96-row workgroups (got rows %lld dim %d N %d mlp_dim %d)",
                (long long)rows, D, N, M);
   LnGemmParams p1 = {};
   p1.x = x; p1.gamma = ln1_w; p1.w = reinterpret_cast<const h16*>(wqkv_t_c);
