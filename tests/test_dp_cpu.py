@@ -224,3 +224,21 @@ def test_sharded_gradients_average_to_full_batch_gradient():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert err < 1e-5, err
+
+
+def test_side_bucket_sizes_and_launch_groups():
+    """The two small rules the data-parallel engine builds its plan from (include/sitk.h, ABI 10): side launch i carries the
+    `per_launch` layers below layer_end - per_launch i; early buckets are consecutive side launches, what a size list leaves
+    uncovered travels with the final bucket."""
+    import sitk  # noqa: F401
+    from sitk import engine
+    assert engine.side_launch_groups(0, 12, 8) == [[10, 11], [8, 9], [6, 7], [4, 5]]
+    assert engine.side_launch_groups(0, 12, 9, 3) == [[9, 10, 11], [6, 7, 8], [3, 4, 5]]
+    assert engine.side_launch_groups(0, 4, 3) == [[2, 3], [1]]
+    assert engine.side_launch_groups(2, 6, 8, 1) == [[5], [4], [3], [2]]
+    assert engine.side_bucket_sizes(4, 1) == [1, 1, 1, 1] and engine.side_bucket_sizes(4, 3) == [3, 1]
+    assert engine.side_bucket_sizes(4, 4) == [4] and engine.side_bucket_sizes(4, 9) == [4]
+    assert engine.side_bucket_sizes(4, [3]) == [3] and engine.side_bucket_sizes(4, [3, 1]) == [3, 1]
+    for bad in ([0], [3, 2], [5]):
+        with pytest.raises(ValueError):
+            engine.side_bucket_sizes(4, bad)
