@@ -406,6 +406,27 @@ def test_bench_gpus_2_as_typed_prints_one_json_line():
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "oracle/sit_oracle.py" in cb["sample"]
 
 
+def test_bench_gpus_4_over_gloo_runs_the_side_stream_form_on_four_ranks():
+    """Four ranks (gloo transport, all on this box's one GPU: the pool allows six processes on the card) through `bench.py --gpus 4`:
+    the launcher, the side-stream data-parallel form with its early buckets (8 samples = 2 568 tokens per rank: side launches are
+    made), the rendezvous-store wait of ranks 1 .. 3 behind rank 0's CPU baseline.  More ranks than two have never met the bucket
+    plan otherwise (RCCL needs one GPU per rank)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--backend", "gloo", "--cpu-baseline-seconds",
+                        "2", "--no-probe", "--steps", "3", "--warmup", "2", "--batch", "8"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[:3000] + "\n...\n" + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 32 and out["config"]["wgrad_overlap_layers"] == 8
+    assert 0 < out["config"]["loss_after"] < 1e4 and out["cpu_baseline"]["value"] > 0
+
+
 # ---- RCCL under the engine: a ONE-rank NCCL (= RCCL) group runs the data-parallel form of the step -- backward slices, one
 # hipGraph per segment, every bucket's all-reduce on the backend's own stream between the replays -- on the real backend
 def _rccl_worker(port, task, use_graph, q):
