@@ -27,10 +27,10 @@ def run_smoke():
         eng = engine.TrainEngine(model, 4, input_layout="surface", lr=0.0, momentum=0.0, use_graph=False, keep_grads=True)
         loss = float(eng.step(torch.from_numpy(xs).to(dev), torch.from_numpy(y).to(dev)))
         assert abs(loss - float(lref)) / float(lref) < tol, (dtype, loss, float(lref))
-        worst = 0.0
+        worst = (0.0, "")
         for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
             e = float((p.grad.cpu().double() - q.grad.double()).norm() / (q.grad.double().norm() + 1e-30))
             assert e < tol, (dtype, k, e)
-            worst = max(worst, e)
-        print(f"smoke[{dtype}]: loss {loss:.6f} (oracle {float(lref):.6f}), worst gradient {worst:.2e} (bar {tol:g})")
+            worst = max(worst, (e, k))
+        print(f"smoke[{dtype}]: loss {loss:.6f} (oracle {float(lref):.6f}), worst gradient {worst[0]:.2e} ({worst[1]}; bar {tol:g})")
     torch.cuda.synchronize()
