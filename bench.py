@@ -146,7 +146,7 @@ def also_lines(timeout_s=240):
 def under_profiler():
     """A profiler preload in the environment (rocprofv3 / rocprof attach through these): the `also` object is skipped then --
     its extra steps and child processes would end up in the trace of the run that is being profiled."""
-    return any(k in os.environ for k in ("HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARIES")) or \
+    return any(k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES") or k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ) or \
         "rocprof" in os.environ.get("LD_PRELOAD", "")
 
 
