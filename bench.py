@@ -124,7 +124,13 @@ def also_lines(timeout_s=240):
     out = {}
     # the children must not inherit a profiler's preload (rocprofv3 attaches through these): they would write their traces
     # into the parent's output directory
-    env = {k: v for k, v in os.environ.items() if not (k in ("LD_PRELOAD", "HSA_TOOLS_LIB") or k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")))}
+    env = {k: v for k, v in os.environ.items() if not (k == "HSA_TOOLS_LIB" or k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")))}
+    if "LD_PRELOAD" in env:        # (only a profiler's own preload goes; whatever else the host preloads stays with the children)
+        kept = [t for t in env["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in t and "roctracer" not in t]
+        if kept:
+            env["LD_PRELOAD"] = " ".join(kept) if " " in os.environ["LD_PRELOAD"] and ":" not in os.environ["LD_PRELOAD"] else ":".join(kept)
+        else:
+            del env["LD_PRELOAD"]
     for name, extra in ALSO_SPECS.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "3", "--no-probe", "--no-cpu-baseline",
                "--no-also"] + extra
