@@ -291,10 +291,11 @@ class TrainEngine:
         fused = self.dtype != rt.F32 and bool(rt.lib.sitk_mlp_fused_supported(self.D, tr.mlp_dim, self.dtype))
         # Data parallelism on the 16-bit fused path, eager launches (the default there): the SAME launch sequence as on one GPU
         # -- one backward call, the first 2 / 3 of the layers' weight gradients on the side stream, two layers per side launch,
-        # the rest in one tail launch behind the chain -- plus one all-reduce bucket per side launch: the library records an
-        # event behind each (sitk_overlap_wait_side_launch), and the flat buffers are ordered by write stage so that a
-        # launch's gradients are one contiguous range (round 4: two buckets, the first -- 58 % of the bytes -- final only 40 us
-        # after the chain; now the first 3.5 MB are final ~1.4 ms into a 2.4 ms step and the last bucket is the tail's).
+        # the rest in one tail launch behind the chain -- plus all-reduce buckets made of side launches: the library records an
+        # event behind each launch (sitk_overlap_wait_side_launch), and the flat buffers are ordered by write stage so that a
+        # bucket's gradients are one contiguous range (round 4: two slices, the first bucket -- 58 % of the bytes -- final only
+        # 40 us after the chain; now a side launch's 3.5 MB are final from ~1.4 ms into a 2.4 ms step on, the last bucket is the
+        # tail's; which launches share a bucket: dp_bucket_launches below).
         self.dp_side = bool(self.dp and fused and use_graph is not True and bwd_slices is None and tr.depth >= 2
                             and (wgrad_overlap is None or wgrad_overlap > 0))
         self.wgrad_overlap_group = int(wgrad_overlap_group) if wgrad_overlap_group else 2
