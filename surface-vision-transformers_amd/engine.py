@@ -217,9 +217,16 @@ class TrainEngine:
     use_graph:    True = the step is replayed from hipGraph(s) (one per segment); False = eager launches.
                   None (default) with wgrad_overlap None: the faster of the two forms measured for the configuration --
                   eager + 8 of 12 layers on the side stream for the 16-bit fused path on one GPU (dim 192); under a process
-                  group the same path runs its two-slice `dp_side` form (eager: layers 4..11's weight gradients on the side
-                  stream, their bucket all-reduced beside the rest of the chain, layers 0..3 + the patch embedding on the main
-                  stream); hipGraph replay without a side stream everywhere else (other widths, f32, use_graph=True).
+                  group the same path runs its `dp_side` form: the SAME launch sequence plus all-reduce buckets behind the
+                  side launches (see dp_bucket_launches); hipGraph replay without a side stream everywhere else (other widths,
+                  f32, use_graph=True).
+    dp_bucket_launches: data-parallel form of the fused path: side launches per early all-reduce bucket -- an int, or a list of
+                  bucket sizes (side launches a list does not cover travel with the final bucket); None = [all but the last,
+                  the last].  dp_channels: RCCL channels (= workgroups of an all-reduce) the weight-gradient launch behind
+                  the chain leaves CUs for (16; set NCCL_MAX_NCHANNELS to the same value before creating the process group).
+                  dp_stream_priority: priority of the stream the early buckets are reduced from (0; a high-priority stream
+                  beside the chain cost a whole step in every measurement: profiles/r05_dp_budget.txt).
+    wgrad_overlap_group: layers per side launch (2; 1 - 3).
 
     The learning rate (and Adam's step count) live in device memory: `set_lr()` takes effect in captured graphs too,
     so the schedulers of tools/pretrain.py:42-50 can drive the engine.  `load_dataset()` keeps a whole data set
