@@ -242,3 +242,28 @@ def test_side_bucket_sizes_and_launch_groups():
     for bad in ([0], [3, 2], [5]):
         with pytest.raises(ValueError):
             engine.side_bucket_sizes(4, bad)
+
+
+@pytest.mark.parametrize("nsl", [1, 3])
+def test_slice_bucket_plan_leaves_the_frozen_parameters_out(nsl):
+    """TrainEngine(task='mpp', optimize='sit') on the slice form (other widths than 192, use_graph=True): the parameters outside the
+    optimizer's scope sit at the END of the flat buffers and no all-reduce range reaches them; everything else is reduced exactly
+    once (tools/pretrain.py:267-280: they never receive an update, so their gradients need no reduction either)."""
+    import sitk  # noqa: F401
+    from sitk import engine
+    depth = 6
+    ssl = _mpp_module(depth)
+    sit = ssl.transformer
+    frozen = {id(p) for p in sit.mlp_head.parameters()} | {id(p) for p in ssl.to_original.parameters()} | {id(ssl.mask_token)}
+    fp = engine.FlatParams(ssl, "cpu", order=lambda p: (id(p) in frozen, 0))
+    n_opt = min(fp.offsets[i][0] for i in frozen)
+    bounds = [round(i * depth / nsl) for i in range(nsl + 1)]
+    slices = [(bounds[i], bounds[i + 1]) for i in range(nsl)][::-1]
+    plan = engine.grad_bucket_plan(fp, engine.grad_write_stages(ssl, "mpp", slices), nsl, limit=n_opt)
+    ranges = sorted(r for point in plan for r in point)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n_opt and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    for name, p in ssl.named_parameters():
+        lo, n = fp.offsets[id(p)]
+        inside = any(a <= lo and lo + n <= b for a, b in ranges)
+        assert inside == (id(p) not in frozen), name
+        assert (lo >= n_opt) == (id(p) in frozen), name
