@@ -301,7 +301,12 @@ def main():
                    "global_batch": B * world, "parallelism": f"dp{world}" + (" (data-parallel form on a one-rank RCCL group)" if args.dp_form and world == 1 else ""),
                    "hip_graph": bool(eng.use_graph),
                    "wgrad_overlap_layers": int(eng.wgrad_overlap),
-                   "loss_after": round(loss, 6)},
+                   "loss_after": round(loss, 6),
+                   # placement of the engine's extra streams, measured at construction (sitk_stream_probe): chain of dependent
+                   # launches alone / with the stream blocked behind an event, us; ok = harmless and concurrent
+                   "stream_probe": {k: [{kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in r.items()} for r in v]
+                                    for k, v in (("side", getattr(eng, "side_stream_probe", [])),
+                                                 ("bucket", getattr(eng, "dp_stream_probe", []))) if v}},
         "step_gflop_per_sample": round(gf, 3),
         "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
     }

@@ -40,7 +40,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 10
+#define SITK_ABI_VERSION 11
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -408,6 +408,20 @@ int sitk_overlap_set_group(sitk_overlap* o, int layers_per_launch);
 int sitk_overlap_side_launches(const sitk_overlap* o);
 int sitk_overlap_wait_side_launch(sitk_overlap* o, int i, sitk_stream_t stream);
 int sitk_overlap_set_tail_cus(sitk_overlap* o, int cus);
+/* Stream placement probe (ABI 11; the reference has one device and one stream: tools/train.py:72).  Measured on MI355X / ROCm 7.2
+ * (tools/micro/blocked_queue.hip, profiles/r06_dp_streams.txt): a stream that sits BLOCKED behind an event is a barrier packet at
+ * the head of its hardware queue, and when that queue shares a dispatch pipe with the queue of the stream that runs a chain of
+ * dependent kernels (hardware queues created four apart do), every dispatch of the chain is delayed by ~35 us -- 2.7 -> 6.5 ms
+ * for 110 kernels -- whatever the blocked stream does afterwards; a stream that shares the chain's hardware QUEUE runs in line
+ * behind it instead.  Which stream lands where follows the creation order of the process's streams, so a data-parallel caller
+ * picks the stream it reduces its early buckets from by measurement: this call runs a chain of 64 dependent ~10-us launches
+ * (214 workgroups) on `main_stream` twice -- alone (chain_free_us), and with `candidate` blocked behind an event that a helper
+ * stream releases after release_us, its wait issued behind the host's enqueue of the chain as the engine issues its collectives
+ * (chain_blocked_us; candidate_done_us = when a small kernel behind that wait finished, from the chain's start).  A good
+ * candidate: chain_blocked_us ~ chain_free_us and candidate_done_us ~ release_us (it ran beside the chain, not behind it).
+ * Synchronises the device (construction time only); both streams are idle again on return.                                  */
+int sitk_stream_probe(sitk_stream_t main_stream, sitk_stream_t candidate, float* chain_free_us, float* chain_blocked_us,
+                      float* candidate_done_us, float* release_us);
 int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_layer_params* params,
                              const sitk_layer_params* grads, const float* x_in, float* dx, void* acts,
                              size_t acts_bytes, void* scratch, size_t scratch_bytes, int layer_begin, int layer_end,

@@ -181,6 +181,73 @@ extern "C" __attribute__((visibility("hidden"))) void* sitk_overlap_next_done_(s
   return (o && o->n_done < (int)o->done.size()) ? (void*)o->done[o->n_done++] : nullptr;
 }
 
+
+// ---- stream placement probe (ABI 11; sitk.h) ----
+// `workgroups` workgroups of 256 threads that hold their CUs for `ticks` of the 100 MHz wall clock (bounded spin).
+__global__ __launch_bounds__(256) void sitk_spin_kernel(unsigned long long ticks, int* sink) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  int spins = 0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks && spins < (1 << 20)) {
+    __builtin_amdgcn_s_sleep(8);
+    ++spins;
+  }
+  if (sink && spins < 0) sink[0] = spins;
+}
+extern "C" int sitk_stream_probe(sitk_stream_t main_stream, sitk_stream_t candidate, float* chain_free_us, float* chain_blocked_us,
+                                 float* candidate_done_us, float* release_us) {
+  if (!chain_free_us || !chain_blocked_us || !candidate_done_us || !release_us) { sitk_rt::set_error("stream_probe: null pointer"); return SITK_ERR_INVALID; }
+  hipStream_t ms = reinterpret_cast<hipStream_t>(main_stream), cs = reinterpret_cast<hipStream_t>(candidate);
+  hipStream_t helper = nullptr;
+  hipEvent_t t0 = nullptr, t1 = nullptr, tc = nullptr, late = nullptr;
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  int rc = SITK_OK;
+  auto fail = [&](const char* what) { sitk_rt::set_error("stream_probe: %s failed", what); rc = SITK_ERR_LAUNCH; };
+  if (hipStreamCreateWithPriority(&helper, hipStreamNonBlocking, prio_least) != hipSuccess) { fail("hipStreamCreate"); return rc; }
+  if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess || hipEventCreate(&tc) != hipSuccess ||
+      hipEventCreate(&late) != hipSuccess)
+    fail("hipEventCreate");
+  const int chain = 64;                                   // dependent launches, one workgroup per CU of 214 CUs, ~10 us each
+  const unsigned long long link_ticks = 1000, late_ticks = 90000;     // 10 us; the helper releases the candidate at 900 us
+  for (int pass = 0; pass < 2 && rc == SITK_OK; ++pass) {
+    if (hipDeviceSynchronize() != hipSuccess) { fail("hipDeviceSynchronize"); break; }
+    if (hipEventRecord(t0, ms) != hipSuccess) { fail("hipEventRecord"); break; }
+    if (pass == 1) {
+      // the helper holds the release event back for 900 us; it starts with the chain (behind t0)
+      if (hipStreamWaitEvent(helper, t0, 0) != hipSuccess) { fail("hipStreamWaitEvent"); break; }
+      hipLaunchKernelGGL(sitk_spin_kernel, dim3(1), dim3(256), 0, helper, late_ticks, (int*)nullptr);
+      if (hipEventRecord(late, helper) != hipSuccess) { fail("hipEventRecord"); break; }
+    }
+    for (int k = 0; k < chain; ++k) hipLaunchKernelGGL(sitk_spin_kernel, dim3(214), dim3(256), 0, ms, link_ticks, (int*)nullptr);
+    if (hipEventRecord(t1, ms) != hipSuccess) { fail("hipEventRecord"); break; }
+    if (pass == 1) {
+      // issued BEHIND the host's enqueue of the chain, as the engine issues its collectives: the candidate sits blocked behind
+      // the release event, then runs one small kernel
+      if (hipStreamWaitEvent(cs, late, 0) != hipSuccess) { fail("hipStreamWaitEvent"); break; }
+      hipLaunchKernelGGL(sitk_spin_kernel, dim3(1), dim3(256), 0, cs, 100ull, (int*)nullptr);
+      if (hipEventRecord(tc, cs) != hipSuccess) { fail("hipEventRecord"); break; }
+      if (hipStreamWaitEvent(ms, tc, 0) != hipSuccess) { fail("hipStreamWaitEvent"); break; }      // (the caller's stream joins)
+    }
+    if (sitk_rt::check_launch("stream_probe") != SITK_OK) { rc = SITK_ERR_LAUNCH; break; }
+    if (hipDeviceSynchronize() != hipSuccess) { fail("hipDeviceSynchronize"); break; }
+    float ms_chain = 0.f, ms_c = 0.f;
+    if (hipEventElapsedTime(&ms_chain, t0, t1) != hipSuccess) { fail("hipEventElapsedTime"); break; }
+    if (pass == 0) *chain_free_us = ms_chain * 1e3f;
+    else {
+      *chain_blocked_us = ms_chain * 1e3f;
+      if (hipEventElapsedTime(&ms_c, t0, tc) != hipSuccess) { fail("hipEventElapsedTime"); break; }
+      *candidate_done_us = ms_c * 1e3f;
+    }
+  }
+  *release_us = (float)late_ticks / 100.f;
+  if (t0) (void)hipEventDestroy(t0);
+  if (t1) (void)hipEventDestroy(t1);
+  if (tc) (void)hipEventDestroy(tc);
+  if (late) (void)hipEventDestroy(late);
+  (void)hipStreamDestroy(helper);
+  return rc;
+}
+
 extern "C" int sitk_abi_version(void) { return SITK_ABI_VERSION; }
 extern "C" const char* sitk_last_error(void) { return sitk_rt::g_err; }
 extern "C" int sitk_dtype_size(int dtype) { return (dtype == SITK_BF16 || dtype == SITK_F16) ? 2 : (dtype == SITK_F32 ? 4 : 0); }

@@ -9,8 +9,10 @@ views of them, so state_dict()/checkpoints keep working), every activation buffe
 once.  Launch form (TrainEngine(use_graph=None) picks it): the 16-bit fused path (dim 192) is enqueued EAGERLY, ~110 launches
 per step, because it forks 8 of 12 layers' weight gradients, the weight staging and the next step's gather onto a side stream
 beside the backward chain (a forked step replayed from ONE hipGraph starts the chain's kernels late: 2.82 against 2.49 ms);
-every other configuration is replayed from hipGraph(s).  With data parallelism the backward is cut into layer slices; each
-finished slice's gradient range is all-reduced (RCCL, on the process group's own stream) while the remaining slices run.
+every other configuration is replayed from hipGraph(s).  With data parallelism every finished bucket of gradients is all-reduced
+(RCCL) while the rest of backward runs -- from ONE stream the engine owns (`_ar_stream`): the collectives are issued as
+synchronous operations with that stream current, and torch >= 2.8 launches a synchronous collective on the CURRENT stream (an
+`async_op=True` one runs on the process group's internal stream behind an event: TrainEngine(dp_collective="group"), the control).
 
 Unlike tools/train.py:293-296 nothing here synchronises with the host: `step()` returns a device
 scalar (the loss) and never calls .item().
@@ -159,6 +161,41 @@ def grad_write_stages_side(model, task, groups, per_bucket=1):
     return stage
 
 
+def probe_stream(stream, main=None, reps=2):
+    """sitk_stream_probe (include/sitk.h) of a torch stream against `main` (default: the current stream): the best of `reps` runs as
+    {'free_us', 'blocked_us', 'done_us', 'release_us', 'ok'}.  ok = blocked behind an event the stream does not slow a chain of
+    dependent launches on `main` (<= 1.15 x) AND its work ran beside that chain (finished within 150 us of its release, not behind
+    the chain's end)."""
+    main = torch.cuda.current_stream(stream.device) if main is None else main
+    best = None
+    for _ in range(reps):
+        v = [C.c_float() for _ in range(4)]
+        rt.check(rt.lib.sitk_stream_probe(main.cuda_stream, stream.cuda_stream, *[C.byref(x) for x in v]))
+        r = dict(free_us=v[0].value, blocked_us=v[1].value, done_us=v[2].value, release_us=v[3].value)
+        if best is None or r["blocked_us"] / r["free_us"] < best["blocked_us"] / best["free_us"]:
+            best = r
+    best["ok"] = bool(best["blocked_us"] <= 1.15 * best["free_us"] and best["done_us"] <= best["release_us"] + 150.0)
+    return best
+
+
+def pick_bucket_stream(device, priority=0, candidates=8):
+    """The stream the early all-reduce buckets are issued from, chosen by MEASUREMENT: candidates are taken from torch's stream pool
+    one after the other (they land on the process's hardware queues in turn) and probed against the current stream; the first one
+    that is harmless while blocked and concurrent while running wins.  Returns (stream, [probe results]); if none passes, the one
+    with the smallest blocked / free ratio (the results say so: 'ok' False)."""
+    tried = []
+    for _ in range(candidates):
+        st = torch.cuda.Stream(device=device, priority=priority)
+        if any(st.cuda_stream == t[0].cuda_stream for t in tried):
+            break                                         # the pool has wrapped around
+        r = probe_stream(st)
+        tried.append((st, r))
+        if r["ok"]:
+            break
+    st, _ = min(tried, key=lambda t: (not t[1]["ok"], t[1]["blocked_us"] / t[1]["free_us"]))
+    return st, [dict(r, stream=f"{t.cuda_stream:#x}", chosen=(t is st)) for t, r in tried]
+
+
 def grad_bucket_plan(fp, stage, n_slices, limit=None):
     """All-reduce ranges of the flat gradient buffer per point of the step: plan[i] (i < n_slices - 1) is issued right
     after backward slice i, plan[n_slices - 1] after `_finish_backward` (the last slice's gradients travel with the
@@ -226,6 +263,11 @@ class TrainEngine:
                   the chain leaves CUs for (16; set NCCL_MAX_NCHANNELS to the same value before creating the process group).
                   dp_stream_priority: priority of the stream the early buckets are reduced from (0; a high-priority stream
                   beside the chain cost a whole step in every measurement: profiles/r05_dp_budget.txt).
+    dp_collective: where a bucket's all-reduce runs.  'stream' (default): on the engine's bucket stream `_ar_stream` (the final
+                  bucket: on the main stream, in line with the optimizer pass behind it) -- issued with async_op=False under that
+                  stream, which torch >= 2.8 launches on the current stream; the main stream waits for ONE event of the bucket
+                  stream in front of the optimizer pass.  'group': async_op=True, i.e. on the process group's internal stream behind
+                  an event of the issuing stream (rounds 2 - 5; kept as the control of tools/dp_cu_budget.py).
     wgrad_overlap_group: layers per side launch (2; 1 - 3).
 
     The learning rate (and Adam's step count) live in device memory: `set_lr()` takes effect in captured graphs too,
@@ -237,7 +279,7 @@ class TrainEngine:
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
                  wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True, dp_channels=None, optimize=None,
-                 wgrad_overlap_group=None, dp_stream_priority=0, dp_bucket_launches=None):
+                 wgrad_overlap_group=None, dp_stream_priority=0, dp_bucket_launches=None, dp_collective="stream"):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -290,6 +332,9 @@ class TrainEngine:
         # process group is given -- also a ONE-rank group, which runs every collective of that form on the real backend
         # (the only way to put RCCL under the engine on a one-GPU box: tests/test_dp_gpu.py)
         self.dp = process_group is not None
+        if dp_collective not in ("stream", "group"):
+            raise rt.SitkError("TrainEngine: dp_collective is 'stream' or 'group'")
+        self.dp_collective = dp_collective
         self._unscale_in_place = keep_grads or self.dp
         self.nsteps = 0
 
@@ -422,7 +467,7 @@ class TrainEngine:
         self.wgrad_overlap = int(wgrad_overlap)
         # workgroups of one side launch (two layers): 42 = the CUs the dim-192 chain's one-wave kernels leave idle
         self.wgrad_overlap_cus = int(wgrad_overlap_cus) if wgrad_overlap_cus else 42
-        self._overlap = rt.lib.sitk_overlap_create(max_side, self.wgrad_overlap_cus, 1) if wgrad_overlap > 0 else None
+        self._overlap, self.side_stream_probe = (self._create_overlap(max_side) if wgrad_overlap > 0 else (None, []))
         if self._overlap and self.wgrad_overlap_group != 2:
             rt.check(rt.lib.sitk_overlap_set_group(self._overlap, self.wgrad_overlap_group))
         self._head_deferred = bool(self._overlap) and bool(head_deferred) and task == "regression"
@@ -441,9 +486,18 @@ class TrainEngine:
             # Bucket i is final behind side launch i (an event the library records on the side stream); its all-reduce is issued
             # from a small stream of its own that waits for THAT event only -- not from the side stream's context, whose tail by
             # then holds later launches.  The one weight-gradient launch behind the chain leaves the channels' CUs free.
-            self._ar_stream = torch.cuda.Stream(device=self.device, priority=int(dp_stream_priority))
             self.dp_channels = int(dp_channels) if dp_channels else 16
             rt.check(rt.lib.sitk_overlap_set_tail_cus(self._overlap, max(64, 256 - self.dp_channels)))
+        if self.dp:
+            # the ONE stream every early bucket is reduced from (see dp_collective), and the event behind its last collective.
+            # WHICH stream matters (round 6, profiles/r06_dp_streams.txt): the bucket stream spends most of the step blocked behind a
+            # side launch's event, and a blocked stream whose hardware queue shares a dispatch pipe with the main stream's delays every
+            # dispatch of the chain (~35 us each; +0.7 .. +2.3 ms per step in rounds 4 - 5), one that shares its QUEUE runs behind the
+            # chain instead of beside it.  Placement follows the process's stream creation order, so it is measured, not assumed.
+            with torch.cuda.device(self.device):
+                self._ar_stream, self.dp_stream_probe = pick_bucket_stream(self.device, int(dp_stream_priority))
+            self._ar_done = torch.cuda.Event()
+            self._ar_used = False
         if use_graph is None:
             use_graph = not self._overlap
         if self.dp_side:
@@ -455,6 +509,29 @@ class TrainEngine:
         self.use_graph = use_graph
         self._graphs = None
         self._pending = []
+
+    def _create_overlap(self, max_side, attempts=4):
+        """The overlap object (side stream + events) -- with the side stream's PLACEMENT measured: the side stream spends much of the
+        step blocked behind fork events of the chain, and a blocked stream on a hardware queue that shares a dispatch pipe with the
+        main stream's delays every dispatch of the chain (see pick_bucket_stream; rounds 3 - 5 met it as "engines created later in
+        one process measure up to 2 ms slower" and "two side streams: the chain 1 230 instead of 890 us").  A side stream that fails
+        the probe is kept alive while the next one is created (so that one lands on another hardware queue) and destroyed afterwards."""
+        tried = []
+        with torch.cuda.device(self.device):
+            for _ in range(attempts):
+                ov = rt.lib.sitk_overlap_create(max_side, self.wgrad_overlap_cus, 1)
+                if not ov:
+                    raise rt.SitkError(f"sitk_overlap_create: {rt.lib.sitk_last_error().decode()}")
+                side = torch.cuda.ExternalStream(rt.lib.sitk_overlap_stream(ov), device=self.device)
+                r = probe_stream(side)
+                tried.append((ov, r))
+                if r["ok"]:
+                    break
+        best = min(tried, key=lambda t: (not t[1]["ok"], t[1]["blocked_us"] / t[1]["free_us"]))
+        for ov, _ in tried:
+            if ov is not best[0]:
+                rt.lib.sitk_overlap_destroy(ov)
+        return best[0], [dict(r, chosen=(ov is best[0])) for ov, r in tried]
 
     def __del__(self):
         ov, self._overlap = getattr(self, "_overlap", None), None
@@ -743,10 +820,45 @@ class TrainEngine:
         return segs
 
     def _allreduce(self, lo, hi):
-        if self.dp:
-            if self.loss_scaled:                # every rank scaled by its own S: reduce unscaled gradients
-                self.fp.grad[lo:hi].mul_(self.gscale[1])
+        """Sum-all-reduce of grad[lo:hi] on the CURRENT stream's behalf: dp_collective 'stream' -> the collective's kernel is
+        launched on the current stream itself (a synchronous c10d operation: nothing to wait for afterwards but the stream);
+        'group' -> on the process group's internal stream behind an event, the work handle kept until the optimizer pass."""
+        if not self.dp:
+            return
+        if self.loss_scaled:                # every rank scaled by its own S: reduce unscaled gradients
+            self.fp.grad[lo:hi].mul_(self.gscale[1])
+        if self.dp_collective == "stream":
+            torch.distributed.all_reduce(self.fp.grad[lo:hi], group=self.pg, async_op=False)
+        else:
             self._pending.append(torch.distributed.all_reduce(self.fp.grad[lo:hi], group=self.pg, async_op=True))
+
+    def _allreduce_early(self, ranges, behind_side_launch=None):
+        """An early bucket: reduced from the bucket stream, behind side launch `behind_side_launch` (an event the library recorded
+        on the side stream) or, without one, behind everything enqueued on the main stream so far."""
+        if not ranges:
+            return
+        if behind_side_launch is None and self.dp_collective == "group":
+            for lo, hi in ranges:               # (the process group's stream waits for the issuing one by itself)
+                self._allreduce(lo, hi)
+            return
+        if behind_side_launch is None:
+            self._ar_stream.wait_stream(torch.cuda.current_stream(self.device))
+        else:
+            rt.check(rt.lib.sitk_overlap_wait_side_launch(self._overlap, behind_side_launch, self._ar_stream.cuda_stream))
+        with torch.cuda.stream(self._ar_stream):
+            for lo, hi in ranges:
+                self._allreduce(lo, hi)
+        self._ar_used = True
+
+    def _join_collectives(self):
+        """The main stream behind every collective of the step (in front of the optimizer pass)."""
+        if self._ar_used:
+            self._ar_done.record(self._ar_stream)
+            torch.cuda.current_stream(self.device).wait_event(self._ar_done)
+            self._ar_used = False
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
 
     def _run(self, fn, idx):
         if not self.use_graph:
@@ -760,7 +872,7 @@ class TrainEngine:
             # earlier segment still copying on another thread / stream makes the capture fail now and then (gloo does).
             for w in self._pending:
                 w.wait()
-            torch.cuda.synchronize()
+            torch.cuda.synchronize()               # (also drains the bucket stream: a synchronous gloo collective has returned by now)
             gr = torch.cuda.CUDAGraph()
             # thread_local: calls made by OTHER threads (the process group's watchdog polling its events) must not
             # invalidate this thread's capture
@@ -854,38 +966,30 @@ class TrainEngine:
         for i, fn in enumerate(segs):
             self._run(fn, i)
             if i < len(segs) - 1:
-                for lo, hi in self.bucket_plan[i]:      # final now: reduce while the remaining slices run
-                    self._allreduce(lo, hi)
+                self._allreduce_early(self.bucket_plan[i])      # final now: reduce while the remaining slices run
         if self.dp_side:
             # The side launches' weight gradients are on the SIDE stream: each bucket is reduced behind the event the library
             # recorded there at the end of ITS launch, so it runs beside the rest of the chain.  The collectives are ISSUED only
-            # now, behind the host's enqueue of the whole chain: should the process group's stream (or the small stream below)
-            # share a hardware queue with the main stream (ROCm maps streams of one priority onto few queues), its wait sits
-            # BEHIND the chain's launches in that queue instead of in front of them (issued right after the first slice it
-            # stalled the chain for 350 us: 3.14 ms per step).
+            # now, behind the host's enqueue of the whole chain: should the bucket stream share a hardware queue with the main
+            # stream (ROCm maps streams of one priority onto few queues), its wait sits BEHIND the chain's launches in that queue
+            # instead of in front of them (issued right after the first slice it stalled the chain for 350 us: 3.14 ms per step).
             n_side = rt.lib.sitk_overlap_side_launches(self._overlap)
             if n_side == 0:
                 # no side launch was made (fewer than 2 048 tokens per rank: the large-tile weight-gradient path the side stream
                 # uses does not take such a batch, every layer's gradients ran on the main stream inside the call): the early
-                # buckets are final here, behind the chain -- reduce them from this stream, nothing to overlap with
+                # buckets are final here, behind the chain -- nothing to overlap with
                 for i in range(self._n_early):
-                    for lo, hi in self.bucket_plan[i]:
-                        self._allreduce(lo, hi)
+                    self._allreduce_early(self.bucket_plan[i])
             elif n_side != len(self._side_groups):
                 raise rt.SitkError(f"engine: {n_side} side launches, bucket plan built for {len(self._side_groups)}")
             else:
                 for i in range(self._n_early):
                     last = sum(self._bucket_sizes[:i + 1]) - 1                     # the bucket is final behind its LAST side launch
-                    rt.check(rt.lib.sitk_overlap_wait_side_launch(self._overlap, last, self._ar_stream.cuda_stream))
-                    with torch.cuda.stream(self._ar_stream):
-                        for lo, hi in self.bucket_plan[i]:
-                            self._allreduce(lo, hi)
+                    self._allreduce_early(self.bucket_plan[i], behind_side_launch=last)
         self._run(self._finish_backward, "finish")
-        for lo, hi in self.bucket_plan[-1]:             # the last slice's gradients + everything `finish` wrote
+        for lo, hi in self.bucket_plan[-1]:             # the last slice's gradients + everything `finish` wrote: on the main stream
             self._allreduce(lo, hi)
-        for w in self._pending:
-            w.wait()
-        self._pending.clear()
+        self._join_collectives()
         self._run(self._optimizer, "opt")
         self.nsteps += 1
         return self.loss

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SITK_LIB") or os.path.join(_HERE, "libsitk.so")
 
 F32, BF16, F16 = 0, 1, 2
 EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class SitkError(RuntimeError):
@@ -117,6 +117,7 @@ _SIGS = {
     "sitk_overlap_side_launches": (C.c_int, [_P]),
     "sitk_overlap_wait_side_launch": (C.c_int, [_P, _I, _P]),
     "sitk_overlap_set_tail_cus": (C.c_int, [_P, _I]),
+    "sitk_stream_probe": (C.c_int, [_P, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sitk_encoder_stage_weights": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), _P, _Z, _P]),
     "sitk_overlap_destroy": (None, [_P]),
     "sitk_encoder_bwd_overlap": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,

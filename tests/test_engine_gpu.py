@@ -365,6 +365,137 @@ def test_mpp_engine_config5_full_width_f32_against_oracle(pk):
     check("engine/cfg5_mpp_b32_d1_oracle", "grad_rel", "f32", worst[0], "grad")
 
 
+_ORACLE_CACHE = {}
+
+
+def _oracle_grads_cpu_chunked(key, model_cpu, n, chunk, loss_of_chunk):
+    """Loss and gradients of the CPU oracle over n samples in chunks of `chunk` (a depth-12 model on 1 281 tokens keeps
+    (chunk, heads, N, N) softmax outputs per layer for its backward: 32 samples at once are tens of GB).  loss_of_chunk(model,
+    lo, hi) returns that chunk's share of the batch loss (its mean times (hi - lo) / n), so the sum is the batch loss and the
+    accumulated .grad its gradient.  Cached per `key`: the two 16-bit modes of one test compare with the same oracle run."""
+    if key in _ORACLE_CACHE:
+        return _ORACLE_CACHE[key]
+    torch.set_num_threads(max(1, min(16, (torch.get_num_threads() or 1))))
+    model_cpu.zero_grad()
+    total = 0.0
+    for lo in range(0, n, chunk):
+        part = loss_of_chunk(model_cpu, lo, min(lo + chunk, n))
+        part.backward()
+        total += float(part.detach())
+    out = total, {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model_cpu.named_parameters()}
+    _ORACLE_CACHE.clear()                     # one entry at a time: base-width gradients are 350 MB
+    _ORACLE_CACHE[key] = out
+    return out
+
+
+def _worst_grads(named_parameters, g_ref):
+    worst_n, worst_e = (0.0, ""), (0.0, "")
+    for k, p in named_parameters:
+        if g_ref[k] is None:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        gn, rn = float(p.grad.double().norm()), float(g_ref[k].double().norm())
+        worst_n = max(worst_n, (abs(gn - rn) / rn, k))
+        worst_e = max(worst_e, (rel(p.grad, g_ref[k]), k))
+    return worst_n, worst_e
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_engine_config3_benchmarked_form_against_cpu_oracle(pk, dtype):
+    """the engine form `bench.py --model small --patches 1280 --batch 32` times (`also.cfg3`, BASELINE
+    config 3) -- SiT-small, 1280 patches x 45 vertices (the synthetic table), DEPTH 12, B = 32, raw (B, 40962, 4) surfaces,
+    the engine's default launch form for this width (ONE hipGraph per step: the unfused LayerNorms / their fused successors,
+    the 2-per-CU N % 192 GEMMs, ring attention on 1 281 tokens, the one-launch weight gradients) -- one REPLAYED step with
+    kept gradients against oracle/sit_oracle.py on the same batch (the reference's loop body, tools/train.py:280-291 on
+    config/SiT/training/hparams.yml:34's shapes).  Until round 6 the oracle met this engine form at depth 1 in f32 only; the
+    depth-12 golden `small1280_d12` goes through the autograd module path at B = 2.  f16: north_star's fixed 1e-3 on the
+    loss, every gradient's norm and every gradient element-wise; bf16: recorded bars under the fixed ceilings.  CPU side:
+    8.1 TFLOP in chunks of 8 samples (~20 s on the box's 16 cores)."""
+    sit, _, engine = pk
+    B, P, V = 32, 1280, 45
+    kw = dict(sit_oracle.MODEL_SIZES["small"], num_patches=P, num_vertices=V, num_channels=4)
+    assert kw["depth"] == 12
+    m = sit.SiT(**kw, compute_dtype=dtype)
+    m.allow_synthetic_table = True
+    _load(m, 33)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn((B, 40962, 4), generator=g)
+    y = torch.randn((B,), generator=g) * 2 + 40
+    from sitk import tables
+    table = tables.load_table(P, V, allow_synthetic=True)
+    tok = torch.from_numpy(sit_oracle.gather_tokens(x.numpy(), table))
+    xp = tok.reshape(B, P, V, 4).permute(0, 3, 1, 2).contiguous()                      # the reference's (B, C, P, V) input
+    ref = sit_oracle.SiT(**kw)
+    ref.load_state_dict({k: v.detach().clone() for k, v in m.state_dict().items()})
+
+    def part(mod, lo, hi):
+        return ((mod(xp[lo:hi]).squeeze(-1) - y[lo:hi]) ** 2).sum() / B
+
+    l_ref, g_ref = _oracle_grads_cpu_chunked("cfg3", ref, B, 8, part)
+    eng = engine.TrainEngine(m, B, input_layout="surface", lr=0.0, momentum=0.0, keep_grads=True)
+    assert eng.use_graph and not eng._overlap, "not the benchmarked launch form of this width"
+    eng.step(x.to(DEV), y.to(DEV))                       # eager run + capture
+    loss = float(eng.step())                             # the replayed graph, same batch (lr = 0: same gradients)
+    case = "engine/cfg3_b32_d12_oracle"
+    check(case, "loss", dtype, abs(loss - l_ref) / abs(l_ref), "loss")
+    worst_n, worst_e = _worst_grads(m.named_parameters(), g_ref)
+    print("worst gradient norm:", worst_n, " worst gradient (element-wise, relative to the tensor):", worst_e)
+    check(case, "gnorm", dtype, worst_n[0], "grad")
+    check(case, "grad_rel", dtype, worst_e[0], "grad")
+    assert eng.nonfinite_count == 0
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_mpp_engine_config5_benchmarked_form_against_cpu_oracle(pk, dtype):
+    """the engine form `bench.py --model base --patches 1280 --batch 32 --task mpp` times (`also.cfg5`,
+    BASELINE config 5's per-GPU share) -- SiT-base masked patch pre-training, 1280 patches x 45 vertices, DEPTH 12, raw
+    surfaces, the default launch form (one hipGraph per step, device-side Philox draws, fused gather + corruption) -- one
+    REPLAYED step with kept gradients against the CPU oracle replaying THAT step's draws (models/mpp.py:77-134 restated in
+    oracle/sit_oracle.py; the loop of tools/pretrain.py:309-319).  B = 32, the benchmarked per-GPU batch: 26.8 TFLOP on the
+    CPU in chunks of 4 samples -- about a minute on the box's 16 cores, which is the largest this test affords (the oracle
+    run is shared by the two 16-bit modes: same seed, same Philox stream, asserted).  f16: fixed 1e-3 on the loss, every
+    gradient's norm and every gradient element-wise; bf16: recorded bars under the fixed ceilings."""
+    sit, mpp, engine = pk
+    B, P, V = 32, 1280, 45
+    kw = dict(sit_oracle.MODEL_SIZES["base"], num_patches=P, num_vertices=V, num_channels=4)
+    assert kw["depth"] == 12
+    torch.manual_seed(77)                                # seeds the engine's Philox stream (torch.initial_seed())
+    model = sit.SiT(**kw, compute_dtype=dtype)
+    model.allow_synthetic_table = True
+    ssl = mpp.masked_patch_pretraining(model, 768, 4 * V, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
+                                       channels=4, num_vertices=V)
+    _load(ssl, 9)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((B, 40962, 4), generator=g)
+    eng = engine.TrainEngine(ssl, B, task="mpp", input_layout="surface", lr=0.0, momentum=0.0, keep_grads=True)
+    assert eng.use_graph and not eng._overlap, "not the benchmarked launch form of this width"
+    eng.step(x.to(DEV))                                  # eager run + capture (first draws)
+    loss = float(eng.step())                             # the replayed graph (second draws)
+    rnd = {k: v.cpu() for k, v in eng.last_randoms.items()}
+    assert int(rnd["corrupted_sequence"].sum()) == B * 960
+    from sitk import tables
+    table = tables.load_table(P, V, allow_synthetic=True)
+    tok = torch.from_numpy(sit_oracle.gather_tokens(x.numpy(), table))
+    xp = tok.reshape(B, P, V, 4).permute(0, 3, 1, 2).contiguous()
+    ref = sit_oracle.MaskedPatchPretraining(sit_oracle.SiT(**kw), 768, 4 * V, "cpu", mask_prob=0.75, replace_prob=0.8,
+                                            swap_prob=0.02, channels=4, num_vertices=V)
+    ref.load_state_dict({k: v.detach().clone() for k, v in ssl.state_dict().items()})
+
+    def part(mod, lo, hi):                               # every sample masks exactly ceil(0.75 P) patches: equal denominators
+        return mod(xp[lo:hi], randoms={k: v[lo:hi] for k, v in rnd.items()})[0] * ((hi - lo) / B)
+
+    import hashlib
+    key = "cfg5-" + hashlib.sha256(b"".join(rnd[k].numpy().tobytes() for k in sorted(rnd))).hexdigest()
+    l_ref, g_ref = _oracle_grads_cpu_chunked(key, ref, B, 4, part)
+    case = "engine/cfg5_mpp_b32_d12_oracle"
+    check(case, "loss", dtype, abs(loss - l_ref) / abs(l_ref), "loss")
+    worst_n, worst_e = _worst_grads(ssl.named_parameters(), g_ref)
+    print("worst gradient norm:", worst_n, " worst gradient (element-wise, relative to the tensor):", worst_e)
+    check(case, "gnorm", dtype, worst_n[0], "grad")
+    check(case, "grad_rel", dtype, worst_e[0], "grad")
+    assert eng.nonfinite_count == 0
+
+
 def test_engine_config3_width_bf16_against_f32_mode(pk):
     """BASELINE config 3 at its full width -- SiT-small, 1280 patches (N = 1281), B = 32 -- through the long-sequence ring
     attention and the two-per-CU N % 192 GEMMs, depth 2: the bf16 engine step against the SAME engine in f32 compute

@@ -2,12 +2,19 @@
 a copy -- the 2.46 ms "per-rank" step says nothing about the CUs and the time a real all-reduce takes.)
 
 The data-parallel form of the step on a ONE-rank RCCL group (every collective on the real backend), plus, behind every
-bucket's all-reduce, on the stream the collective was issued from (--own-stream 1: on a stream of its own behind an event, round 4's
-form, whose cost turned out to be that extra stream: profiles/r05_dp_budget.txt), a DUMMY kernel of `--channels` workgroups x 256
+bucket's all-reduce, ON THE STREAM THE ENGINE'S COLLECTIVE RUNS ON, a DUMMY kernel of `--channels` workgroups x 256
 threads that holds its CUs for the time the bucket needs on the wire: --latency-us + bytes / (--gbs GB/s) (SURVEY section 5:
 22 MB in ~0.25 ms per ring = 88 GB/s; the mesh algorithm is ~7x faster; 30 us for the launch + the ring's hops of a small
 message).  Round 5: the stand-in has the footprint of RCCL's own kernel on gfx950 (256 threads, 19 744 B of LDS, 280 registers:
-csrc/core.hip), the step is the per-side-launch bucket form, and `--side-cus` / `--channels` take lists to sweep.  Needs the
+csrc/core.hip), the step is the per-side-launch bucket form, and `--side-cus` / `--channels` take lists to sweep.
+
+Round 6: the stand-in follows the engine's arrangement.  `--collective stream` (the engine's default since round 6: synchronous c10d
+collectives issued with the bucket stream current, which torch >= 2.8 launches on THAT stream; the final bucket on the main stream)
+puts the stand-in on the stream that is current when the engine issues the collective -- same number and kind of streams as an N > 1
+run.  `--collective group` is the control: the engine issues async_op=True collectives (rounds 2 - 5), whose kernel runs on the
+process group's internal stream behind an event, and the stand-in runs on a stream of its own behind an event in the same way
+(`--own-stream` overrides the placement alone).  `--skip-streams n` takes n streams from torch's pool first, so that the stand-in's
+own stream lands on another hardware queue (ROCm maps streams onto GPU_MAX_HW_QUEUES queues in creation order).  Needs the
 diagnostic build:
 
     SITK_LIB=$PWD/surface-vision-transformers_amd/libsitk_ab.so python tools/dp_cu_budget.py [--channels 16 --side-cus 42,34,26]
@@ -28,12 +35,13 @@ from sitk import runtime as rt  # noqa: E402
 from sitk.models.sit import SiT  # noqa: E402
 
 
-class _Both:
-    def __init__(self, work, ev):
-        self.work, self.ev = work, ev
+class _EventWait:
+    """Stands in the engine's list of pending work handles: wait() puts the current stream behind the stand-in's end."""
+
+    def __init__(self, ev):
+        self.ev = ev
 
     def wait(self):
-        self.work.wait()
         torch.cuda.current_stream().wait_event(self.ev)
 
 
@@ -47,8 +55,12 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--main-prio", type=int, default=0, help="-1: run the step itself on a HIGH-priority stream (main high, all-reduce path "
                     "normal, side stream lowest: three priority classes = three sets of hardware queues)")
-    ap.add_argument("--own-stream", type=int, default=0, help="1: the stand-in runs on a stream of its own behind an event (round 4's form); "
-                    "0: on the stream the bucket's all-reduce was issued from (the engine's bucket stream / the main stream)")
+    ap.add_argument("--collective", default="stream", choices=("stream", "group"), help="TrainEngine(dp_collective=...): 'stream' = the "
+                    "shipped arrangement; 'group' = async_op=True on the process group's stream, the control")
+    ap.add_argument("--own-stream", type=int, default=None, help="1: the stand-in runs on a stream of its own behind an event (where an "
+                    "async_op=True collective runs); 0: on the stream that is current when the engine issues the collective (where a "
+                    "synchronous one runs).  Default: follows --collective")
+    ap.add_argument("--skip-streams", type=int, default=0, help="take this many streams from torch's pool before the stand-in's own one")
     ap.add_argument("--per-bucket", default=None, help="side launches per early all-reduce bucket: an int, or a comma list of bucket sizes "
                     "(launches it does not cover travel with the final bucket); engine default: all side launches in one early bucket")
     ap.add_argument("--standin-us", type=float, default=None, help="fixed stand-in time per bucket instead of latency + bytes / rate")
@@ -58,6 +70,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--prio", type=int, default=0, help="priority of the stream the dummy runs on (0 = default, like the process group of bench.py; -1 = high)")
     a = ap.parse_args()
+    if a.own_stream is None:
+        a.own_stream = int(a.collective == "group")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
     os.environ.setdefault("RANK", "0")
@@ -71,9 +85,12 @@ def main():
     lib = ctypes.CDLL(rt.LIB_PATH)
     lib.sitk_debug_occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.sitk_debug_occupy.restype = ctypes.c_int
+    _skipped = [torch.cuda.Stream(device=dev, priority=a.prio) for _ in range(a.skip_streams)]
     hp = torch.cuda.Stream(device=dev, priority=a.prio)
     B = 64
-    print(f"# stand-in: latency {a.latency_us:.0f} us + bytes / {a.gbs:.0f} GB/s per bucket, stream priority {a.prio}, {a.steps} steps, {a.dtype}")
+    print(f"# collectives: {a.collective}; stand-in on {'a stream of its own behind an event' if a.own_stream else 'the stream the collective is issued on'}"
+          f"; latency {a.latency_us:.0f} us + bytes / {a.gbs:.0f} GB/s per bucket, stream priority {a.prio}, {a.steps} steps, {a.dtype}, "
+          f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', '(default)')}, {a.skip_streams} pool streams skipped")
     if a.configs:
         cfgs = [tuple(int(v) for v in c.split(":")) for c in a.configs.split(",")]
         cfgs = [c2 for c in cfgs for c2 in ((c[0], c[1], c[2], 0), c)]
@@ -86,8 +103,11 @@ def main():
                     compute_dtype=a.dtype)
         eng = engine.TrainEngine(model, B, input_layout="surface", lr=1e-5, momentum=0.9, process_group=dist.group.WORLD, device=dev,
                                  wgrad_overlap_cus=side, dp_channels=(ch or chans[0]), wgrad_overlap=nlay, wgrad_overlap_group=group,
-                                 dp_stream_priority=a.prio, dp_bucket_launches=(None if a.per_bucket is None else (int(a.per_bucket) if a.per_bucket.isdigit() else [int(v) for v in a.per_bucket.split(",")])))
+                                 dp_stream_priority=a.prio, dp_collective=a.collective, dp_bucket_launches=(None if a.per_bucket is None else (int(a.per_bucket) if a.per_bucket.isdigit() else [int(v) for v in a.per_bucket.split(",")])))
         assert eng.dp_side, "expected the side-stream form"
+        fmt = lambda rs: ", ".join(f"{r['blocked_us']:.0f}/{r['free_us']:.0f} us done {r['done_us']:.0f}{' *' if r['chosen'] else ''}" for r in rs)
+        print(f"  placement probes (chain blocked / free, candidate's kernel done; * = chosen): side stream [{fmt(eng.side_stream_probe)}]  "
+              f"bucket stream [{fmt(eng.dp_stream_probe)}]", flush=True)
         log, tl = [], []
         if not ch and a.timeline:
             orig0 = eng._allreduce
@@ -102,7 +122,6 @@ def main():
             orig = eng._allreduce
 
             def wrapped(lo, hi, orig=orig, eng=eng, log=log, ch=ch):
-                n0 = len(eng._pending)
                 orig(lo, hi)
                 us = max(1, int(a.latency_us + (hi - lo) * 4 / (a.gbs * 1e3))) if a.standin_us is None else max(1, int(a.standin_us))
                 ev0, ev1 = torch.cuda.Event(enable_timing=a.timeline), torch.cuda.Event(enable_timing=a.timeline)
@@ -119,7 +138,8 @@ def main():
                 if a.standin_us is None or a.standin_us > 0:          # (--standin-us 0: the events alone, no kernel)
                     assert lib.sitk_debug_occupy(ch, us, ds.cuda_stream) == 0
                 ev1.record(ds)
-                eng._pending[n0] = _Both(eng._pending[n0], ev1)
+                if a.own_stream:                      # (on the issuing stream the engine's own join covers the stand-in)
+                    eng._pending.append(_EventWait(ev1))
                 log.append(((hi - lo) * 4, us))
             eng._allreduce = wrapped
         g = torch.Generator(device=dev).manual_seed(100)
