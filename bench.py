@@ -96,7 +96,7 @@ def cpu_baseline(seconds=15.0):
         loss.backward()
         opt.step()
         dt = time.perf_counter() - t0
-        if it >= 2:
+        if it >= 3:                       # three untimed warm-up steps
             times.append(dt)
         it += 1
         now = time.perf_counter()

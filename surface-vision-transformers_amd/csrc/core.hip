@@ -209,18 +209,18 @@ extern "C" int sitk_stream_probe(sitk_stream_t main_stream, sitk_stream_t candid
     fail("hipEventCreate");
   const int chain = 64;                                   // dependent launches, one workgroup per CU of 214 CUs, ~10 us each
   const unsigned long long link_ticks = 1000, late_ticks = 90000;     // 10 us; the helper releases the candidate at 900 us
-  for (int pass = 0; pass < 2 && rc == SITK_OK; ++pass) {
+  // pass 0: warm-up (the first launch of the kernel pays for its code object), discarded; pass 1: the reference -- the chain beside
+  // the helper's kernel, the candidate idle; pass 2: the same with the candidate blocked behind the helper's release event
+  for (int pass = 0; pass < 3 && rc == SITK_OK; ++pass) {
     if (hipDeviceSynchronize() != hipSuccess) { fail("hipDeviceSynchronize"); break; }
     if (hipEventRecord(t0, ms) != hipSuccess) { fail("hipEventRecord"); break; }
-    if (pass == 1) {
-      // the helper holds the release event back for 900 us; it starts with the chain (behind t0)
-      if (hipStreamWaitEvent(helper, t0, 0) != hipSuccess) { fail("hipStreamWaitEvent"); break; }
-      hipLaunchKernelGGL(sitk_spin_kernel, dim3(1), dim3(256), 0, helper, late_ticks, (int*)nullptr);
-      if (hipEventRecord(late, helper) != hipSuccess) { fail("hipEventRecord"); break; }
-    }
+    // the helper holds the release event back for 900 us; it starts with the chain (behind t0)
+    if (hipStreamWaitEvent(helper, t0, 0) != hipSuccess) { fail("hipStreamWaitEvent"); break; }
+    hipLaunchKernelGGL(sitk_spin_kernel, dim3(1), dim3(256), 0, helper, late_ticks, (int*)nullptr);
+    if (hipEventRecord(late, helper) != hipSuccess) { fail("hipEventRecord"); break; }
     for (int k = 0; k < chain; ++k) hipLaunchKernelGGL(sitk_spin_kernel, dim3(214), dim3(256), 0, ms, link_ticks, (int*)nullptr);
     if (hipEventRecord(t1, ms) != hipSuccess) { fail("hipEventRecord"); break; }
-    if (pass == 1) {
+    if (pass == 2) {
       // issued BEHIND the host's enqueue of the chain, as the engine issues its collectives: the candidate sits blocked behind
       // the release event, then runs one small kernel
       if (hipStreamWaitEvent(cs, late, 0) != hipSuccess) { fail("hipStreamWaitEvent"); break; }
@@ -228,12 +228,13 @@ extern "C" int sitk_stream_probe(sitk_stream_t main_stream, sitk_stream_t candid
       if (hipEventRecord(tc, cs) != hipSuccess) { fail("hipEventRecord"); break; }
       if (hipStreamWaitEvent(ms, tc, 0) != hipSuccess) { fail("hipStreamWaitEvent"); break; }      // (the caller's stream joins)
     }
+    if (hipStreamWaitEvent(ms, late, 0) != hipSuccess) { fail("hipStreamWaitEvent"); break; }      // (... and the helper)
     if (sitk_rt::check_launch("stream_probe") != SITK_OK) { rc = SITK_ERR_LAUNCH; break; }
     if (hipDeviceSynchronize() != hipSuccess) { fail("hipDeviceSynchronize"); break; }
     float ms_chain = 0.f, ms_c = 0.f;
     if (hipEventElapsedTime(&ms_chain, t0, t1) != hipSuccess) { fail("hipEventElapsedTime"); break; }
-    if (pass == 0) *chain_free_us = ms_chain * 1e3f;
-    else {
+    if (pass == 1) *chain_free_us = ms_chain * 1e3f;
+    else if (pass == 2) {
       *chain_blocked_us = ms_chain * 1e3f;
       if (hipEventElapsedTime(&ms_c, t0, tc) != hipSuccess) { fail("hipEventElapsedTime"); break; }
       *candidate_done_us = ms_c * 1e3f;

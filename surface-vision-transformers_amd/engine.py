@@ -164,8 +164,9 @@ def grad_write_stages_side(model, task, groups, per_bucket=1):
 def probe_stream(stream, main=None, reps=2):
     """sitk_stream_probe (include/sitk.h) of a torch stream against `main` (default: the current stream): the best of `reps` runs as
     {'free_us', 'blocked_us', 'done_us', 'release_us', 'ok'}.  ok = blocked behind an event the stream does not slow a chain of
-    dependent launches on `main` (<= 1.15 x) AND its work ran beside that chain (finished within 150 us of its release, not behind
-    the chain's end)."""
+    dependent launches on `main` (<= 1.2 x the same chain with the stream idle; a stream on the toxic hardware queue measures 1.6 -
+    2.6 x, a harmless one 0.98 - 1.05 x) AND its work ran beside that chain (finished within 150 us of its release, not behind the
+    chain's end)."""
     main = torch.cuda.current_stream(stream.device) if main is None else main
     best = None
     for _ in range(reps):
@@ -174,7 +175,7 @@ def probe_stream(stream, main=None, reps=2):
         r = dict(free_us=v[0].value, blocked_us=v[1].value, done_us=v[2].value, release_us=v[3].value)
         if best is None or r["blocked_us"] / r["free_us"] < best["blocked_us"] / best["free_us"]:
             best = r
-    best["ok"] = bool(best["blocked_us"] <= 1.15 * best["free_us"] and best["done_us"] <= best["release_us"] + 150.0)
+    best["ok"] = bool(best["blocked_us"] <= 1.2 * best["free_us"] and best["done_us"] <= best["release_us"] + 150.0)
     return best
 
 
@@ -263,10 +264,11 @@ class TrainEngine:
                   the chain leaves CUs for (16; set NCCL_MAX_NCHANNELS to the same value before creating the process group).
                   dp_stream_priority: priority of the stream the early buckets are reduced from (0; a high-priority stream
                   beside the chain cost a whole step in every measurement: profiles/r05_dp_budget.txt).
-    dp_collective: where a bucket's all-reduce runs.  'stream' (default): on the engine's bucket stream `_ar_stream` (the final
-                  bucket: on the main stream, in line with the optimizer pass behind it) -- issued with async_op=False under that
-                  stream, which torch >= 2.8 launches on the current stream; the main stream waits for ONE event of the bucket
-                  stream in front of the optimizer pass.  'group': async_op=True, i.e. on the process group's internal stream behind
+    dp_collective: where a bucket's all-reduce runs.  'stream' (default): on the engine's bucket stream `_ar_stream`, EVERY bucket
+                  of the step (the final one behind an event of the main stream's finish stage) -- issued with async_op=False under
+                  that stream, which torch >= 2.8 launches on the current stream (profiles/r06_dp_streams.txt: rocprofv3 trace);
+                  the main stream waits for ONE event of the bucket stream in front of the optimizer pass.  The stream is picked
+                  by measurement (pick_bucket_stream).  'group': async_op=True, i.e. on the process group's internal stream behind
                   an event of the issuing stream (rounds 2 - 5; kept as the control of tools/dp_cu_budget.py).
     wgrad_overlap_group: layers per side launch (2; 1 - 3).
 
@@ -335,6 +337,13 @@ class TrainEngine:
         if dp_collective not in ("stream", "group"):
             raise rt.SitkError("TrainEngine: dp_collective is 'stream' or 'group'")
         self.dp_collective = dp_collective
+        if self.dp and dp_collective == "stream" and torch.distributed.get_backend(process_group) == "nccl":
+            # (c10d before 2.8 launched EVERY NCCL collective on the process group's internal stream: the bucket stream would only
+            # carry the events; the arrangement the stand-in study measured is the one torch >= 2.8 produces)
+            ver = tuple(int(v) for v in torch.__version__.split("+")[0].split(".")[:2])
+            if ver < (2, 8):
+                raise rt.SitkError(f"TrainEngine(dp_collective='stream') needs torch >= 2.8 (synchronous NCCL collectives on the "
+                                   f"current stream); this is {torch.__version__}: pass dp_collective='group'")
         self._unscale_in_place = keep_grads or self.dp
         self.nsteps = 0
 
@@ -987,8 +996,11 @@ class TrainEngine:
                     last = sum(self._bucket_sizes[:i + 1]) - 1                     # the bucket is final behind its LAST side launch
                     self._allreduce_early(self.bucket_plan[i], behind_side_launch=last)
         self._run(self._finish_backward, "finish")
-        for lo, hi in self.bucket_plan[-1]:             # the last slice's gradients + everything `finish` wrote: on the main stream
-            self._allreduce(lo, hi)
+        # the last slice's gradients + everything `finish` wrote: from the SAME stream as the early buckets, behind the finish stage
+        # -- every collective of the communicator is launched from one stream, in one order, on every rank (two streams feeding
+        # one communicator would rely on the library's internal launch serialisation; nothing is gained by it: the optimizer pass
+        # waits for this bucket either way)
+        self._allreduce_early(self.bucket_plan[-1])
         self._join_collectives()
         self._run(self._optimizer, "opt")
         self.nsteps += 1

@@ -454,6 +454,26 @@ def _rccl_worker(port, task, use_graph, q):
     dist.destroy_process_group()
 
 
+def test_bucket_stream_is_picked_by_measurement():
+    """Round 6: the stream the all-reduce buckets are issued from is chosen by sitk_stream_probe (include/sitk.h) -- a stream that
+    sits blocked behind an event on a hardware queue which shares a dispatch pipe with the main stream's delays every dispatch
+    of the chain (tools/micro/blocked_queue.hip: 2.7 -> 6.5 ms for 110 kernels), and which stream lands there follows the
+    process's stream creation order.  The pick must pass its own criterion (chain with the candidate blocked <= 1.2 x the chain
+    with it idle; the candidate's kernel done within 150 us of its release, i.e. beside the chain), and the probe's numbers must
+    be those of the probe's design: a chain of 64 x ~10 us, a release at 900 us."""
+    import sitk  # noqa: F401
+    from sitk import engine
+    st, results = engine.pick_bucket_stream(torch.device("cuda:0"))
+    chosen = [r for r in results if r["chosen"]]
+    assert len(chosen) == 1 and chosen[0]["ok"], results
+    c = chosen[0]
+    assert 500 < c["free_us"] < 2000 and c["blocked_us"] <= 1.2 * c["free_us"], c
+    assert c["release_us"] == 900.0 and 900.0 <= c["done_us"] <= 1050.0, c
+    assert st.cuda_stream != torch.cuda.current_stream().cuda_stream
+    for r in results:                                     # every rejected candidate failed the criterion, none was skipped
+        assert r["chosen"] or not r["ok"], results
+
+
 @pytest.mark.parametrize("task,use_graph", [("regression", True), ("regression", False), ("mpp", True)])
 def test_one_rank_rccl_group_runs_the_data_parallel_step(task, use_graph):
     import sitk  # noqa: F401

@@ -365,7 +365,8 @@ def test_attention_fwd_bwd(ops, dtype, B, N, H):
     I = H * 64
     for name, sl in (("dq", slice(0, I)), ("dk", slice(I, 2 * I)), ("dv", slice(2 * I, 3 * I))):
         e = rel(dqkv[:, sl], qr.grad[:, sl])
-        assert e < (5e-5 if dtype == "f32" else 2e-2), (name, e)
+        # (f16: 11 significant bits against bf16's 8 -- held to a quarter of the bf16 bar)
+        assert e < {"f32": 5e-5, "bf16": 2e-2, "f16": 5e-3}[dtype], (name, e)
 
 
 @pytest.mark.parametrize("h16", H16S)
@@ -501,7 +502,8 @@ def test_encoder_fwd_bwd_vs_oracle(ops, dtype, dim, heads, mlp, N, depth):
     xin = torch.from_numpy(x).to(DEV).reshape(B * N, dim).contiguous()
     xout = torch.empty_like(xin)
     ops.encoder_fwd(cfg, P, xin, xout, acts, scratch, save=True)
-    tol_f, tol_g = (1e-4, 5e-4) if dtype == "f32" else (1e-2, 4e-2)
+    # (f16: a quarter of the bf16 bars)
+    tol_f, tol_g = {"f32": (1e-4, 5e-4), "bf16": (1e-2, 4e-2), "f16": (2.5e-3, 1e-2)}[dtype]
     assert rel(xout.reshape(B, N, dim), yr.detach()) < tol_f
     # forward-only schedule gives the same output
     xo2 = torch.empty_like(xin)

@@ -25,6 +25,21 @@ for k, v in rec.items():
         out[key] = v
 json.dump(dict(sorted(out.items())), open(dst, "w"), indent=1)
 print(f"{len(out)} bf16 entries -> {dst}")
+# the f16 margin guard of tests/parity_bars.py: every f16 value above 90 % of its fixed bar, as measured by this run
+sys.path.insert(0, ROOT)
+from tests import parity_bars as pb  # noqa: E402
+watch = json.load(open(pb.WATCH_PATH)) if keep and os.path.exists(pb.WATCH_PATH) else {}
+for k, v in rec.items():
+    if k.startswith("f16/"):
+        key = k[len("f16/"):]
+        case, metric = key.rsplit("/", 1)
+        b = pb.F16_EXCEPTIONS.get(key, 1e-3)
+        if v > pb.F16_WATCH_FROM * b:
+            watch[key] = float(f"{v:.3e}")
+        elif key in watch:
+            del watch[key]
+json.dump(dict(sorted(watch.items())), open(pb.WATCH_PATH, "w"), indent=1)
+print(f"{len(watch)} watched f16 entries -> {pb.WATCH_PATH}: {watch}")
 f32 = {k: v for k, v in rec.items() if k.startswith("f32/")}
 if f32:
     worst = max(f32.items(), key=lambda kv: kv[1])
