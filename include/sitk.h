@@ -414,12 +414,13 @@ int sitk_overlap_set_tail_cus(sitk_overlap* o, int cus);
  * dependent kernels (hardware queues created four apart do), every dispatch of the chain is delayed by ~35 us -- 2.7 -> 6.5 ms
  * for 110 kernels -- whatever the blocked stream does afterwards; a stream that shares the chain's hardware QUEUE runs in line
  * behind it instead.  Which stream lands where follows the creation order of the process's streams, so a data-parallel caller
- * picks the stream it reduces its early buckets from by measurement: this call runs a chain of 64 dependent ~10-us launches
+ * picks the stream it reduces its early buckets from by measurement: this call runs a chain of 128 dependent ~11-us launches
  * (214 workgroups) on `main_stream` beside a helper stream's one-workgroup kernel -- with `candidate` idle (chain_free_us; after
  * one discarded warm-up pass), and with `candidate` blocked behind an event that the helper releases after release_us, its wait
  * issued behind the host's enqueue of the chain as the engine issues its collectives (chain_blocked_us; candidate_done_us = when
  * a small kernel behind that wait finished, from the chain's start).  A good
- * candidate: chain_blocked_us ~ chain_free_us and candidate_done_us ~ release_us (it ran beside the chain, not behind it).
+ * candidate: chain_blocked_us ~ chain_free_us and candidate_done_us ~ release_us (the release falls inside the chain: a candidate
+ * that shares the chain's hardware queue finishes behind the chain's END instead).
  * Synchronises the device (construction time only); both streams are idle again on return.                                  */
 int sitk_stream_probe(sitk_stream_t main_stream, sitk_stream_t candidate, float* chain_free_us, float* chain_blocked_us,
                       float* candidate_done_us, float* release_us);

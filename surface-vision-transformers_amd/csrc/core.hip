@@ -207,7 +207,8 @@ extern "C" int sitk_stream_probe(sitk_stream_t main_stream, sitk_stream_t candid
   if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess || hipEventCreate(&tc) != hipSuccess ||
       hipEventCreate(&late) != hipSuccess)
     fail("hipEventCreate");
-  const int chain = 64;                                   // dependent launches, one workgroup per CU of 214 CUs, ~10 us each
+  const int chain = 128;                                  // dependent launches, one workgroup per CU of 214 CUs, ~11 us each:
+                                                          // ~1.4 ms, so the release at 0.9 ms falls INSIDE the chain
   const unsigned long long link_ticks = 1000, late_ticks = 90000;     // 10 us; the helper releases the candidate at 900 us
   // pass 0: warm-up (the first launch of the kernel pays for its code object), discarded; pass 1: the reference -- the chain beside
   // the helper's kernel, the candidate idle; pass 2: the same with the candidate blocked behind the helper's release event

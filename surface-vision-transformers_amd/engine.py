@@ -161,12 +161,16 @@ def grad_write_stages_side(model, task, groups, per_bucket=1):
     return stage
 
 
+PROBE_RATIO = 1.12        # chain with the candidate parked / chain with it idle: above this the candidate is rejected
+
+
 def probe_stream(stream, main=None, reps=2):
     """sitk_stream_probe (include/sitk.h) of a torch stream against `main` (default: the current stream): the best of `reps` runs as
     {'free_us', 'blocked_us', 'done_us', 'release_us', 'ok'}.  ok = blocked behind an event the stream does not slow a chain of
-    dependent launches on `main` (<= 1.2 x the same chain with the stream idle; a stream on the toxic hardware queue measures 1.6 -
-    2.6 x, a harmless one 0.98 - 1.05 x) AND its work ran beside that chain (finished within 150 us of its release, not behind the
-    chain's end)."""
+    dependent launches on `main` (<= PROBE_RATIO x the same chain with the stream idle: measured 1.03 - 1.06 x for a harmless stream,
+    1.22 - 1.28 x when `main` is the lowest-priority side stream and the two queues share a dispatch pipe, 1.6 - 2.6 x when `main` is
+    the null stream and they do) AND its work ran beside that chain (finished within 150 us of its release; a stream that shares
+    the chain's hardware QUEUE finishes behind the chain's end)."""
     main = torch.cuda.current_stream(stream.device) if main is None else main
     best = None
     for _ in range(reps):
@@ -175,11 +179,11 @@ def probe_stream(stream, main=None, reps=2):
         r = dict(free_us=v[0].value, blocked_us=v[1].value, done_us=v[2].value, release_us=v[3].value)
         if best is None or r["blocked_us"] / r["free_us"] < best["blocked_us"] / best["free_us"]:
             best = r
-    best["ok"] = bool(best["blocked_us"] <= 1.2 * best["free_us"] and best["done_us"] <= best["release_us"] + 150.0)
+    best["ok"] = bool(best["blocked_us"] <= PROBE_RATIO * best["free_us"] and best["done_us"] <= best["release_us"] + 150.0)
     return best
 
 
-def pick_bucket_stream(device, priority=0, candidates=8):
+def pick_bucket_stream(device, priority=0, candidates=8, victims=()):
     """The stream the early all-reduce buckets are issued from, chosen by MEASUREMENT: candidates are taken from torch's stream pool
     one after the other (they land on the process's hardware queues in turn) and probed against the current stream; the first one
     that is harmless while blocked and concurrent while running wins.  Returns (stream, [probe results]); if none passes, the one
@@ -190,6 +194,13 @@ def pick_bucket_stream(device, priority=0, candidates=8):
         if any(st.cuda_stream == t[0].cuda_stream for t in tried):
             break                                         # the pool has wrapped around
         r = probe_stream(st)
+        # the candidate must also leave the OTHER streams of the step alone: parked, it delays the dispatches of every queue that
+        # shares its dispatch pipe -- the side stream's few launches (weight gradients, reductions, column sums: ~20 dispatches
+        # x ~35 us) were the victim in every slow data-parallel run of rounds 4 - 6
+        for i, v in enumerate(victims):
+            rv = probe_stream(st, main=v)
+            r[f"victim{i}_free_us"], r[f"victim{i}_blocked_us"] = rv["free_us"], rv["blocked_us"]
+            r["ok"] = bool(r["ok"] and rv["blocked_us"] <= PROBE_RATIO * rv["free_us"])
         tried.append((st, r))
         if r["ok"]:
             break
@@ -281,7 +292,7 @@ class TrainEngine:
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
                  wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True, dp_channels=None, optimize=None,
-                 wgrad_overlap_group=None, dp_stream_priority=0, dp_bucket_launches=None, dp_collective="stream"):
+                 wgrad_overlap_group=None, dp_stream_priority=0, dp_bucket_launches=None, dp_collective="stream", dp_final_on="bucket"):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -337,6 +348,7 @@ class TrainEngine:
         if dp_collective not in ("stream", "group"):
             raise rt.SitkError("TrainEngine: dp_collective is 'stream' or 'group'")
         self.dp_collective = dp_collective
+        self.dp_final_on = dp_final_on          # "bucket": the final bucket from the bucket stream too; "main": from the main stream (A/B)
         if self.dp and dp_collective == "stream" and torch.distributed.get_backend(process_group) == "nccl":
             # (c10d before 2.8 launched EVERY NCCL collective on the process group's internal stream: the bucket stream would only
             # carry the events; the arrangement the stand-in study measured is the one torch >= 2.8 produces)
@@ -504,7 +516,8 @@ class TrainEngine:
             # dispatch of the chain (~35 us each; +0.7 .. +2.3 ms per step in rounds 4 - 5), one that shares its QUEUE runs behind the
             # chain instead of beside it.  Placement follows the process's stream creation order, so it is measured, not assumed.
             with torch.cuda.device(self.device):
-                self._ar_stream, self.dp_stream_probe = pick_bucket_stream(self.device, int(dp_stream_priority))
+                self._ar_stream, self.dp_stream_probe = pick_bucket_stream(
+                    self.device, int(dp_stream_priority), victims=([self._side_torch] if self._side_torch is not None else []))
             self._ar_done = torch.cuda.Event()
             self._ar_used = False
         if use_graph is None:
@@ -1000,7 +1013,11 @@ class TrainEngine:
         # -- every collective of the communicator is launched from one stream, in one order, on every rank (two streams feeding
         # one communicator would rely on the library's internal launch serialisation; nothing is gained by it: the optimizer pass
         # waits for this bucket either way)
-        self._allreduce_early(self.bucket_plan[-1])
+        if self.dp_final_on == "main" and self.dp_collective == "stream":
+            for lo, hi in self.bucket_plan[-1]:
+                self._allreduce(lo, hi)
+        else:
+            self._allreduce_early(self.bucket_plan[-1])
         self._join_collectives()
         self._run(self._optimizer, "opt")
         self.nsteps += 1

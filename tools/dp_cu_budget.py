@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--own-stream", type=int, default=None, help="1: the stand-in runs on a stream of its own behind an event (where an "
                     "async_op=True collective runs); 0: on the stream that is current when the engine issues the collective (where a "
                     "synchronous one runs).  Default: follows --collective")
+    ap.add_argument("--final-on", default="bucket", choices=("bucket", "main"), help="TrainEngine(dp_final_on=...): the final bucket from the bucket stream (default) or the main stream")
     ap.add_argument("--skip-streams", type=int, default=0, help="take this many streams from torch's pool before the stand-in's own one")
     ap.add_argument("--per-bucket", default=None, help="side launches per early all-reduce bucket: an int, or a comma list of bucket sizes "
                     "(launches it does not cover travel with the final bucket); engine default: all side launches in one early bucket")
@@ -103,9 +104,9 @@ def main():
                     compute_dtype=a.dtype)
         eng = engine.TrainEngine(model, B, input_layout="surface", lr=1e-5, momentum=0.9, process_group=dist.group.WORLD, device=dev,
                                  wgrad_overlap_cus=side, dp_channels=(ch or chans[0]), wgrad_overlap=nlay, wgrad_overlap_group=group,
-                                 dp_stream_priority=a.prio, dp_collective=a.collective, dp_bucket_launches=(None if a.per_bucket is None else (int(a.per_bucket) if a.per_bucket.isdigit() else [int(v) for v in a.per_bucket.split(",")])))
+                                 dp_stream_priority=a.prio, dp_collective=a.collective, dp_final_on=a.final_on, dp_bucket_launches=(None if a.per_bucket is None else (int(a.per_bucket) if a.per_bucket.isdigit() else [int(v) for v in a.per_bucket.split(",")])))
         assert eng.dp_side, "expected the side-stream form"
-        fmt = lambda rs: ", ".join(f"{r['blocked_us']:.0f}/{r['free_us']:.0f} us done {r['done_us']:.0f}{' *' if r['chosen'] else ''}" for r in rs)
+        fmt = lambda rs: ", ".join(f"{r['blocked_us']:.0f}/{r['free_us']:.0f} us done {r['done_us']:.0f}" + (f" side {r['victim0_blocked_us']:.0f}/{r['victim0_free_us']:.0f}" if 'victim0_free_us' in r else "") + (' *' if r['chosen'] else '') for r in rs)
         print(f"  placement probes (chain blocked / free, candidate's kernel done; * = chosen): side stream [{fmt(eng.side_stream_probe)}]  "
               f"bucket stream [{fmt(eng.dp_stream_probe)}]", flush=True)
         log, tl = [], []
