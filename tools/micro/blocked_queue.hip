@@ -59,12 +59,16 @@ int main(int argc, char** argv) {
     for (auto s : X) busy_kernel<<<1, 64, 0, s>>>(p, 10);
     busy_kernel<<<1, 64, 0, side>>>(p, 10);
     CHECK(hipDeviceSynchronize());
-    const char* all_modes[] = {"none", "wait", "kernel", "hop"};
+    // "alone": the chain with NO side stream at all; "sidefree": the four side kernels run, but unforked (enqueued up front, nothing
+    // parked behind an event of the chain) -- what the side stream's own parked waits cost the chain
+    const char* all_modes[] = {"none", "wait", "kernel", "hop", "alone", "sidefree"};
     std::vector<const char*> modes(all_modes, all_modes + (argc > 4 ? atoi(argv[4]) : 4));     // argv[4] = 2: "none" and "wait" only
+    if (argc > 5 && atoi(argv[5])) modes = {"none", "alone", "sidefree"};
     printf("# %d extra streams, %d dummy low-priority streams in front of them, chain on the %s stream, GPU_MAX_HW_QUEUES=%s\n", NX, ndummy, use_null ? "null" : "created",
            getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(default)");
     for (const char* mode : modes) {
-        const bool none = !strcmp(mode, "none");
+        const bool alone = !strcmp(mode, "alone"), sidefree = !strcmp(mode, "sidefree");
+        const bool none = !strcmp(mode, "none") || alone || sidefree;
         for (int j = 0; j < (none ? 1 : NX); ++j) {
             const int j2 = (j + 1) % NX;
             float best_chain = 1e9f, best_all = 1e9f, sum_chain = 0.f;
@@ -75,9 +79,11 @@ int main(int argc, char** argv) {
                 int nfork = 0;
                 for (int k = 0; k < NK; ++k) {
                     busy_kernel<<<214, 768, 150 * 1024, mainS>>>(p, chain_iters);
-                    if (k >= 50 && (k - 50) % 12 == 11 && nfork < 4) {      // four forks through the second half of the chain
-                        CHECK(hipEventRecord(fork[nfork], mainS));
-                        CHECK(hipStreamWaitEvent(side, fork[nfork], 0));
+                    if (!alone && k >= 50 && (k - 50) % 12 == 11 && nfork < 4) {      // four forks through the second half of the chain
+                        if (!sidefree) {
+                            CHECK(hipEventRecord(fork[nfork], mainS));
+                            CHECK(hipStreamWaitEvent(side, fork[nfork], 0));
+                        }
                         busy_kernel<<<40, 256, 150 * 1024, side>>>(p, side_iters);
                         CHECK(hipEventRecord(done[nfork], side));
                         ++nfork;
