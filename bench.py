@@ -143,7 +143,8 @@ def also_lines(timeout_s=240):
             d = json.loads(lines[-1])
             out[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "step_mfma_frac": d["step_mfma_frac"],
                          "dtype": d["dtype"], "steps": d["steps"], "workload": d["config"]["workload"],
-                         "parallelism": d["config"]["parallelism"], "hip_graph": d["config"]["hip_graph"]}
+                         "parallelism": d["config"]["parallelism"], "hip_graph": d["config"]["hip_graph"],
+                         "batch_parts": d["config"].get("batch_parts", 1)}
         except subprocess.TimeoutExpired:
             out[name] = {"error": f"timeout after {timeout_s} s"}
     return out
@@ -192,6 +193,7 @@ def main():
                          "all-reduced over a ONE-rank RCCL group -- what each rank of an N > 1 run executes, minus the wire time")
     ap.add_argument("--dp-channels", type=int, default=None,
                     help="RCCL channels (= workgroups of an all-reduce; NCCL_MAX_NCHANNELS) the step leaves CUs for (default 16)")
+    ap.add_argument("--whole-batch", action="store_true", help="A/B: the plain engine where make_engine would split the batch over two streams")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the `also` object (f16, data-parallel form, configs 3 and 5 as child processes behind the headline)")
     ap.add_argument("--pg-priority", default="default", choices=["default", "high"],
@@ -257,11 +259,14 @@ def main():
     if args.task == "mpp":
         model = masked_patch_pretraining(model, mk["dim"], K, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02,
                                          channels=4, num_vertices=V)
-    eng = engine.TrainEngine(model, B, task=args.task, input_layout="surface", lr=1e-5, momentum=0.9,
-                             process_group=pg, use_graph=(True if args.graph else (False if args.no_graph else None)), device=dev,
-                             wgrad_overlap=args.wgrad_overlap, prefetch_gather=not args.no_prefetch,
-                             wgrad_overlap_cus=args.overlap_cus, head_deferred=not args.no_head_deferred,
-                             dp_channels=args.dp_channels)
+    # (engine.make_engine: the form measured fastest for the configuration -- SiT-small on one GPU runs its batch as two concurrent
+    # half-batch steps on two streams, everything else the plain engine; --whole-batch forces the latter)
+    mk_engine = engine.TrainEngine if args.whole_batch else engine.make_engine
+    eng = mk_engine(model, B, task=args.task, input_layout="surface", lr=1e-5, momentum=0.9,
+                    process_group=pg, use_graph=(True if args.graph else (False if args.no_graph else None)), device=dev,
+                    wgrad_overlap=args.wgrad_overlap, prefetch_gather=not args.no_prefetch,
+                    wgrad_overlap_cus=args.overlap_cus, head_deferred=not args.no_head_deferred,
+                    dp_channels=args.dp_channels)
     g = torch.Generator(device=dev).manual_seed(100 + rank)   # every rank its own synthetic shard
     x = torch.randn((B, 40962, 4), device=dev, generator=g)
     y = torch.randn((B,), device=dev, generator=g) * 2 + 40 if args.task == "regression" else None
@@ -300,20 +305,23 @@ def main():
                                                   "f32": "f32 MFMA (verification mode)"}[args.dtype],
                    "global_batch": B * world, "parallelism": f"dp{world}" + (" (data-parallel form on a one-rank RCCL group)" if args.dp_form and world == 1 else ""),
                    "hip_graph": bool(eng.use_graph),
+                   "batch_parts": len(getattr(eng, "parts", [eng])),      # 2: two concurrent half-batch steps (engine.SplitTrainEngine)
                    "wgrad_overlap_layers": int(eng.wgrad_overlap),
                    "loss_after": round(loss, 6),
                    # placement of the engine's extra streams, measured at construction (sitk_stream_probe): chain of dependent
                    # launches alone / with the stream blocked behind an event, us; ok = harmless and concurrent
                    "stream_probe": {k: [{kk: (round(vv, 1) if isinstance(vv, float) else vv) for kk, vv in r.items()} for r in v]
                                     for k, v in (("side", getattr(eng, "side_stream_probe", [])),
-                                                 ("bucket", getattr(eng, "dp_stream_probe", []))) if v}},
+                                                 ("bucket", getattr(eng, "dp_stream_probe", [])),
+                                                 ("parts", [r for pr in getattr(eng, "stream_probe", []) for r in pr])) if v}},
         "step_gflop_per_sample": round(gf, 3),
         "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
     }
     if rank == 0:
         if not args.no_probe:
             from sitk import probe
-            out["roofline"] = probe.dominant_kernel_roofline(eng, PEAK_BF16_TFLOPS, PEAK_HBM_GBS)
+            # (a split engine: the kernels of ONE half-batch step, the shapes its launches really have)
+            out["roofline"] = probe.dominant_kernel_roofline(getattr(eng, "owner", eng), PEAK_BF16_TFLOPS, PEAK_HBM_GBS)
             try:  # HBM traffic of the dominant kernel from the committed PMC run (cannot be collected live)
                 tr = json.load(open(os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")))
                 if args.model == "tiny" and args.batch == 64 and args.patches == 320:

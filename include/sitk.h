@@ -40,7 +40,7 @@ extern "C" {
 #define SITK_ERR_INVALID (-1)
 #define SITK_ERR_LAUNCH (-2)
 
-#define SITK_ABI_VERSION 11
+#define SITK_ABI_VERSION 12
 
 typedef void* sitk_stream_t; /* hipStream_t */
 
@@ -558,15 +558,20 @@ int sitk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
  * guard: a non-finite gradient reaches the parameters).  Not NULL (the engine: loss-scaled f16 mode only): a gradient ELEMENT that
  * is not finite -- an f16 intermediate that overflowed behind the loss scale -- never reaches the parameters or the optimizer
  * state: it is skipped, zeroed like every consumed gradient, and counted in *nonfinite (atomic add; the caller polls it when it
- * likes).  Adam's step count advances whether or not elements were skipped.                                              */
+ * likes).  Adam's step count advances whether or not elements were skipped.
+ * grad2 (ABI 12; NULL = none): a SECOND gradient buffer of the same layout (n gradients + n_extra accumulators) -- the other half of
+ * a batch that ran as two concurrent half-batch steps (engine.SplitTrainEngine): the pass consumes grad * grad_scale *
+ * *inv_loss_scale + grad2 * grad_scale * *inv_loss_scale2 (each half has its own loss scale in f16 mode), clears BOTH buffers
+ * (zero_grad), and copies (grad[n + keep_idx] + grad2[n + keep_idx]) * keep_scale to keep_dst (the batch loss = the mean of the
+ * halves' losses: keep_scale 1 / 2; without grad2 pass 1).                                                               */
 int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state, float momentum,
                       float weight_decay, int nesterov, float grad_scale, int zero_grad, int64_t n_extra,
-                      int64_t keep_idx, float* keep_dst, const float* inv_loss_scale, int* nonfinite,
-                      sitk_stream_t stream);
+                      int64_t keep_idx, float* keep_dst, const float* inv_loss_scale, int* nonfinite, float* grad2,
+                      const float* inv_loss_scale2, float keep_scale, sitk_stream_t stream);
 int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double* state,
                        float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, float grad_scale,
                        int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst, const float* inv_loss_scale,
-                       int* nonfinite, sitk_stream_t stream);
+                       int* nonfinite, float* grad2, const float* inv_loss_scale2, float keep_scale, sitk_stream_t stream);
 
 #ifdef __cplusplus
 }

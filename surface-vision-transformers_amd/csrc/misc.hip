@@ -668,7 +668,11 @@ __global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, flo
                                                       int64_t n, const double* __restrict__ state, float momentum, float wd,
                                                       int nesterov, float gscale, int zero, int64_t n_extra, int64_t keep_idx,
                                                       float* __restrict__ keep_dst, const float* __restrict__ inv_gscale,
-                                                      int* __restrict__ nonfinite) {
+                                                      int* __restrict__ nonfinite, float* __restrict__ g2,
+                                                      const float* __restrict__ inv_gscale2, float keep_scale) {
+  // g2 (ABI 12): a SECOND gradient buffer of the same layout (the other half of a batch that ran as two concurrent half-batch
+  // steps, each with its own loss scale in f16 mode): the pass consumes g * s1 + g2 * s2 and clears both
+  const float gscale2 = g2 ? gscale * (inv_gscale2 ? inv_gscale2[0] : 1.f) : 0.f;
   if (inv_gscale) gscale *= inv_gscale[0];               // the step's loss scale (f16 compute mode), undone here
   const float lr = (float)state[0];
   const int64_t nvec = n >> 2;
@@ -681,8 +685,12 @@ __global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, flo
   int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
     const f32x4 pv = load4(p + 4 * i);
-    const f32x4 graw = load4(g + 4 * i) * gscale;
+    f32x4 graw = load4(g + 4 * i) * gscale;
     if (zero) store4(g + 4 * i, z);
+    if (g2) {
+      graw = graw + load4(g2 + 4 * i) * gscale2;
+      if (zero) store4(g2 + 4 * i, z);
+    }
     f32x4 gv = graw + pv * wd;
     f32x4 bv = z, bold = z;
     if (momentum != 0.f) {
@@ -701,8 +709,12 @@ __global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, flo
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     const int64_t i = (nvec << 2) + threadIdx.x;
-    const float graw = g[i] * gscale;
+    float graw = g[i] * gscale;
     if (zero) g[i] = 0.f;
+    if (g2) {
+      graw += g2[i] * gscale2;
+      if (zero) g2[i] = 0.f;
+    }
     if (!guard || fabsf(graw) <= 3.0e38f) {
       float gv = graw + p[i] * wd;
       if (momentum != 0.f) {
@@ -718,8 +730,9 @@ __global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, flo
   if (bad && nonfinite) atomicAdd(nonfinite, bad);
   if (zero)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra; i += (int64_t)gridDim.x * 256) {
-      if (i == keep_idx && keep_dst) keep_dst[0] = g[n + i];
+      if (i == keep_idx && keep_dst) keep_dst[0] = (g[n + i] + (g2 ? g2[n + i] : 0.f)) * keep_scale;
       g[n + i] = 0.f;
+      if (g2) g2[n + i] = 0.f;
     }
 }
 
@@ -733,13 +746,20 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, fl
                                                        float* __restrict__ v, int64_t n, const double* __restrict__ state,
                                                        float b1, float b2, float eps, float wd, int decoupled, float gscale,
                                                        int zero, int64_t n_extra, int64_t keep_idx, float* __restrict__ keep_dst,
-                                                       const float* __restrict__ inv_gscale, int* __restrict__ nonfinite) {
+                                                       const float* __restrict__ inv_gscale, int* __restrict__ nonfinite,
+                                                       float* __restrict__ g2, const float* __restrict__ inv_gscale2,
+                                                       float keep_scale) {
+  const float gscale2 = g2 ? gscale * (inv_gscale2 ? inv_gscale2[0] : 1.f) : 0.f;      // (see sgd_dev_kernel)
   if (inv_gscale) gscale *= inv_gscale[0];               // the step's loss scale (f16 compute mode), undone here
   const float lr = (float)state[0];
   const float bc1 = (float)(1.0 - state[1]), bc2_sqrt = (float)sqrt(1.0 - state[2]);
   int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     float pv = p[i], gv = g[i] * gscale;
+    if (g2) {
+      gv += g2[i] * gscale2;
+      if (zero) g2[i] = 0.f;
+    }
     if (nonfinite && !(fabsf(gv) <= 3.0e38f)) {          // not finite, guarded mode: skipped and counted (see sgd_dev_kernel)
       ++bad;
       if (zero) g[i] = 0.f;
@@ -758,8 +778,9 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, fl
   if (bad && nonfinite) atomicAdd(nonfinite, bad);
   if (zero)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_extra; i += (int64_t)gridDim.x * 256) {
-      if (i == keep_idx && keep_dst) keep_dst[0] = g[n + i];
+      if (i == keep_idx && keep_dst) keep_dst[0] = (g[n + i] + (g2 ? g2[n + i] : 0.f)) * keep_scale;
       g[n + i] = 0.f;
+      if (g2) g2[n + i] = 0.f;
     }
 }
 
@@ -939,21 +960,23 @@ extern "C" int sitk_adam_step(float* param, const float* grad, float* exp_avg, f
 extern "C" int sitk_sgd_step_dev(float* param, float* grad, float* momentum_buf, int64_t n, const double* state,
                                  float momentum, float weight_decay, int nesterov, float grad_scale, int zero_grad,
                                  int64_t n_extra, int64_t keep_idx, float* keep_dst, const float* inv_loss_scale,
-                                 int* nonfinite, sitk_stream_t stream) {
+                                 int* nonfinite, float* grad2, const float* inv_loss_scale2, float keep_scale,
+                                 sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(param && grad && state && n > 0 && n_extra >= 0, "sgd_step_dev: bad arguments");
   SITK_REQUIRE(momentum == 0.f || momentum_buf, "sgd_step_dev: momentum needs a buffer");
   SITK_REQUIRE(n % 4 == 0 || n_extra == 0, "sgd_step_dev: accumulators behind the gradients need n %% 4 == 0");
   hipLaunchKernelGGL(sgd_dev_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      param, grad, momentum_buf, n, state, momentum, weight_decay, nesterov, grad_scale, zero_grad, n_extra,
-                     keep_idx, keep_dst, inv_loss_scale, nonfinite);
+                     keep_idx, keep_dst, inv_loss_scale, nonfinite, grad2, inv_loss_scale2, keep_scale);
   return check_launch("sgd_step_dev");
 }
 
 extern "C" int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double* state,
                                   float beta1, float beta2, float eps, float weight_decay, int decoupled_wd, float grad_scale,
                                   int zero_grad, int64_t n_extra, int64_t keep_idx, float* keep_dst,
-                                  const float* inv_loss_scale, int* nonfinite, sitk_stream_t stream) {
+                                  const float* inv_loss_scale, int* nonfinite, float* grad2, const float* inv_loss_scale2,
+                                  float keep_scale, sitk_stream_t stream) {
   using namespace sitk;
   SITK_REQUIRE(param && grad && exp_avg && exp_avg_sq && state && n > 0 && n_extra >= 0, "adam_step_dev: bad arguments");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -961,7 +984,7 @@ extern "C" int sitk_adam_step_dev(float* param, float* grad, float* exp_avg, flo
   SITK_LAUNCH_CHECK("adam_advance");
   hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n, state,
                      beta1, beta2, eps, weight_decay, decoupled_wd, grad_scale, zero_grad, n_extra, keep_idx, keep_dst,
-                     inv_loss_scale, nonfinite);
+                     inv_loss_scale, nonfinite, grad2, inv_loss_scale2, keep_scale);
   return check_launch("adam_step_dev");
 }
 

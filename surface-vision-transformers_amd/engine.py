@@ -34,11 +34,13 @@ _ALIGN = 64  # floats (256 B): every parameter view is 16-byte aligned with room
 class FlatParams:
     """Flat fp32 storage for parameters / gradients / optimizer state of a module."""
 
-    def __init__(self, module, device, grad_extra=0, order=None):
+    def __init__(self, module, device, grad_extra=0, order=None, share=None):
         """order: key(parameter) -> sortable; the buffer then holds the parameters sorted by it (stable: module order within
         one key).  The data-parallel engine orders by the point of the step at which a gradient becomes final, so that
         every all-reduce bucket is ONE contiguous range.  Nothing else depends on the order: the module's parameters are
-        views (state_dict / checkpoints unchanged), the optimizer pass is elementwise."""
+        views (state_dict / checkpoints unchanged), the optimizer pass is elementwise.
+        share: another FlatParams of the SAME module and order (SplitTrainEngine): this one uses ITS parameter buffer -- the module's
+        parameters stay views of it, their .grad stays the first engine's -- and owns only a gradient buffer of the same layout."""
         self.params = []
         seen = set()
         for p in module.parameters():
@@ -52,6 +54,14 @@ class FlatParams:
             self.offsets[id(p)] = (off, p.numel())
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         self.total = off
+        if share is not None:
+            assert share.total == off and [id(p) for p in share.params] == [id(p) for p in self.params]
+            self.flat = share.flat
+            self.grad_all = torch.zeros(off + grad_extra, dtype=torch.float32, device=device)
+            self.grad = self.grad_all[:off]
+            self._extra_used = 0
+            assert share.still_flat()
+            return
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
         # grad_extra floats behind the gradients: per-step accumulators (loss, padded embedding gradient, ...) that are
         # zeroed together with the gradients by ONE fill (`grad_all.zero_()`); never part of an all-reduce range
@@ -292,7 +302,7 @@ class TrainEngine:
                  lr=1e-5, momentum=0.9, weight_decay=0.0, nesterov=False, betas=(0.9, 0.999), eps=1e-8,
                  process_group=None, bwd_slices=None, use_graph=None, device=None, normalise=None, keep_grads=False,
                  wgrad_overlap=None, prefetch_gather=True, wgrad_overlap_cus=None, head_deferred=True, dp_channels=None, optimize=None,
-                 wgrad_overlap_group=None, dp_stream_priority=0, dp_bucket_launches=None, dp_collective="stream", dp_final_on="bucket"):
+                 wgrad_overlap_group=None, dp_stream_priority=0, dp_bucket_launches=None, dp_collective="stream", dp_final_on="bucket", _share=None, _defer_optimizer=False):
         if task == "mpp":
             assert isinstance(model, masked_patch_pretraining)
             self.ssl, self.sit = model, model.transformer
@@ -399,8 +409,12 @@ class TrainEngine:
         self._bucket_sizes = side_bucket_sizes(len(self._side_groups), self.dp_bucket_launches) if self.dp_side else []
         self._n_early = len(self._bucket_sizes)
         side_stage = grad_write_stages_side(self.module, task, self._side_groups, self.dp_bucket_launches) if self.dp_side else {}
+        # _share (SplitTrainEngine): another engine of the same module whose parameter buffer this one uses; this one then runs
+        # forward + backward into a gradient buffer of its own and leaves the optimizer pass to its owner
+        self._defer_optimizer = bool(_defer_optimizer) or _share is not None
         self.fp = FlatParams(self.module, self.device, grad_extra=self.D * self.ld + 4 * _ALIGN + self.D,
-                             order=lambda p: (id(p) in frozen, side_stage.get(id(p), 0)))
+                             order=lambda p: (id(p) in frozen, side_stage.get(id(p), 0)),
+                             share=(_share.fp if isinstance(_share, TrainEngine) else None))
         self.n_opt = min([self.fp.offsets[i][0] for i in frozen], default=self.fp.total)
         dev, f32 = self.device, torch.float32
         B, P, N, D, K, ld = self.B, self.P, self.N, self.D, self.K, self.ld
@@ -454,7 +468,9 @@ class TrainEngine:
             rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
             self.rng_state = torch.tensor([(torch.initial_seed() + 0x9E3779B97F4A7C15 * rank) & 0x7FFFFFFFFFFFFFFF, 0],
                                           dtype=torch.int64, device=dev)
-        if optimizer == "sgd":
+        if _share is not None:
+            self.state = [None, None]                   # (the owner of the shared parameters holds the optimizer state)
+        elif optimizer == "sgd":
             self.state = [torch.zeros_like(self.fp.flat)] if momentum != 0 else [None]
         elif optimizer in ("adam", "adamw"):
             self.state = [torch.zeros_like(self.fp.flat), torch.zeros_like(self.fp.flat)]
@@ -806,9 +822,12 @@ class TrainEngine:
         self.opt["lr"] = float(lr)
         self.hyper[0:1].fill_(float(lr))
 
-    def _optimizer(self):
+    def _optimizer(self, other=None):
+        """The fused optimizer pass over this engine's gradient buffer -- or, with `other` (SplitTrainEngine: the engine of the other
+        half batch, same parameters, its own gradient buffer), over the MEAN of the two buffers: each half's loss is a mean over its
+        own samples, so the whole batch's gradient is (g_a + g_b) / 2 and its loss (l_a + l_b) / 2; the pass clears both."""
         o, fp, L, s = self.opt, self.fp, rt.lib, self._s()
-        scale = 1.0 / self.world
+        scale = (0.5 if other is not None else 1.0) / self.world
         # the loss scale S of the f16 mode: divided out by the optimizer pass itself (1 / S read from device memory), unless
         # the gradients were already unscaled in place (kept gradients; data parallelism, where every rank has its own S)
         inv_s = self.gscale[1:2].data_ptr() if self.loss_scaled and not self._unscale_in_place else None
@@ -820,15 +839,21 @@ class TrainEngine:
         keep_idx = self._loss_extra_idx + (fp.total - n)
         keep_dst = self.loss.data_ptr() if zero else None
         guard = self.nonfinite.data_ptr() if self.loss_scaled else None
+        g2 = inv_s2 = None
+        if other is not None:
+            assert other.fp.grad_all.numel() == fp.grad_all.numel() and other.fp.flat.data_ptr() == fp.flat.data_ptr()
+            g2 = other.fp.grad_all.data_ptr()
+            inv_s2 = other.gscale[1:2].data_ptr() if other.loss_scaled and not other._unscale_in_place else None
+        keep_scale = 0.5 if other is not None else 1.0
         if o["kind"] == "sgd":
             rt.check(L.sitk_sgd_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), rt.ptr(self.state[0]), n,
                                          self.hyper.data_ptr(), o["momentum"], o["wd"], int(o["nesterov"]), scale, zero,
-                                         n_extra, keep_idx, keep_dst, inv_s, guard, s))
+                                         n_extra, keep_idx, keep_dst, inv_s, guard, g2, inv_s2, keep_scale, s))
         else:
             rt.check(L.sitk_adam_step_dev(fp.flat.data_ptr(), fp.grad_all.data_ptr(), self.state[0].data_ptr(),
                                           self.state[1].data_ptr(), n, self.hyper.data_ptr(), o["betas"][0],
                                           o["betas"][1], o["eps"], o["wd"], int(o["kind"] == "adamw"), scale, zero, n_extra,
-                                          keep_idx, keep_dst, inv_s, guard, s))
+                                          keep_idx, keep_dst, inv_s, guard, g2, inv_s2, keep_scale, s))
 
     # ---- segments: [fwd + loss + head/backward slice 0], [slice 1], ..., [finish + optimizer] ------------
     def _segment_fns(self):
@@ -981,7 +1006,8 @@ class TrainEngine:
                 self._finish_backward()
                 if self.loss_scaled and self.keep_grads:
                     self.fp.grad.mul_(self.gscale[1])          # .grad is read by the caller: unscaled
-                self._optimizer()
+                if not self._defer_optimizer:                  # (a half of a SplitTrainEngine: its owner runs the pass over both halves)
+                    self._optimizer()
             self._run(whole, "step")
             self.nsteps += 1
             return self.loss
@@ -1022,3 +1048,112 @@ class TrainEngine:
         self._run(self._optimizer, "opt")
         self.nsteps += 1
         return self.loss
+
+
+class SplitTrainEngine:
+    """One train step as TWO concurrent half-batch steps on two streams (round 6).
+
+    For the wide configurations (dim 384: SiT-small) every kernel of the step is a multi-round grid -- 642 GEMM workgroups on 512
+    slots, LayerNorm and epilogue phases that stream while the matrix pipe idles, attention rounds with a quarter-full tail --
+    and two half-batch steps side by side fill each other's gaps: measured on MI355X (tools/dual_engine.py,
+    profiles/r06_split_batch.txt) SiT-small on 1280 patches, B = 32: 15.09 -> 13.87 ms per step (-8 %), on 320 patches, B = 64:
+    6.82 -> 6.58 (-3.5 %); SiT-base: -0.6 .. -1.7 % (its grids have enough rounds of their own); four parts: slower than one.  The
+    tiny model's kernels are single-wave grids: nothing to fill (2.45 = 2.45 ms; its own form is the side-stream step).
+
+    Two TrainEngines over the SAME module share one parameter buffer (FlatParams(share=...)); each owns its activations, its
+    hipGraph, its stream and a gradient buffer of the same layout, and runs gather -> forward -> loss -> backward -> weight
+    gradients of ITS half; the owner's optimizer pass then consumes both gradient buffers at once (sitk_*_step_dev, grad2:
+    (g_a + g_b) / 2 -- each half's loss is the mean over its own samples -- and the loss (l_a + l_b) / 2), clears both and is
+    the only launch on the caller's stream.  Same arithmetic as the whole-batch step up to the order of the fp32 sums over
+    samples (tests/test_engine_gpu.py::test_split_engine_*).  The two streams are picked by measurement (pick_bucket_stream): the
+    caller's stream is parked behind them for the length of a step, and a parked stream on the wrong hardware queue delays every
+    dispatch of its pipe mates (profiles/r06_dp_streams.txt).
+
+    Regression only, one GPU only (no process group), hipGraph replay (the wide models' form)."""
+
+    def __init__(self, model, batch_size, **kw):
+        if kw.get("task", "regression") != "regression" or kw.get("process_group") is not None:
+            raise rt.SitkError("SplitTrainEngine: task='regression' on one GPU only")
+        if batch_size % 2:
+            raise rt.SitkError("SplitTrainEngine: the batch must be even")
+        if kw.get("use_graph") is False:
+            raise rt.SitkError("SplitTrainEngine: the halves replay hipGraphs (use_graph=False is the whole-batch engine's)")
+        kw = dict(kw, use_graph=True, wgrad_overlap=0)
+        self.device = torch.device(kw.get("device") if kw.get("device") is not None else f"cuda:{torch.cuda.current_device()}")
+        self.B, self.half = batch_size, batch_size // 2
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            self.streams, self.stream_probe, self._rejected = [], [], []
+            for _ in range(2):
+                for attempt in range(6):
+                    st, probes = pick_bucket_stream(self.device, victims=list(self.streams))
+                    # ... and the other way round: the CALLER's stream is the one that sits parked while the halves run
+                    rv = probe_stream(cur, main=st)
+                    probes[-1]["caller_parked_ratio"] = rv["blocked_us"] / rv["free_us"]
+                    if rv["blocked_us"] <= PROBE_RATIO * rv["free_us"] or attempt == 5:
+                        break
+                    self._rejected.append(st)         # (kept: the pool's next stream lands on another queue)
+                self.streams.append(st)
+                self.stream_probe.append(probes)
+        self.owner = TrainEngine(model, self.half, _defer_optimizer=True, **kw)
+        self.other = TrainEngine(model, self.half, _share=self.owner, **kw)
+        self.parts = [self.owner, self.other]
+        self.module, self.fp = self.owner.module, self.owner.fp
+        self.use_graph, self.wgrad_overlap, self.keep_grads = True, 0, self.owner.keep_grads
+        self.loss = self.owner.loss
+        self.nsteps = 0
+
+    @property
+    def nonfinite_count(self):
+        return self.owner.nonfinite_count            # (the ONE optimizer pass counts for both halves)
+
+    def set_lr(self, lr):
+        self.owner.set_lr(lr)
+
+    def load_batch(self, x, target=None):
+        h = self.half
+        for i, e in enumerate(self.parts):
+            e.load_batch(x[i * h:(i + 1) * h], None if target is None else target.reshape(self.B, -1)[i * h:(i + 1) * h])
+
+    def _optimizer(self):
+        self.owner._optimizer(other=self.other)
+
+    def step(self, x=None, target=None, indices=None):
+        """One optimisation step on the batch in the halves' static input buffers (or on x / target).  Returns the device tensor
+        holding the step's loss (no host sync)."""
+        if indices is not None:
+            raise rt.SitkError("SplitTrainEngine: resident data sets (step(indices=...)) are the whole-batch engine's")
+        if x is not None:
+            self.load_batch(x, target)
+        cur = torch.cuda.current_stream(self.device)
+        for st, e in zip(self.streams, self.parts):
+            st.wait_stream(cur)                       # behind the previous optimizer pass and this step's input copies
+            with torch.cuda.stream(st):
+                e.step()
+        for st in self.streams:
+            cur.wait_stream(st)
+        if self.keep_grads:
+            # kept gradients (tests): the halves unscaled theirs in place; .grad (the owner's buffer) = the batch's gradient
+            self.owner.fp.grad.mul_(0.5).add_(self.other.fp.grad, alpha=0.5)
+            self.owner.loss_acc.mul_(0.5).add_(self.other.loss_acc, alpha=0.5)
+            self.other.fp.grad_all.zero_()
+            self.owner._optimizer()                   # (zero = 0 here: the buffers are cleared at the start of the next step)
+            self.loss = self.owner.loss
+        else:
+            self._optimizer()                         # ONE launch on the caller's stream: both gradient buffers, both cleared
+        self.nsteps += 1
+        return self.loss
+
+
+def make_engine(model, batch_size, **kw):
+    """The engine form measured fastest for the configuration: SplitTrainEngine (two concurrent half-batch steps) for a dim-384
+    regression model on one GPU with an even batch -- SiT-small, BASELINE config 3: -8 % at 1280 patches, -3.5 % at 320 --
+    TrainEngine otherwise (dim 192: the side-stream step; dim 768: its grids have rounds enough of their own, -0.6 .. -1.7 % is inside
+    the boxes' spread; masked patch pre-training; any process group).  Explicit launch-form arguments (use_graph=False,
+    wgrad_overlap, bwd_slices) select the plain engine."""
+    sit = model.transformer if kw.get("task", "regression") == "mpp" else model
+    explicit = kw.get("use_graph") is False or kw.get("wgrad_overlap") is not None or kw.get("bwd_slices") is not None
+    if (kw.get("task", "regression") == "regression" and kw.get("process_group") is None and not explicit and batch_size % 2 == 0
+            and getattr(sit, "dim", 0) == 384 and rt.dtype_code(sit.compute_dtype) != rt.F32):
+        return SplitTrainEngine(model, batch_size, **kw)
+    return TrainEngine(model, batch_size, **kw)

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SITK_LIB") or os.path.join(_HERE, "libsitk.so")
 
 F32, BF16, F16 = 0, 1, 2
 EPI_STORE, EPI_BIAS_RES, EPI_BIAS_GELU, EPI_DGELU = 0, 1, 2, 3
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class SitkError(RuntimeError):
@@ -145,8 +145,8 @@ _SIGS = {
     "sitk_gelu_bwd": (C.c_int, [_P, _P, _P, _L, _P]),
     "sitk_sgd_step": (C.c_int, [_P, _P, _P, _L, _F, _F, _F, _I, _F, _P]),
     "sitk_adam_step": (C.c_int, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _I, _F, _P]),
-    "sitk_sgd_step_dev": (C.c_int, [_P, _P, _P, _L, _P, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P, _P]),
-    "sitk_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P, _P]),
+    "sitk_sgd_step_dev": (C.c_int, [_P, _P, _P, _L, _P, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P, _P, _P, _F, _P]),
+    "sitk_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _I, _F, _I, _L, _L, _P, _P, _P, _P, _P, _F, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGS)
 
