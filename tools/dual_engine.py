@@ -30,7 +30,7 @@ def make(a, B, dev):
     model.allow_synthetic_table = True
     if a.task == "mpp":
         model = masked_patch_pretraining(model, mk["dim"], 4 * V, "cpu", mask_prob=0.75, replace_prob=0.8, swap_prob=0.02, channels=4, num_vertices=V)
-    eng = engine.TrainEngine(model, B, task=a.task, input_layout="surface", lr=1e-5, momentum=0.9, device=dev, use_graph=True)
+    eng = engine.TrainEngine(model, B, task=a.task, input_layout="surface", lr=1e-5, momentum=0.9, device=dev, use_graph=(None if a.default_form else True))
     g = torch.Generator(device=dev).manual_seed(100)
     x = torch.randn((B, 40962, 4), device=dev, generator=g)
     y = torch.randn((B,), device=dev, generator=g) * 2 + 40 if a.task == "regression" else None
@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--task", default="regression")
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--default-form", action="store_true", help="the engines' default launch form (dim 192: eager + side stream) instead of hipGraph replay")
     ap.add_argument("--parts", type=int, default=2, help="how many equal parts of the batch, each on a stream of its own")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
