@@ -1115,6 +1115,9 @@ class SplitTrainEngine:
         for i, e in enumerate(self.parts):
             e.load_batch(x[i * h:(i + 1) * h], None if target is None else target.reshape(self.B, -1)[i * h:(i + 1) * h])
 
+    def load_dataset(self, *a, **k):
+        raise rt.SitkError("SplitTrainEngine: resident data sets (load_dataset / step(indices=...)) are the whole-batch engine's")
+
     def _optimizer(self):
         self.owner._optimizer(other=self.other)
 
