@@ -1148,15 +1148,23 @@ class SplitTrainEngine:
         return self.loss
 
 
+def split_batch_by_default(dim, batch_size, task="regression", has_process_group=False, f32=False, explicit_form=False):
+    """make_engine's rule, as a pure function of the configuration (tests/test_host_cpu.py): the split-batch form is taken where it
+    was MEASURED faster by more than the spread between boxes -- dim 384 (SiT-small: -8 .. -9 % at 1280 patches, -2 .. -3.5 % at 320),
+    regression, one GPU, an even batch, a 16-bit compute mode, no explicit launch-form argument.  dim 192: its own form is the
+    side-stream step (the split loses 4 % at B = 64); dim 768: -0.6 .. -1.7 %, not enabled."""
+    return bool(dim == 384 and task == "regression" and not has_process_group and not f32 and not explicit_form
+                and batch_size >= 2 and batch_size % 2 == 0)
+
+
 def make_engine(model, batch_size, **kw):
     """The engine form measured fastest for the configuration: SplitTrainEngine (two concurrent half-batch steps) for a dim-384
-    regression model on one GPU with an even batch -- SiT-small, BASELINE config 3: -8 % at 1280 patches, -3.5 % at 320 --
-    TrainEngine otherwise (dim 192: the side-stream step; dim 768: its grids have rounds enough of their own, -0.6 .. -1.7 % is inside
-    the boxes' spread; masked patch pre-training; any process group).  Explicit launch-form arguments (use_graph=False,
-    wgrad_overlap, bwd_slices) select the plain engine."""
-    sit = model.transformer if kw.get("task", "regression") == "mpp" else model
+    regression model on one GPU with an even batch -- SiT-small, BASELINE config 3 -- TrainEngine otherwise (split_batch_by_default).
+    Explicit launch-form arguments (use_graph=False, wgrad_overlap, bwd_slices) select the plain engine."""
+    task = kw.get("task", "regression")
+    sit = model.transformer if task == "mpp" else model
     explicit = kw.get("use_graph") is False or kw.get("wgrad_overlap") is not None or kw.get("bwd_slices") is not None
-    if (kw.get("task", "regression") == "regression" and kw.get("process_group") is None and not explicit and batch_size % 2 == 0
-            and getattr(sit, "dim", 0) == 384 and rt.dtype_code(sit.compute_dtype) != rt.F32):
+    if split_batch_by_default(getattr(sit, "dim", 0), batch_size, task, kw.get("process_group") is not None,
+                              rt.dtype_code(sit.compute_dtype) == rt.F32, explicit):
         return SplitTrainEngine(model, batch_size, **kw)
     return TrainEngine(model, batch_size, **kw)

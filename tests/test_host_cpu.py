@@ -233,3 +233,18 @@ def test_seeded_construction_equals_the_reference(sitk_pkg, case):
             assert list(v.shape) == want[k]["shape"], (who, k)
             got = hashlib.sha256(v.detach().contiguous().numpy().tobytes()).hexdigest()
             assert got == want[k]["sha256"], f"{who}: {k} differs from the reference's seeded initial value"
+
+
+def test_make_engine_rule_is_the_measured_one(sitk_pkg):
+    """engine.make_engine's choice of launch form as a pure function (no GPU needed): the split-batch form -- two concurrent
+    half-batch steps on two streams -- exactly where profiles/r06_split_batch.txt measured it faster by more than the spread
+    between boxes: dim 384, regression, one GPU, an even batch, a 16-bit mode, no explicit launch-form argument."""
+    from sitk import engine
+    rule = engine.split_batch_by_default
+    assert rule(384, 32) and rule(384, 64)                                   # BASELINE config 3 and SiT-small on 320 patches
+    assert not rule(192, 64)                                                 # the tiny model: the side-stream step (the split loses there)
+    assert not rule(768, 32) and not rule(768, 32, task="mpp")              # base: -0.6 .. -1.7 %, inside the boxes' spread
+    assert not rule(384, 32, task="mpp")                                     # masked patch pre-training: not built
+    assert not rule(384, 32, has_process_group=True)                         # data parallel: the bucketed form
+    assert not rule(384, 33) and not rule(384, 1)                            # an odd batch cannot be halved
+    assert not rule(384, 32, f32=True) and not rule(384, 32, explicit_form=True)
