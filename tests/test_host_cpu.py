@@ -248,3 +248,24 @@ def test_make_engine_rule_is_the_measured_one(sitk_pkg):
     assert not rule(384, 32, has_process_group=True)                         # data parallel: the bucketed form
     assert not rule(384, 33) and not rule(384, 1)                            # an odd batch cannot be halved
     assert not rule(384, 32, f32=True) and not rule(384, 32, explicit_form=True)
+
+
+def test_flat_params_share_one_parameter_buffer(sitk_pkg):
+    """engine.FlatParams(share=...) -- what SplitTrainEngine's second half is built on: the same parameter buffer (the module's
+    parameters stay views of it, state_dict unchanged), the same layout, a gradient buffer and per-step accumulators of its own;
+    the module's .grad stays the first engine's."""
+    from sitk import engine
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.LayerNorm(7), torch.nn.Linear(7, 3))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    a = engine.FlatParams(m, "cpu", grad_extra=128)
+    b = engine.FlatParams(m, "cpu", grad_extra=128, share=a)
+    assert b.flat.data_ptr() == a.flat.data_ptr() and b.total == a.total and b.offsets == a.offsets
+    assert b.grad_all.data_ptr() != a.grad_all.data_ptr() and b.grad_all.numel() == a.grad_all.numel()
+    assert a.still_flat() and all(torch.equal(v, before[k]) for k, v in m.state_dict().items())
+    for p in m.parameters():
+        assert p.grad.data_ptr() == a.g(p).data_ptr() != b.g(p).data_ptr() and b.g(p).shape == p.shape
+    a.flat.add_(1.0)                                      # an optimizer pass through either object moves the module's parameters
+    assert all(torch.equal(v, before[k] + 1.0) for k, v in m.state_dict().items())
+    ea, eb = a.extra((4,)), b.extra((4,))                 # accumulators behind the gradients: same index, different buffers
+    assert ea.data_ptr() - a.grad_all.data_ptr() == eb.data_ptr() - b.grad_all.data_ptr()
