@@ -196,14 +196,15 @@ def probe_stream(stream, main=None, reps=2):
 def pick_bucket_stream(device, priority=0, candidates=8, victims=()):
     """The stream the early all-reduce buckets are issued from, chosen by MEASUREMENT: candidates are taken from torch's stream pool
     one after the other (they land on the process's hardware queues in turn) and probed against the current stream; the first one
-    that is harmless while blocked and concurrent while running wins.  Returns (stream, [probe results]); if none passes, the one
-    with the smallest blocked / free ratio (the results say so: 'ok' False)."""
+    that is harmless while blocked -- for the current stream and for every stream in `victims` -- and concurrent while running
+    wins.  Returns (stream, [probe results]); if none passes, the least harmful one (the results say so: 'ok' False)."""
     tried = []
     for _ in range(candidates):
         st = torch.cuda.Stream(device=device, priority=priority)
         if any(st.cuda_stream == t[0].cuda_stream for t in tried):
             break                                         # the pool has wrapped around
         r = probe_stream(st)
+        r["worst_ratio"] = r["blocked_us"] / r["free_us"] + (0.0 if r["done_us"] <= r["release_us"] + 150.0 else 10.0)
         # the candidate must also leave the OTHER streams of the step alone: parked, it delays the dispatches of every queue that
         # shares its dispatch pipe -- the side stream's few launches (weight gradients, reductions, column sums: ~20 dispatches
         # x ~35 us) were the victim in every slow data-parallel run of rounds 4 - 6
@@ -211,10 +212,11 @@ def pick_bucket_stream(device, priority=0, candidates=8, victims=()):
             rv = probe_stream(st, main=v)
             r[f"victim{i}_free_us"], r[f"victim{i}_blocked_us"] = rv["free_us"], rv["blocked_us"]
             r["ok"] = bool(r["ok"] and rv["blocked_us"] <= PROBE_RATIO * rv["free_us"])
+            r["worst_ratio"] = max(r["worst_ratio"], rv["blocked_us"] / rv["free_us"])
         tried.append((st, r))
         if r["ok"]:
             break
-    st, _ = min(tried, key=lambda t: (not t[1]["ok"], t[1]["blocked_us"] / t[1]["free_us"]))
+    st, _ = min(tried, key=lambda t: (not t[1]["ok"], t[1]["worst_ratio"]))      # (none passed: the least harmful one)
     return st, [dict(r, stream=f"{t.cuda_stream:#x}", chosen=(t is st)) for t, r in tried]
 
 
