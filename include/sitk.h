@@ -333,6 +333,12 @@ typedef struct {
  * + staged weights) and must stay untouched between fwd and bwd; `scratch` is transient.      */
 size_t sitk_encoder_acts_bytes(const sitk_encoder_cfg* cfg);
 size_t sitk_encoder_scratch_bytes(const sitk_encoder_cfg* cfg);
+/* The part of `scratch` reserved as the slab of a backward slice's ONE weight-gradient launch (sitk_gemm_wgrad_group_ws): sized
+ * for the worst slice LENGTH -- how many token splits a launch takes depends on how its tiles fill the chip's rounds, so a
+ * 4-layer slice of SiT-base needs more slab than all 12 layers -- plus room for the patch embedding's and the caller's extra
+ * problems.  0 when the shapes do not take the large-tile path.  (A launch that does not fit falls back to generic tiles:
+ * sitk_encoder_bwd* refuse to do that silently.)                                                                          */
+size_t sitk_encoder_wgrad_slab_bytes(const sitk_encoder_cfg* cfg);
 
 /* x_in (B*N, dim) fp32 -> x_out (B*N, dim) fp32.  save_for_backward = 0 runs the forward-only
  * (inference) schedule that keeps no activations (acts then only needs the staged weights).

@@ -201,9 +201,14 @@ static Layout make_layout(const sitk_encoder_cfg& c, char* acts, char* scratch) 
   {  // slab of the large-tile weight-gradient path (0 bytes when the shapes are not eligible)
     std::vector<sitk_wgrad_desc> wg(4 * nslot);
     for (int i = 0; i < 4 * nslot; ++i) wg[i] = wg4[i % 4];
-    L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg.data(), 4 * nslot, c.dtype);
-    if (L.scratch.wgrad_ws_bytes < sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype))     // a one-layer slice splits 12 ways
-      L.scratch.wgrad_ws_bytes = sitk_gemm_wgrad_group_ws_bytes(wg4, 4, c.dtype);
+    // The slab is sized for the WORST slice length, not for the whole depth: how many token splits a launch takes depends on how
+    // its tiles fill the chip's rounds, and a middle-sized slice can need more slab than all layers together (SiT-base: 4 layers
+    // = 2.25 rounds of tile pairs -> four token splits -> 453 MB, 12 layers = 6.75 rounds -> no split -> 340 MB).  Until round 6
+    // only the full depth and one layer were priced, and a data-parallel step of SiT-base in its default three slices fell back to
+    // the generic 64 x 64 weight-gradient tiles for two of them without a word: 49.1 instead of 39.9 ms per step.
+    L.scratch.wgrad_ws_bytes = 0;
+    for (int k = 1; k <= nslot; ++k)
+      L.scratch.wgrad_ws_bytes = std::max(L.scratch.wgrad_ws_bytes, sitk_gemm_wgrad_group_ws_bytes(wg.data(), 4 * k, c.dtype));
     if (L.scratch.wgrad_ws_bytes) L.scratch.wgrad_ws_bytes += (size_t)128 * 128 * 192 * 4;   // + the patch embedding's and the caller's extra tiles (sitk_encoder_bwd_extra)
     L.scratch.wgrad_ws = stake(L.scratch.wgrad_ws_bytes);
     {
@@ -299,6 +304,14 @@ extern "C" size_t sitk_encoder_scratch_bytes(const sitk_encoder_cfg* cfg) {
   SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_scratch_bytes, cfg);
   if (check_cfg(cfg)) return 0;
   return make_layout(*cfg, nullptr, nullptr).scratch_bytes;
+}
+
+// the slab make_layout reserves for the one weight-gradient launch of a backward slice (tests: every slice length must fit)
+SITK_F16_TWIN(sitk_encoder_wgrad_slab_bytes)
+extern "C" size_t sitk_encoder_wgrad_slab_bytes(const sitk_encoder_cfg* cfg) {
+  SITK_FORWARD_F16(cfg ? cfg->dtype : -1, sitk_encoder_wgrad_slab_bytes, cfg);
+  if (check_cfg(cfg)) return 0;
+  return make_layout(*cfg, nullptr, nullptr).scratch.wgrad_ws_bytes;
 }
 
 SITK_F16_TWIN(sitk_encoder_stage_weights)
@@ -654,6 +667,11 @@ extern "C" int sitk_encoder_bwd_overlap(const sitk_encoder_cfg* cfg, const sitk_
       wg_all.resize(before);
   }
   if (S.wg_batch && !wg_all.empty()) {
+    // (make_layout sizes the slab for every slice length; a launch that does not fit would fall back to the generic tiles
+    // without a word -- round 6 found SiT-base's three-slice data-parallel step doing exactly that, 25 % slower)
+    const size_t need = sitk_gemm_wgrad_group_ws_bytes(wg_all.data(), (int)wg_all.size(), dt);
+    SITK_REQUIRE(need == 0 || need <= S.wgrad_ws_bytes, "encoder_bwd: weight-gradient slab of %zu bytes, slice [%d, %d) needs %zu",
+                 S.wgrad_ws_bytes, layer_begin, layer_end, need);
     // (a data-parallel caller leaves the all-reduce channels' CUs out of the tail launch: sitk_overlap_set_tail_cus)
     SITK_TRY(sitk_gemm_wgrad_group_ws_cus(wg_all.data(), (int)wg_all.size(), dt, S.wgrad_ws, S.wgrad_ws_bytes,
                                           overlap ? sitk_overlap_tail_cus_(overlap) : 256, stream));

@@ -485,7 +485,10 @@ class TrainEngine:
         if bwd_slices is None:
             # every extra slice costs ~35 us (its own weight-gradient launch and reduction: 2.77 / 2.82 / 2.86 / 2.89 ms per
             # step for 1 / 2 / 3 / 4 slices, SiT-tiny B = 64) and hides that fraction of the gradient all-reduce less
-            bwd_slices = 1 if not self.dp else min(3, tr.depth)
+            # wide models, measured on a one-rank RCCL group (tools/dp_wide_probe.py, profiles/r06_dp_wide.txt): SiT-base 39.22 / 39.23 /
+            # 39.27 ms for 1 / 2 / 3 slices (three: the exposed final bucket is the smallest), SiT-small 15.59 / 15.51 / 16.28 (its
+            # 4-layer weight-gradient launches fill the chip's rounds badly: two slices)
+            bwd_slices = 1 if not self.dp else min(2 if self.D == 384 else 3, tr.depth)
         if not self.dp_side:
             bounds = [round(i * tr.depth / bwd_slices) for i in range(bwd_slices + 1)]
             self.slices = [(bounds[i], bounds[i + 1]) for i in range(bwd_slices)][::-1]

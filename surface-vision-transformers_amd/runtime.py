@@ -100,6 +100,7 @@ _SIGS = {
     "sitk_attention_bwd_phases": (C.c_int, [_P] * 9 + [_I, _I, _I, _I, _F, _I, _I, _P]),
     "sitk_encoder_acts_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "sitk_encoder_scratch_bytes": (_Z, [C.POINTER(EncoderCfg)]),
+    "sitk_encoder_wgrad_slab_bytes": (_Z, [C.POINTER(EncoderCfg)]),
     "sitk_encoder_fwd": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), _P, _P, _P, _Z, _P, _Z, _I, _P]),
     "sitk_encoder_bwd": (C.c_int, [C.POINTER(EncoderCfg), C.POINTER(LayerParams), C.POINTER(LayerParams), _P, _P,
                                    _P, _Z, _P, _Z, _I, _I, _P]),

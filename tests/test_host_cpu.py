@@ -269,3 +269,38 @@ def test_flat_params_share_one_parameter_buffer(sitk_pkg):
     assert all(torch.equal(v, before[k] + 1.0) for k, v in m.state_dict().items())
     ea, eb = a.extra((4,)), b.extra((4,))                 # accumulators behind the gradients: same index, different buffers
     assert ea.data_ptr() - a.grad_all.data_ptr() == eb.data_ptr() - b.grad_all.data_ptr()
+
+
+@pytest.mark.parametrize("model,B,N", [("tiny", 64, 321), ("small", 32, 1281), ("small", 64, 321), ("base", 32, 1281), ("base", 64, 321)])
+def test_wgrad_slab_fits_every_slice_length(sitk_pkg, model, B, N):
+    """Round 6 regression test.  The slab of a backward slice's one weight-gradient launch was sized for all layers and for one layer
+    only; how many token splits a launch takes depends on how its tiles fill the chip's rounds, so a MIDDLE-sized slice can need
+    more (SiT-base on 1281 tokens, 4 layers: 453 MB against 340 MB for all 12) -- and a launch that does not fit falls back to the
+    generic tiles without a word: the default three-slice data-parallel step of BASELINE config 5 ran 49.1 instead of 39.3 ms.
+    Host arithmetic only (no GPU): for every BASELINE width and every slice length the launch's need <= the layout's slab."""
+    import ctypes as C
+    from sitk import ops
+    from sitk import runtime as rt
+    kw = sit_oracle.MODEL_SIZES[model]
+    D, H, M = kw["dim"], kw["heads"], kw["mlp_dim"]
+    I, R = H * 64, B * N
+    cfg = ops.encoder_cfg(B, N, D, 12, H, M, rt.BF16)
+    slab = rt.lib.sitk_encoder_wgrad_slab_bytes(C.byref(cfg))
+    assert slab > 0
+    dims = [(D, M), (M, D), (D, I), (3 * I, D)]
+    worst = 0
+    for k in range(1, 13):
+        arr = (rt.WgradDesc * (4 * k))()
+        for i in range(4 * k):
+            n, kk = dims[i % 4]
+            arr[i].M, arr[i].N, arr[i].K, arr[i].lddy, arr[i].ldx, arr[i].lddw = R, n, kk, n, kk, kk
+        need = rt.lib.sitk_gemm_wgrad_group_ws_bytes(arr, 4 * k, rt.BF16)
+        assert 0 < need <= slab, (model, k, need, slab)
+        worst = max(worst, need)
+    assert slab >= worst
+    if model == "base" and N == 1281:                       # the case that was wrong: the worst slice is NOT the whole depth
+        arr = (rt.WgradDesc * 48)()
+        for i in range(48):
+            n, kk = dims[i % 4]
+            arr[i].M, arr[i].N, arr[i].K, arr[i].lddy, arr[i].ldx, arr[i].lddw = R, n, kk, n, kk, kk
+        assert rt.lib.sitk_gemm_wgrad_group_ws_bytes(arr, 16, rt.BF16) > rt.lib.sitk_gemm_wgrad_group_ws_bytes(arr, 48, rt.BF16)
