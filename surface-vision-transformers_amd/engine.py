@@ -1153,23 +1153,30 @@ class SplitTrainEngine:
         return self.loss
 
 
-def split_batch_by_default(dim, batch_size, task="regression", has_process_group=False, f32=False, explicit_form=False):
+def split_batch_by_default(dim, batch_size, task="regression", has_process_group=False, f32=False, explicit_form=False, tokens=0):
     """make_engine's rule, as a pure function of the configuration (tests/test_host_cpu.py): the split-batch form is taken where it
-    was MEASURED faster by more than the spread between boxes -- dim 384 (SiT-small: -8 .. -9 % at 1280 patches, -2 .. -3.5 % at 320),
-    regression, one GPU, an even batch, a 16-bit compute mode, no explicit launch-form argument.  dim 192: its own form is the
-    side-stream step (the split loses 4 % at B = 64); dim 768: -0.6 .. -1.7 %, not enabled."""
-    return bool(dim == 384 and task == "regression" and not has_process_group and not f32 and not explicit_form
+    was MEASURED faster by more than the spread between boxes (profiles/r06_split_batch.txt) -- regression, one GPU, an even batch,
+    a 16-bit compute mode, no explicit launch-form argument, and
+      * dim 384 (SiT-small): -8 .. -9 % at 1280 patches, -2 .. -3.5 % at 320;
+      * dim 192 (SiT-tiny) when the batch has more tokens than ONE round of the fused kernels' 96-row workgroups (256 x 96 = 24 576):
+        B = 128 / 256 / 512 on 320 patches -11 / -6 / -4 %, B = 32 on 1280 patches -8 % against the side-stream step.  At BASELINE's
+        B = 64 (20 544 tokens: single-wave kernels) the side-stream step is the faster form (the split loses 4 %).
+    dim 768: -0.6 .. -1.7 %, not enabled."""
+    wide = dim == 384 or (dim == 192 and tokens > 256 * 96)
+    return bool(wide and task == "regression" and not has_process_group and not f32 and not explicit_form
                 and batch_size >= 2 and batch_size % 2 == 0)
 
 
 def make_engine(model, batch_size, **kw):
     """The engine form measured fastest for the configuration: SplitTrainEngine (two concurrent half-batch steps) for a dim-384
-    regression model on one GPU with an even batch -- SiT-small, BASELINE config 3 -- TrainEngine otherwise (split_batch_by_default).
+    regression model on one GPU with an even batch -- SiT-small, BASELINE config 3 -- and for SiT-tiny batches of more than one
+    round of workgroups; TrainEngine otherwise (split_batch_by_default).
     Explicit launch-form arguments (use_graph=False, wgrad_overlap, bwd_slices) select the plain engine."""
     task = kw.get("task", "regression")
     sit = model.transformer if task == "mpp" else model
     explicit = kw.get("use_graph") is False or kw.get("wgrad_overlap") is not None or kw.get("bwd_slices") is not None
     if split_batch_by_default(getattr(sit, "dim", 0), batch_size, task, kw.get("process_group") is not None,
-                              rt.dtype_code(sit.compute_dtype) == rt.F32, explicit):
+                              rt.dtype_code(sit.compute_dtype) == rt.F32, explicit,
+                              tokens=batch_size * (getattr(sit, "num_patches", 0) + 1)):
         return SplitTrainEngine(model, batch_size, **kw)
     return TrainEngine(model, batch_size, **kw)

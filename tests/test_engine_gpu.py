@@ -498,8 +498,9 @@ def test_mpp_engine_config5_benchmarked_form_against_cpu_oracle(pk, dtype):
     assert eng.nonfinite_count == 0
 
 
-@pytest.mark.parametrize("dtype,optimizer", [("f32", "sgd"), ("bf16", "sgd"), ("f16", "sgd"), ("bf16", "adamw")])
-def test_split_engine_matches_whole_batch_engine(pk, dtype, optimizer):
+@pytest.mark.parametrize("size,dtype,optimizer", [("small", "f32", "sgd"), ("small", "bf16", "sgd"), ("small", "f16", "sgd"),
+                                                  ("small", "bf16", "adamw"), ("tiny", "bf16", "sgd"), ("tiny", "f16", "sgd")])
+def test_split_engine_matches_whole_batch_engine(pk, size, dtype, optimizer):
     """Round 6: engine.SplitTrainEngine -- the batch as two concurrent half-batch steps on two streams, two gradient buffers, ONE
     optimizer pass over both (sitk_*_step_dev with grad2; the loss and every gradient are the means of the halves') -- against the
     whole-batch TrainEngine on the same batches: three steps of SGD(momentum 0.9, weight decay) / AdamW from the same weights
@@ -508,7 +509,7 @@ def test_split_engine_matches_whole_batch_engine(pk, dtype, optimizer):
     scale each half picks: losses to 2e-6, every parameter's three-step update to 2e-4 of its norm."""
     sit, _, engine = pk
     B, lr = 8, 1e-5                                       # (bench.py's rate: a stable trajectory, so that the forms can be compared)
-    kw = dict(sit_oracle.MODEL_SIZES["small"], num_patches=320, num_vertices=153, num_channels=4)
+    kw = dict(sit_oracle.MODEL_SIZES[size], num_patches=320, num_vertices=153, num_channels=4)   # (tiny: the fused dim-192 kernels)
     kw["depth"] = 2
     g = torch.Generator(device=DEV).manual_seed(11)
     xs = [torch.randn((B, 40962, 4), device=DEV, generator=g) for _ in range(3)]

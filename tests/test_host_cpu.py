@@ -242,7 +242,9 @@ def test_make_engine_rule_is_the_measured_one(sitk_pkg):
     from sitk import engine
     rule = engine.split_batch_by_default
     assert rule(384, 32) and rule(384, 64)                                   # BASELINE config 3 and SiT-small on 320 patches
-    assert not rule(192, 64)                                                 # the tiny model: the side-stream step (the split loses there)
+    assert not rule(192, 64, tokens=64 * 321)                                # BASELINE config 2: the side-stream step (the split loses 4 % there)
+    assert rule(192, 128, tokens=128 * 321) and rule(192, 32, tokens=32 * 1281)      # more than one round of workgroups: -11 % / -8 %
+    assert not rule(192, 128, tokens=128 * 321, has_process_group=True)
     assert not rule(768, 32) and not rule(768, 32, task="mpp")              # base: -0.6 .. -1.7 %, inside the boxes' spread
     assert not rule(384, 32, task="mpp")                                     # masked patch pre-training: not built
     assert not rule(384, 32, has_process_group=True)                         # data parallel: the bucketed form
