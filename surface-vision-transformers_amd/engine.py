@@ -1063,7 +1063,8 @@ class SplitTrainEngine:
     and two half-batch steps side by side fill each other's gaps: measured on MI355X (tools/dual_engine.py,
     profiles/r06_split_batch.txt) SiT-small on 1280 patches, B = 32: 15.09 -> 13.87 ms per step (-8 %), on 320 patches, B = 64:
     6.82 -> 6.58 (-3.5 %); SiT-base: -0.6 .. -1.7 % (its grids have enough rounds of their own); four parts: slower than one.  The
-    tiny model's kernels are single-wave grids: nothing to fill (2.45 = 2.45 ms; its own form is the side-stream step).
+    tiny model at BASELINE's B = 64 runs single-wave grids: nothing to fill (its own form is the side-stream step; the split loses
+    4 % there) -- but above one round of workgroups it gains like the wide models (B = 128 / 256: -12 / -9 %).
 
     Two TrainEngines over the SAME module share one parameter buffer (FlatParams(share=...)); each owns its activations, its
     hipGraph, its stream and a gradient buffer of the same layout, and runs gather -> forward -> loss -> backward -> weight
